@@ -1,0 +1,291 @@
+"""Generate ``tests/golden/*.npz`` by EXECUTING the reference's own functions.
+
+TEST INFRASTRUCTURE ONLY; runs in the build container only (needs
+``/root/reference``).  Usage::
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+The reference modules are imported from where they lie under placeholder modules
+for the absent third-party packages (``oracle/_refstub.py``).  What is executed,
+unmodified, is the reference source of
+
+* ``transform._make_marray`` / ``_unpack_marray`` / ``_make_ssarray``
+* ``transform.MModeTransform.process`` / ``MModeInverseTransform.process``
+  (on duck-typed containers: the arithmetic at ``transform.py:594-639`` and
+  ``:756-790`` is the reference's own)
+* ``mapmaker.pinv_svd`` and the three ``_solve_m`` methods (against a duck-typed
+  beam-transfer object supplying seeded synthetic ``beam_m`` tiles).
+
+Fixtures hold inputs and the reference's outputs only -- no reference source.
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def crandn(rng, shape, dtype=np.complex128):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dtype)
+
+
+# --------------------------------------------------------------------------- containers
+class _Arr(np.ndarray):
+    @property
+    def local_array(self):
+        return self.view(np.ndarray)
+
+
+class _DS:
+    def __init__(self, arr):
+        self.arr = arr.view(_Arr)
+
+    def __getitem__(self, k):
+        return self.arr[k]
+
+    def __setitem__(self, k, v):
+        self.arr[k] = v
+
+    @property
+    def shape(self):
+        return self.arr.shape
+
+
+class _FakeCont:
+    comm = None
+
+    def redistribute(self, axis):
+        pass
+
+
+class FakeSiderealStream(_FakeCont):
+    def __init__(self, vis=None, weight=None, ra=None, axes_from=None, attrs_from=None, **kw):
+        if vis is None:
+            mm = axes_from
+            nfreq, nstack = mm.vis.shape[2:]
+            vis = np.zeros((nfreq, nstack, ra), np.complex64)
+            weight = np.zeros((nfreq, nstack, ra), np.float32)
+        self.vis = _DS(vis)
+        self.weight = _DS(weight)
+        self.attrs = {}
+
+
+class FakeMModes(_FakeCont):
+    def __init__(self, mmax=None, oddra=None, axes_from=None, attrs_from=None, comm=None, vis=None, weight=None):
+        if vis is None:
+            shp = axes_from.vis.shape[:-1]
+            vis = np.zeros((mmax + 1, 2, *shp), np.complex128)
+            weight = np.zeros((mmax + 1, 2, *shp), np.float64)
+        self.vis = _DS(vis)
+        self.weight = _DS(weight)
+        self.attrs = {"oddra": bool(oddra)}
+        self.mmax = vis.shape[0] - 1
+        self.oddra = bool(oddra)
+
+
+class _FakeContainers:
+    SiderealStream = FakeSiderealStream
+    MModes = FakeMModes
+
+    class HybridVisStream(_FakeCont):
+        pass
+
+    class HybridVisMModes(_FakeCont):
+        pass
+
+
+class _Tel:
+    def __init__(self, lmax, mmax, nfreq, npol=4):
+        self.lmax = lmax
+        self.mmax = mmax
+        self.nfreq = nfreq
+        self.num_pol_sky = npol
+        self.frequencies = np.linspace(400.0, 800.0, nfreq, endpoint=False)
+
+
+class _BT:
+    """Duck-typed beam-transfer object serving seeded tiles with the l<m zeros."""
+
+    def __init__(self, npairs, lmax, nfreq, seed, npol=4):
+        self.telescope = _Tel(lmax, lmax, nfreq, npol)
+        self.npairs = npairs
+        self.ntel = 2 * npairs
+        self.nsky = npol * (lmax + 1)
+        self.seed = seed
+        self.npol = npol
+
+    def beam_m(self, m, fi=None):
+        rng = np.random.default_rng([self.seed, m, fi])
+        lmax = self.telescope.lmax
+        b = crandn(rng, (2, self.npairs, self.npol, lmax + 1)) / np.sqrt(self.ntel)
+        b[..., :m] = 0.0
+        return b
+
+
+def gen_transform(transform, out):
+    rng = np.random.default_rng(1001)
+    cases = {}
+    idx = 0
+    for N in (16, 15):
+        for mmax in (N // 2, N // 2 - 3, N):
+            for lead in ((3, 5), (2, 2, 3, 2)):
+                ts = crandn(rng, (*lead, N), np.complex64)
+                mm = transform._make_marray(ts, mmax=mmax, use_fftw=False)
+                # also the write-into-complex128 form used by MModeTransform (:623-624)
+                mm128 = np.zeros((mmax + 1, 2, *lead), np.complex128)
+                transform._make_marray(ts, mm128, use_fftw=False)
+                cases[f"c{idx}_ts"] = ts
+                cases[f"c{idx}_mmax"] = np.int64(mmax)
+                cases[f"c{idx}_out64"] = mm
+                cases[f"c{idx}_out128"] = mm128
+                idx += 1
+    # complex128 input (exact path, used for tight-tolerance checks of the packing)
+    for N, mmax in ((16, 8), (15, 7), (12, 4), (9, 11)):
+        ts = crandn(rng, (2, 3, N), np.complex128)
+        mm = transform._make_marray(ts, mmax=mmax, dtype=np.complex128, use_fftw=False)
+        cases[f"c{idx}_ts"] = ts
+        cases[f"c{idx}_mmax"] = np.int64(mmax)
+        cases[f"c{idx}_out64"] = mm
+        cases[f"c{idx}_out128"] = mm
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "transform_make_marray.npz"), **cases)
+
+    # inverse: _unpack_marray / _make_ssarray incl. n= resampling and the Nyquist rule
+    cases = {}
+    idx = 0
+    for N, mmax, n in ((16, 8, None), (15, 7, None), (16, 8, 12), (16, 8, 24), (15, 7, 9), (15, 7, 32), (16, 5, None), (15, 4, 15)):
+        ts = crandn(rng, (2, 3, N), np.complex128)
+        mm = transform._make_marray(ts, mmax=mmax, dtype=np.complex128, use_fftw=False)
+        up = transform._unpack_marray(mm, n=n)
+        ss = transform._make_ssarray(mm, n=n)
+        cases[f"c{idx}_mm"] = mm
+        cases[f"c{idx}_n"] = np.int64(-1 if n is None else n)
+        cases[f"c{idx}_unpack"] = up
+        cases[f"c{idx}_ss"] = ss
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "transform_unpack.npz"), **cases)
+
+    # task level: MModeTransform.process / MModeInverseTransform.process on fake containers
+    transform.containers = _FakeContainers
+    transform.mpiarray.MPIArray.wrap = staticmethod(lambda a, axis=0, comm=None: a)
+    cases = {}
+    idx = 0
+    for nra, tel_mmax, window in ((16, None, False), (15, None, False), (16, 5, False), (16, None, True), (15, 6, True), (32, 40, False)):
+        vis = crandn(rng, (3, 4, nra), np.complex64)
+        w = rng.uniform(0.5, 1.5, (3, 4, nra)).astype(np.float32)
+        w[rng.uniform(size=w.shape) < 0.1] = 0.0
+        w[1, 2, :] = 0.0  # a fully flagged baseline
+        task = transform.MModeTransform.__new__(transform.MModeTransform)
+        task.remove_integration_window = window
+        task.use_fftw = False
+        task.telescope = None if tel_mmax is None else _Tel(tel_mmax, tel_mmax, 3)
+        ma = task.process(FakeSiderealStream(vis.copy(), w.copy()))
+        cases[f"c{idx}_vis"] = vis
+        cases[f"c{idx}_weight"] = w
+        cases[f"c{idx}_mmax"] = np.int64(-1 if tel_mmax is None else tel_mmax)
+        cases[f"c{idx}_window"] = np.bool_(window)
+        cases[f"c{idx}_mvis"] = ma.vis.arr.view(np.ndarray)
+        cases[f"c{idx}_mweight"] = ma.weight.arr.view(np.ndarray)
+        cases[f"c{idx}_oddra"] = np.bool_(ma.attrs["oddra"])
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "transform_mmode_task.npz"), **cases)
+
+    cases = {}
+    idx = 0
+    for nra_in, mmax, nra_out, window in ((16, 8, None, False), (15, 7, None, False), (16, 8, 24, False), (16, 8, 10, True), (15, 7, 15, True)):
+        ts = crandn(rng, (3, 4, nra_in), np.complex128)
+        mv = transform._make_marray(ts, mmax=mmax, dtype=np.complex128, use_fftw=False)
+        mw = np.broadcast_to(rng.uniform(0.5, 1.5, (1, 1, 3, 4)), mv.shape).copy()
+        task = transform.MModeInverseTransform.__new__(transform.MModeInverseTransform)
+        task.nra = nra_out
+        task.apply_integration_window = window
+        mcont = FakeMModes(oddra=bool(nra_in % 2), vis=mv.copy(), weight=mw.copy())
+        ss = task.process(mcont)
+        cases[f"c{idx}_mvis"] = mv
+        cases[f"c{idx}_mweight"] = mw
+        cases[f"c{idx}_oddra"] = np.bool_(nra_in % 2)
+        cases[f"c{idx}_nra"] = np.int64(-1 if nra_out is None else nra_out)
+        cases[f"c{idx}_window"] = np.bool_(window)
+        cases[f"c{idx}_vis"] = ss.vis.arr.view(np.ndarray)
+        cases[f"c{idx}_weight"] = ss.weight.arr.view(np.ndarray)
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "transform_inverse_task.npz"), **cases)
+
+
+def gen_mapmaker(mapmaker, out):
+    rng = np.random.default_rng(2002)
+
+    # pinv_svd: full rank, rank-deficient by the rcond rule, by the acond rule
+    cases = {}
+    A = crandn(rng, (12, 7))
+    u, s, vh = np.linalg.svd(crandn(rng, (10, 14)), full_matrices=False)
+    s_r = np.array([5.0, 3.0, 1.0, 0.5, 0.2, 0.05, 6e-3, 4e-3, 1e-3, 1e-5])  # rcond cut at 5e-3
+    B = (u * s_r) @ vh
+    s_a = np.array([0.05, 0.03, 0.01, 5e-3, 2e-3, 1e-3, 3e-4, 1.5e-4, 5e-5, 1e-6])  # acond cut 1e-4
+    C = (u * s_a) @ vh
+    for i, M in enumerate((A, B, C, A.real.copy())):
+        cases[f"c{i}_M"] = M
+        cases[f"c{i}_pinv"] = mapmaker.pinv_svd(M)
+    cases["ncase"] = np.int64(4)
+    np.savez_compressed(os.path.join(out, "mapmaker_pinv_svd.npz"), **cases)
+
+    # _solve_m for the three map-makers
+    cases = {}
+    idx = 0
+    # (npairs, lmax): ntel > nsky (Wiener branch 1) and ntel <= nsky (branch 2)
+    for npairs, lmax, seed in ((20, 5, 31), (7, 9, 32), (9, 8, 33)):
+        bt = _BT(npairs, lmax, 3, seed)
+        tasks = {}
+        for name, cls in (("dirty", mapmaker.DirtyMapMaker), ("ml", mapmaker.MaximumLikelihoodMapMaker), ("wiener", mapmaker.WienerMapMaker)):
+            t = cls.__new__(cls)
+            t.beamtransfer = bt
+            t.bt_cache = None
+            t.prior_amp = 1.0
+            t.prior_tilt = 0.5
+            tasks[name] = t
+        for m in (0, 2, lmax):
+            for f in (0, 2):
+                v = crandn(rng, (2, npairs))
+                Ni = rng.uniform(0.5, 1.5, (2, npairs))
+                Ni[rng.uniform(size=Ni.shape) < 0.15] = 0.0
+                if m == 2:
+                    Ni *= 25.0  # move the singular values relative to acond
+                cases[f"c{idx}_bm"] = bt.beam_m(m, fi=f)
+                cases[f"c{idx}_m"] = np.int64(m)
+                cases[f"c{idx}_v"] = v
+                cases[f"c{idx}_Ni"] = Ni
+                for name, t in tasks.items():
+                    cases[f"c{idx}_{name}"] = t._solve_m(m, f, v.copy(), Ni.copy())
+                # non-default prior
+                tw = tasks["wiener"]
+                tw.prior_amp, tw.prior_tilt = 2.5, 1.25
+                cases[f"c{idx}_wiener_p"] = tw._solve_m(m, f, v.copy(), Ni.copy())
+                tw.prior_amp, tw.prior_tilt = 1.0, 0.5
+                idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "mapmaker_solve_m.npz"), **cases)
+
+
+def main():
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle._refstub import load_reference
+
+    transform, mapmaker = load_reference()
+    os.makedirs(GOLDEN, exist_ok=True)
+    gen_transform(transform, GOLDEN)
+    gen_mapmaker(mapmaker, GOLDEN)
+    for f in sorted(os.listdir(GOLDEN)):
+        print(f, os.path.getsize(os.path.join(GOLDEN, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""Oracle vs. the golden vectors produced by the reference's own functions.
+
+The fixtures under tests/golden/ were written by oracle/gen_golden.py, which executes
+the reference source (transform.py / mapmaker.py) in the build container.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mapmaker as omm
+from oracle import transform as otr
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_make_marray(golden_dir):
+    g = _load(golden_dir, "transform_make_marray.npz")
+    for i in range(int(g["ncase"])):
+        ts, mmax = g[f"c{i}_ts"], int(g[f"c{i}_mmax"])
+        dt = np.complex128 if ts.dtype == np.complex128 else None
+        out = otr.make_marray(ts, mmax=mmax, dtype=dt)
+        ref = g[f"c{i}_out64"]
+        assert out.dtype == ref.dtype and out.shape == ref.shape
+        # same algorithm, same FFT library, same precision: bit-exact
+        np.testing.assert_array_equal(out, ref)
+        mm = np.zeros((mmax + 1, 2, *ts.shape[:-1]), np.complex128)
+        otr.make_marray(ts, mm)
+        np.testing.assert_array_equal(mm, g[f"c{i}_out128"])
+
+
+def test_make_marray_fill_pattern(golden_dir):
+    """Which (m, sign) slots are filled: transform.py:678-679,701-703."""
+    ts = np.ones((1, 16), np.complex128) + 1j
+    for N, mmax, pos, neg in ((16, 8, 8, 7), (15, 7, 7, 7), (16, 5, 5, 5), (16, 12, 8, 7)):
+        rng = np.random.default_rng(N * 100 + mmax)
+        ts = rng.standard_normal((2, N)) + 1j * rng.standard_normal((2, N))
+        mm = otr.make_marray(ts, mmax=mmax, dtype=np.complex128)
+        filled_pos = np.nonzero(np.abs(mm[:, 0]).sum(axis=-1))[0]
+        filled_neg = np.nonzero(np.abs(mm[:, 1]).sum(axis=-1))[0]
+        assert filled_pos.max() == pos and filled_neg.max() == neg and filled_neg.min() == 1
+
+
+def test_make_marray_errors():
+    ts = np.zeros((2, 3, 8), np.complex64)
+    with pytest.raises(ValueError):
+        otr.make_marray(ts)
+    with pytest.raises(ValueError):
+        otr.make_marray(ts, np.zeros((5, 2, 2, 3), np.complex64), mmax=4)
+    with pytest.raises(ValueError):
+        otr.make_marray(ts, np.zeros((5, 2, 3, 2), np.complex64))
+
+
+def test_unpack_and_ssarray(golden_dir):
+    g = _load(golden_dir, "transform_unpack.npz")
+    for i in range(int(g["ncase"])):
+        n = int(g[f"c{i}_n"])
+        n = None if n < 0 else n
+        np.testing.assert_array_equal(otr.unpack_marray(g[f"c{i}_mm"], n=n), g[f"c{i}_unpack"])
+        np.testing.assert_array_equal(otr.make_ssarray(g[f"c{i}_mm"], n=n), g[f"c{i}_ss"])
+
+
+def test_mmode_task(golden_dir):
+    g = _load(golden_dir, "transform_mmode_task.npz")
+    for i in range(int(g["ncase"])):
+        mmax = int(g[f"c{i}_mmax"])
+        mv, mw = otr.mmode_transform(
+            g[f"c{i}_vis"], g[f"c{i}_weight"], None if mmax < 0 else mmax, bool(g[f"c{i}_window"])
+        )
+        np.testing.assert_array_equal(mv, g[f"c{i}_mvis"])
+        np.testing.assert_array_equal(mw, g[f"c{i}_mweight"])
+        assert bool(g[f"c{i}_oddra"]) == bool(g[f"c{i}_vis"].shape[-1] % 2)
+
+
+def test_inverse_task(golden_dir):
+    g = _load(golden_dir, "transform_inverse_task.npz")
+    for i in range(int(g["ncase"])):
+        nra = int(g[f"c{i}_nra"])
+        vis, w = otr.mmode_inverse_transform(
+            g[f"c{i}_mvis"], g[f"c{i}_mweight"], bool(g[f"c{i}_oddra"]), None if nra < 0 else nra, bool(g[f"c{i}_window"])
+        )
+        np.testing.assert_array_equal(vis, g[f"c{i}_vis"])
+        np.testing.assert_array_equal(w, g[f"c{i}_weight"])
+
+
+def test_pinv_svd(golden_dir):
+    g = _load(golden_dir, "mapmaker_pinv_svd.npz")
+    ranks = []
+    for i in range(int(g["ncase"])):
+        p = omm.pinv_svd(g[f"c{i}_M"])
+        np.testing.assert_allclose(p, g[f"c{i}_pinv"], rtol=0, atol=1e-12 * np.abs(g[f"c{i}_pinv"]).max())
+        ranks.append(np.linalg.matrix_rank(p, tol=1e-9 * np.abs(p).max()))
+    assert ranks[0] == 7 and ranks[1] == 7 and ranks[2] == 8  # rcond and acond cuts bite
+
+
+def test_solve_m(golden_dir):
+    g = _load(golden_dir, "mapmaker_solve_m.npz")
+    n = int(g["ncase"])
+    assert n == 18
+    for i in range(n):
+        bm, m, v, Ni = g[f"c{i}_bm"], int(g[f"c{i}_m"]), g[f"c{i}_v"], g[f"c{i}_Ni"]
+        for name, got in (
+            ("dirty", omm.dirty_solve(bm, v, Ni)),
+            ("ml", omm.ml_solve(bm, v, Ni)),
+            ("wiener", omm.wiener_solve(bm, m, v, Ni)),
+            ("wiener_p", omm.wiener_solve(bm, m, v, Ni, 2.5, 1.25)),
+        ):
+            ref = g[f"c{i}_{name}"]
+            assert got.shape == ref.shape
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * max(np.abs(ref).max(), 1e-30), err_msg=f"case {i} {name}")
+            if name == "ml":  # the SVD leaves O(eps) dust in the structurally-zero l<m slots (so does the reference)
+                assert np.abs(got[:, :m]).max(initial=0) < 1e-12 and np.abs(ref[:, :m]).max(initial=0) < 1e-12
+            else:
+                assert np.all(got[:, :m] == 0) and np.all(ref[:, :m] == 0)
+
+
+def test_find_keys():
+    assert omm.find_keys([400.0, 401.0, 402.0], [402.0, 400.0]) == [2, 0]
+    assert omm.find_keys([400.0, 401.0], [399.0]) == [None]
+    with pytest.raises(ValueError):
+        omm.find_keys([400.0, 401.0], [399.0], require_match=True)
