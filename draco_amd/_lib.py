@@ -1,0 +1,97 @@
+"""ctypes binding of ``libdraco_amd.so`` (the C ABI in ``include/draco_amd.h``).
+
+The binding is deliberately thin: argument marshalling and status -> exception
+translation only.  If the shared library is missing this module raises at import: the
+product path never falls back to a CPU implementation.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdraco_amd.so")
+
+DMM_C64, DMM_C128 = 0, 1
+DMM_B_FULL, DMM_B_PACKED = 0, 1
+DMM_E_ARG, DMM_E_UNSUPPORTED, DMM_E_NOMEM, DMM_E_STATE = -1, -2, -3, -4
+DMM_MAX_NRA = 8192
+
+
+class DmmError(RuntimeError):
+    """A call into libdraco_amd.so failed (HIP error or unsupported request)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libdraco_amd status {code}: {msg}")
+        self.code = code
+
+
+class dmm_tile(C.Structure):
+    _fields_ = [("b_off", C.c_int64), ("m", C.c_int32), ("f", C.c_int32)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C draco_amd/csrc`.  draco_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_SIGS = {
+    "dmm_version": (C.c_int, []),
+    "dmm_last_error": (C.c_char_p, []),
+    "dmm_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "dmm_ctx_destroy": (_i, [_vp]),
+    "dmm_ctx_set_stream": (_i, [_vp, _vp]),
+    "dmm_ctx_sync": (_i, [_vp]),
+    "dmm_timer_start": (_i, [_vp]),
+    "dmm_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "dmm_mfft_pack": (_i, [_vp, _vp, _i64, _i, _vp, _i, _i, _vp]),
+    "dmm_mmode_weight": (_i, [_vp, _vp, _i64, _i, _vp, _i, _vp]),
+    "dmm_mifft_unpack": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
+    "dmm_mrow_is_zero": (_i, [_vp, _vp, _i, _i64, _i, _i, C.POINTER(_i)]),
+    "dmm_solve_plan_create": (_i, [_vp, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "dmm_plan_destroy": (_i, [_vp]),
+    "dmm_plan_b_bytes": (_i64, [_vp]),
+    "dmm_dirty_run": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "dmm_wiener_workspace_bytes": (_i64, [_vp]),
+    "dmm_wiener_run": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
+    "dmm_ml_workspace_bytes": (_i64, [_vp]),
+    "dmm_ml_run": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
+    "dmm_project_run": (_i, [_vp, _vp, _vp, _vp]),
+    "dmm_alm2map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dmm_map2alm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dmm_synth_beam_fill": (_i, [_vp, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, C.c_uint64, _vp]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library disagree
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = tuple(_SIGS)
+
+
+def check(rc: int) -> None:
+    """Translate a status code into an exception (0 = ok)."""
+    if rc == 0:
+        return
+    msg = (lib.dmm_last_error() or b"").decode("utf-8", "replace")
+    if rc == DMM_E_ARG:
+        raise ValueError(f"libdraco_amd: {msg}")
+    if rc == DMM_E_NOMEM:
+        raise MemoryError(f"libdraco_amd: {msg}")
+    raise DmmError(rc, msg)
+
+
+def tile_array(ms, fs, offs):
+    """Pack parallel sequences into a ctypes array of ``dmm_tile``."""
+    n = len(ms)
+    arr = (dmm_tile * n)()
+    for i in range(n):
+        arr[i].b_off = int(offs[i])
+        arr[i].m = int(ms[i])
+        arr[i].f = int(fs[i])
+    return arr

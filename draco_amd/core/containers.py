@@ -1,0 +1,253 @@
+"""Minimal container duck-types for the m-mode path.
+
+These mirror the parts of the reference containers the path touches
+(``draco/core/containers.py``): dataset names, axis order and dtypes, ``index_map``,
+``attrs`` and the ``axes_from`` / ``attrs_from`` constructor protocol.  They are not a
+re-implementation of caput's memh5 containers [3P]; HDF5 I/O, MPI distribution and
+selections are out of scope.
+
+* :class:`SiderealStream`  ``containers.py:489-593``  vis c64 ``[freq, stack, ra]``, weight f32
+* :class:`MModes`          ``containers.py:1167-1193`` vis c128 ``[m, msign, freq, stack]``, weight f64
+* :class:`Map`             ``containers.py:470-486`` (+ cora ``Map`` [3P]) map f64 ``[freq, pol, pixel]``
+
+A dataset may live on the host (ndarray), on the GPU (torch tensor) or both; tasks of
+this package hand device-resident containers to each other so that a
+``MModeTransform -> DirtyMapMaker`` chain never crosses PCIe.  ``ds[:]`` always gives
+NumPy (copying back once if needed).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+class Dataset:
+    """An array that is valid on the host, on a device, or both."""
+
+    def __init__(self, host=None, dev=None, attrs=None):
+        assert host is not None or dev is not None
+        self._host = host
+        self._dev = dev
+        self.attrs = dict(attrs or {})
+
+    # -- shape/dtype without forcing a copy
+    @property
+    def shape(self):
+        return tuple(self._host.shape) if self._host is not None else tuple(self._dev.shape)
+
+    @property
+    def dtype(self):
+        if self._host is not None:
+            return self._host.dtype
+        import torch
+
+        return np.dtype(
+            {
+                torch.complex64: np.complex64,
+                torch.complex128: np.complex128,
+                torch.float32: np.float32,
+                torch.float64: np.float64,
+            }[self._dev.dtype]
+        )
+
+    @property
+    def on_device(self):
+        return self._dev is not None
+
+    def host(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self._dev.detach().cpu().numpy()
+        return self._host
+
+    def device(self, ctx):
+        """Device tensor on ``ctx`` (uploading the host copy the first time)."""
+        if self._dev is None or self._dev.device != ctx.device:
+            self._dev = ctx.to_device(self.host())
+        return self._dev
+
+    def set_device(self, t):
+        """Make a device tensor the (only) valid copy."""
+        self._dev = t
+        self._host = None
+
+    def __getitem__(self, key):
+        return self.host()[key]
+
+    def __setitem__(self, key, value):
+        h = self.host()
+        h[key] = value
+        self._dev = None  # host copy is now the authority
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.host()
+        return a if dtype is None else a.astype(dtype)
+
+    @property
+    def local_array(self):  # MPIArray compatibility (single process)
+        return self.host()
+
+
+def _freq_map(freq):
+    """Build the structured ``index_map['freq']`` (fields ``centre``, ``width``)."""
+    if freq is None:
+        return None
+    f = np.asarray(freq)
+    if f.dtype.names and "centre" in f.dtype.names:
+        return f
+    out = np.zeros(f.shape[0], dtype=[("centre", np.float64), ("width", np.float64)])
+    out["centre"] = f
+    out["width"] = np.abs(np.diff(f)).mean() if f.shape[0] > 1 else 1.0
+    return out
+
+
+class ContainerBase:
+    """Axes + datasets + attrs; ``axes_from`` / ``attrs_from`` copy like caput does."""
+
+    _axes: tuple = ()
+    _dataset_spec: dict = {}
+
+    def __init__(self, axes_from=None, attrs_from=None, comm=None, distributed=True, allocate=True, **axes):
+        self.index_map = {}
+        self.attrs = {}
+        self.comm = comm
+        self.reverse_map = {}
+        if axes_from is not None:
+            for ax in self._axes:
+                if ax in axes_from.index_map and ax not in axes:
+                    self.index_map[ax] = axes_from.index_map[ax]
+            if "stack" in getattr(axes_from, "reverse_map", {}):
+                self.reverse_map["stack"] = axes_from.reverse_map["stack"]
+        for ax, val in axes.items():
+            if val is None:
+                continue
+            if ax == "freq":
+                val = _freq_map(val)
+            elif isinstance(val, (int, np.integer)):
+                val = np.arange(int(val))
+            self.index_map[ax] = np.asarray(val)
+        if attrs_from is not None:
+            self.attrs.update(attrs_from.attrs)
+        self.datasets = {}
+        for name, spec in self._dataset_spec.items():
+            missing = [a for a in spec["axes"] if a not in self.index_map]
+            if missing:
+                raise ValueError(f"{type(self).__name__}: axes {missing} are not defined")
+            shape = tuple(len(self.index_map[a]) for a in spec["axes"])
+            if allocate:  # allocate=False: the producing task attaches device tensors instead
+                self.datasets[name] = Dataset(host=np.zeros(shape, dtype=spec["dtype"]), attrs={"axis": spec["axes"]})
+
+    def redistribute(self, axis):  # single process: nothing to move
+        return None
+
+    def dataset_shape(self, name):
+        return tuple(len(self.index_map[a]) for a in self._dataset_spec[name]["axes"])
+
+    def attach(self, name, dev_tensor):
+        """Attach a device tensor as dataset ``name`` (shape/dtype checked against the spec)."""
+        spec = self._dataset_spec[name]
+        if tuple(dev_tensor.shape) != self.dataset_shape(name):
+            raise ValueError(f"{name}: shape {tuple(dev_tensor.shape)} != {self.dataset_shape(name)}")
+        ds = Dataset(dev=dev_tensor, attrs={"axis": spec["axes"]})
+        if ds.dtype != np.dtype(spec["dtype"]):
+            raise ValueError(f"{name}: dtype {ds.dtype} != {np.dtype(spec['dtype'])}")
+        self.datasets[name] = ds
+        return ds
+
+    def __getitem__(self, name):
+        return self.datasets[name]
+
+    def __contains__(self, name):
+        return name in self.datasets
+
+
+class _FreqMixin:
+    @property
+    def freq(self):
+        return self.index_map["freq"]["centre"]
+
+
+class _VisMixin:
+    @property
+    def vis(self):
+        return self.datasets["vis"]
+
+    @property
+    def weight(self):
+        return self.datasets["vis_weight"]
+
+
+class SiderealStream(ContainerBase, _FreqMixin, _VisMixin):
+    """``vis [freq, stack, ra]`` complex64 + ``vis_weight`` float32 (``containers.py:489-593``)."""
+
+    _axes = ("freq", "stack", "ra", "prod", "input")
+    _dataset_spec = {
+        "vis": {"axes": ["freq", "stack", "ra"], "dtype": np.complex64},
+        "vis_weight": {"axes": ["freq", "stack", "ra"], "dtype": np.float32},
+    }
+
+    def __init__(self, ra=None, stack=None, prod=None, input=None, reverse_map_stack=None, **kwargs):
+        if isinstance(ra, (int, np.integer)):
+            ra = np.linspace(0.0, 360.0, int(ra), endpoint=False)  # containers.py:407-410
+        if stack is None and prod is not None and kwargs.get("axes_from") is None:
+            stack = len(prod)  # VisContainer default: one stack entry per product
+        super().__init__(ra=ra, stack=stack, prod=prod, input=input, **kwargs)
+        if reverse_map_stack is not None:
+            self.reverse_map["stack"] = reverse_map_stack
+
+    @property
+    def ra(self):
+        return self.index_map["ra"]
+
+
+class MContainer(ContainerBase):
+    """m-mode containers: axes ``m``, ``msign`` and the ``oddra`` attribute (``containers.py:422-467``)."""
+
+    def __init__(self, mmax=None, oddra=None, **kwargs):
+        if mmax is not None:
+            kwargs["m"] = int(mmax) + 1
+        kwargs["msign"] = np.array(["+", "-"])
+        super().__init__(**kwargs)
+        if oddra is not None:
+            self.attrs["oddra"] = bool(oddra)
+        elif "oddra" not in self.attrs:
+            self.attrs["oddra"] = False
+
+    @property
+    def mmax(self) -> int:
+        return int(self.index_map["m"][-1])
+
+    @property
+    def oddra(self) -> bool:
+        return bool(self.attrs["oddra"])
+
+
+class MModes(MContainer, _FreqMixin, _VisMixin):
+    """``vis [m, msign, freq, stack]`` complex128 + ``vis_weight`` float64 (``containers.py:1167-1193``)."""
+
+    _axes = ("m", "msign", "freq", "stack", "prod", "input")
+    _dataset_spec = {
+        "vis": {"axes": ["m", "msign", "freq", "stack"], "dtype": np.complex128},
+        "vis_weight": {"axes": ["m", "msign", "freq", "stack"], "dtype": np.float64},
+    }
+
+
+class Map(ContainerBase, _FreqMixin):
+    """``map [freq, pol, pixel]`` float64, HEALPix RING (``containers.py:470-486``, cora ``Map`` [3P])."""
+
+    _axes = ("freq", "pol", "pixel")
+    _dataset_spec = {"map": {"axes": ["freq", "pol", "pixel"], "dtype": np.float64}}
+
+    def __init__(self, nside=None, polarisation=True, **kwargs):
+        if nside is not None:
+            kwargs["pixel"] = 12 * int(nside) ** 2
+        if "pol" not in kwargs:
+            kwargs["pol"] = np.array(["I", "Q", "U", "V"] if polarisation else ["I"])
+        super().__init__(**kwargs)
+
+    @property
+    def map(self):
+        return self.datasets["map"]
+
+    @property
+    def nside(self):
+        return int(round((len(self.index_map["pixel"]) // 12) ** 0.5))

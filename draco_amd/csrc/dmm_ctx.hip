@@ -1,0 +1,89 @@
+// Context, error reporting and the HIP-event stopwatch of the C ABI.
+#include <stdio.h>
+#include <string.h>
+
+#include "dmm_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int dmm_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" {
+
+int dmm_version(void) { return DMM_VERSION; }
+const char* dmm_last_error(void) { return g_err; }
+
+int dmm_ctx_create(int device, dmm_ctx** out) {
+  DMM_REQUIRE(out != nullptr, "dmm_ctx_create: ctx is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  DMM_HIP(hipGetDeviceCount(&ndev));
+  DMM_REQUIRE(device >= 0 && device < ndev, "dmm_ctx_create: device %d out of range (%d devices)", device, ndev);
+  DMM_HIP(hipSetDevice(device));
+  dmm_ctx* c = new (std::nothrow) dmm_ctx();
+  if (!c) return dmm_set_error(DMM_E_NOMEM, "dmm_ctx_create: out of host memory");
+  c->device = device;
+  hipDeviceProp_t prop;
+  DMM_HIP(hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  DMM_HIP(hipEventCreate(&c->ev0));
+  DMM_HIP(hipEventCreate(&c->ev1));
+  *out = c;
+  return DMM_OK;
+}
+
+static void free_tables(std::map<int, dmm_fft_tables>& m) {
+  for (auto& kv : m) {
+    if (kv.second.tw) (void)hipFree(kv.second.tw);
+    if (kv.second.chirp) (void)hipFree(kv.second.chirp);
+    if (kv.second.bfilt) (void)hipFree(kv.second.bfilt);
+  }
+  m.clear();
+}
+
+int dmm_ctx_destroy(dmm_ctx* c) {
+  if (!c) return DMM_OK;
+  (void)hipSetDevice(c->device);
+  free_tables(c->fft);
+  free_tables(c->ifft);
+  for (auto& kv : c->sht)
+    if (kv.second) (void)hipFree(kv.second);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+  return DMM_OK;
+}
+
+int dmm_ctx_set_stream(dmm_ctx* c, void* s) {
+  DMM_REQUIRE(c != nullptr, "dmm_ctx_set_stream: ctx is NULL");
+  c->stream = (hipStream_t)s;
+  return DMM_OK;
+}
+
+int dmm_ctx_sync(dmm_ctx* c) {
+  DMM_REQUIRE(c != nullptr, "dmm_ctx_sync: ctx is NULL");
+  DMM_HIP(hipStreamSynchronize(c->stream));
+  return DMM_OK;
+}
+
+int dmm_timer_start(dmm_ctx* c) {
+  DMM_REQUIRE(c != nullptr, "dmm_timer_start: ctx is NULL");
+  DMM_HIP(hipEventRecord(c->ev0, c->stream));
+  return DMM_OK;
+}
+
+int dmm_timer_stop(dmm_ctx* c, float* ms) {
+  DMM_REQUIRE(c != nullptr && ms != nullptr, "dmm_timer_stop: NULL argument");
+  DMM_HIP(hipEventRecord(c->ev1, c->stream));
+  DMM_HIP(hipEventSynchronize(c->ev1));
+  DMM_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return DMM_OK;
+}
+
+}  // extern "C"

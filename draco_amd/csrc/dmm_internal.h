@@ -1,0 +1,56 @@
+// Internal declarations shared by the HIP translation units of libdraco_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <map>
+#include <vector>
+
+#include "draco_amd.h"
+
+struct dmm_fft_tables {          // per transform length, built on first use
+  int n = 0;                     // nra
+  int M = 0;                     // FFT length actually run (n if power of two, else Bluestein length)
+  float2* tw = nullptr;          // [M/2] exp(-2 pi i k / M)
+  float2* chirp = nullptr;       // [n]   exp(-i pi k^2 / n)              (Bluestein only)
+  float2* bfilt = nullptr;       // [M]   FFT_M(conj chirp, wrapped)/M, bit-reversed order (Bluestein only)
+};
+
+struct dmm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 256;
+  std::map<int, dmm_fft_tables> fft;       // forward tables by nra
+  std::map<int, dmm_fft_tables> ifft;      // inverse tables by nra
+  std::map<int64_t, void*> sht;            // SHT geometry caches keyed by (nside,lmax,mmax)
+};
+
+struct dmm_plan {
+  dmm_ctx* ctx = nullptr;
+  int64_t ntile = 0;
+  int npairs = 0, npol = 0, lmax = 0, nfreq = 0, n_m = 0, b_dtype = 0, b_layout = 0;
+  std::vector<dmm_tile> tiles_h;
+  dmm_tile* tiles_d = nullptr;
+  int32_t* work_start_d = nullptr;   // [ntile+1] first column-block task of each tile (dirty)
+  int32_t* work_rows_d = nullptr;    // [ntile+1] first 64-row-block task of each tile (project)
+  int64_t nwork = 0, nwork_rows = 0;
+  int cols_per_block = 0;
+  int pair_ok = 0;                   // packed complex64 rows are 16-byte aligned: 2 columns per lane
+  int64_t b_bytes = 0;
+};
+
+int dmm_set_error(int code, const char* fmt, ...);
+#define DMM_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return dmm_set_error((int)e_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                        \
+  } while (0)
+#define DMM_REQUIRE(cond, ...)                                \
+  do {                                                        \
+    if (!(cond)) return dmm_set_error(DMM_E_ARG, __VA_ARGS__); \
+  } while (0)
+
+static inline bool dmm_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }

@@ -1,0 +1,523 @@
+// m-mode transform kernels: batched sidereal-time <-> m FFT fused with the +/-m
+// pack / unpack, plus the noise-weight reduction.
+//
+// Replaces (reference radiocosmology/draco):
+//   _make_marray            draco/analysis/transform.py:644-705  -> k_mfft_pack
+//   weight reduction        draco/analysis/transform.py:599-602,627,638-639 -> k_mmode_weight
+//   _unpack_marray/_make_ssarray  transform.py:814-851           -> k_mifft_unpack
+//
+// Design (gfx950): one workgroup transforms RB rows that are adjacent in the
+// (freq, baseline) order entirely inside LDS, so that the transposed store into
+// the m-major MModes layout [m, +/-, row] writes RB*16-byte contiguous segments
+// and the spectrum never makes a round trip through HBM.  Power-of-two lengths run
+// an in-place radix-2 decimation-in-frequency pass (natural in, bit-reversed out;
+// the pack stage reads through the bit reversal for free).  Every other length --
+// SimulateSidereal always produces the odd length 2*mmax+1 (stream.py:76) -- runs
+// Bluestein's chirp-z inside the same LDS image: DIF forward, pointwise filter stored
+// in bit-reversed order, DIT inverse, so no reordering pass exists anywhere.
+// The forward transform is single precision like the reference's complex64 FFT
+// (transform.py:689); the inverse is double precision like the reference's complex128
+// ifft (transform.py:817).
+#include <math.h>
+
+#include <vector>
+
+#include "dmm_internal.h"
+
+namespace {
+
+template <typename T>
+struct C {
+  T x, y;
+};
+template <typename T>
+__device__ __forceinline__ C<T> cmul(C<T> a, C<T> b) {
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <typename T>
+__device__ __forceinline__ C<T> cmulc(C<T> a, C<T> b) {  // a * conj(b)
+  return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+}
+
+constexpr int kThreads = 256;
+
+// ---- block-cooperative in-LDS transforms over RB rows of length M (pitch P)
+// DIF: natural order in, bit-reversed order out, forward sign (tw = exp(-2 pi i k/M)).
+template <typename T>
+__device__ void fft_dif(C<T>* buf, const C<T>* tw, int RB, int M, int logM, int P) {
+  const int halfM = M >> 1;
+  for (int s = logM - 1; s >= 0; --s) {
+    const int half = 1 << s;
+    for (int b = threadIdx.x; b < RB * halfM; b += kThreads) {
+      const int r = b / halfM, k = b - r * halfM;
+      const int t = k & (half - 1);
+      const int j0 = ((k >> s) << (s + 1)) | t;
+      C<T>* p = buf + r * P + j0;
+      const C<T> a = p[0], c = p[half];
+      const C<T> w = tw[t << (logM - 1 - s)];
+      p[0] = {a.x + c.x, a.y + c.y};
+      p[half] = cmul<T>({a.x - c.x, a.y - c.y}, w);
+    }
+    __syncthreads();
+  }
+}
+// DIT: bit-reversed order in, natural order out; CONJ selects exp(+2 pi i k/M).
+template <typename T, bool CONJ>
+__device__ void fft_dit(C<T>* buf, const C<T>* tw, int RB, int M, int logM, int P) {
+  const int halfM = M >> 1;
+  for (int s = 0; s < logM; ++s) {
+    const int half = 1 << s;
+    for (int b = threadIdx.x; b < RB * halfM; b += kThreads) {
+      const int r = b / halfM, k = b - r * halfM;
+      const int t = k & (half - 1);
+      const int j0 = ((k >> s) << (s + 1)) | t;
+      C<T>* p = buf + r * P + j0;
+      const C<T> a = p[0];
+      const C<T> w = tw[t << (logM - 1 - s)];
+      const C<T> c = CONJ ? cmulc<T>(p[half], w) : cmul<T>(p[half], w);
+      p[0] = {a.x + c.x, a.y + c.y};
+      p[half] = {a.x - c.x, a.y - c.y};
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int bitrev(int k, int logM) {
+  return logM == 0 ? 0 : (int)(__brev((unsigned)k) >> (32 - logM));
+}
+
+struct MfftParams {
+  const float2* ts;
+  int64_t nrow;
+  int N, M, logM, RB, P;
+  const float2* tw;     // [M/2]
+  const float2* chirp;  // [N]  (Bluestein) or null
+  const float2* bfilt;  // [M]  (Bluestein) or null
+  void* out;
+  int out_c128;
+  int mmax, mlim, mlim_neg;
+  const double* mscale;
+};
+
+// Forward: FFT RB rows in LDS, then pack +/-m (transform.py:678-703) straight into
+// out[m, s, row] with zeros in every slot the reference leaves at its :623 zero fill.
+template <bool BLUESTEIN>
+__global__ __launch_bounds__(kThreads) void k_mfft_pack(MfftParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C<float>* buf = reinterpret_cast<C<float>*>(smem);
+  C<float>* tw = buf + (size_t)p.RB * p.P;
+  const int N = p.N, M = p.M, RB = p.RB, P = p.P;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+
+  for (int k = threadIdx.x; k < (M >> 1); k += kThreads) {
+    const float2 w = p.tw[k];
+    tw[k] = {w.x, w.y};
+  }
+  // coalesced row loads; rows past the end of the batch are zero
+  for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
+    const int r = idx / M, k = idx - r * M;
+    C<float> v = {0.f, 0.f};
+    if (k < N && r0 + r < p.nrow) {
+      const float2 x = p.ts[(r0 + r) * (int64_t)N + k];
+      v = {x.x, x.y};
+      if (BLUESTEIN) {
+        const float2 c = p.chirp[k];
+        v = cmul<float>(v, {c.x, c.y});
+      }
+    }
+    buf[r * P + k] = v;
+  }
+  __syncthreads();
+  fft_dif<float>(buf, tw, RB, M, p.logM, P);
+  if (BLUESTEIN) {
+    for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
+      const int r = idx / M, k = idx - r * M;
+      const float2 f = p.bfilt[k];
+      buf[r * P + k] = cmul<float>(buf[r * P + k], {f.x, f.y});
+    }
+    __syncthreads();
+    fft_dit<float, true>(buf, tw, RB, M, p.logM, P);
+  }
+
+  // pack: consecutive threads -> consecutive rows, so each (m, s) slot is one
+  // RB*elem-byte contiguous store segment
+  const double inv_n = 1.0 / (double)N;
+  const int nslot = (p.mmax + 1) * 2;
+  for (int idx = threadIdx.x; idx < nslot * RB; idx += kThreads) {
+    const int r = idx % RB, ms = idx / RB;
+    const int s = ms & 1, m = ms >> 1;
+    if (r0 + r >= p.nrow) continue;
+    double re = 0.0, im = 0.0;
+    int k = -1;
+    if (s == 0 && m <= p.mlim) k = m;
+    if (s == 1 && m >= 1 && m <= p.mlim_neg) k = N - m;
+    if (k >= 0) {
+      C<float> v;
+      if (BLUESTEIN) {
+        const float2 c = p.chirp[k];
+        v = cmul<float>(buf[r * P + k], {c.x, c.y});
+      } else {
+        v = buf[r * P + bitrev(k, p.logM)];
+      }
+      double sc = inv_n;
+      if (p.mscale) sc *= p.mscale[m];
+      re = (double)v.x * sc;
+      im = (s ? -(double)v.y : (double)v.y) * sc;
+    }
+    const int64_t o = (int64_t)ms * p.nrow + r0 + r;
+    if (p.out_c128)
+      reinterpret_cast<double2*>(p.out)[o] = make_double2(re, im);
+    else
+      reinterpret_cast<float2*>(p.out)[o] = make_float2((float)re, (float)im);
+  }
+}
+
+struct MifftParams {
+  const double2* mvis;  // [n_m, 2, nrow]
+  int64_t nrow;
+  int N, M, logM, RB, P;
+  const double2* tw;
+  const double2* chirp;
+  const double2* bfilt;
+  int mmax_plus, mmax_minus;
+  const double* mscale;
+  float2* out;  // [nrow, N]
+};
+
+// Inverse: gather the +/-m slots into FFT order (transform.py:838-849), run
+// y[n] = sum_k X[k] exp(+2 pi i k n / N)  (= ifft(X * N), transform.py:817) and store
+// complex64 rows.  Computed as conj(DFT(conj X)) so the forward machinery is shared.
+template <bool BLUESTEIN>
+__global__ __launch_bounds__(kThreads) void k_mifft_unpack(MifftParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C<double>* buf = reinterpret_cast<C<double>*>(smem);
+  C<double>* tw = buf + (size_t)p.RB * p.P;
+  const int N = p.N, M = p.M, RB = p.RB, P = p.P;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+
+  for (int k = threadIdx.x; k < (M >> 1); k += kThreads) {
+    const double2 w = p.tw[k];
+    tw[k] = {w.x, w.y};
+  }
+  // transposed gather: consecutive threads -> consecutive rows of one (m, s) slot
+  for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
+    const int r = idx % RB, k = idx / RB;
+    C<double> v = {0.0, 0.0};
+    if (k < N && r0 + r < p.nrow) {
+      int m = -1, s = 0;
+      if (k <= p.mmax_plus) {  // k == 0, the +m side and (even lengths) the Nyquist bin
+        m = k;
+        s = 0;
+        // the -m side wins where both map to the same bin only if k > mmax_plus: never here
+      }
+      if (k >= 1 && N - k >= 1 && N - k <= p.mmax_minus && k > p.mmax_plus) {
+        m = N - k;
+        s = 1;
+      }
+      if (m >= 0) {
+        const double2 x = p.mvis[((int64_t)m * 2 + s) * p.nrow + r0 + r];
+        const double sc = p.mscale ? p.mscale[m] : 1.0;
+        // X[k] = +m value, or conj(-m value); we load conj(X[k])
+        v = {x.x * sc, (s ? x.y : -x.y) * sc};
+        if (BLUESTEIN) {
+          const double2 c = p.chirp[k];
+          v = cmul<double>(v, {c.x, c.y});
+        }
+      }
+    }
+    buf[r * P + (BLUESTEIN ? k : bitrev(k, p.logM))] = v;
+  }
+  __syncthreads();
+  if (BLUESTEIN) {
+    fft_dif<double>(buf, tw, RB, M, p.logM, P);
+    for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
+      const int r = idx / M, k = idx - r * M;
+      const double2 f = p.bfilt[k];
+      buf[r * P + k] = cmul<double>(buf[r * P + k], {f.x, f.y});
+    }
+    __syncthreads();
+    fft_dit<double, true>(buf, tw, RB, M, p.logM, P);
+  } else {
+    fft_dit<double, false>(buf, tw, RB, M, p.logM, P);
+  }
+  for (int idx = threadIdx.x; idx < RB * N; idx += kThreads) {
+    const int r = idx / N, n = idx - r * N;
+    if (r0 + r >= p.nrow) continue;
+    C<double> v = buf[r * P + n];
+    if (BLUESTEIN) {
+      const double2 c = p.chirp[n];
+      v = cmul<double>(v, {c.x, c.y});
+    }
+    p.out[(r0 + r) * (int64_t)N + n] = make_float2((float)v.x, (float)(-v.y));
+  }
+}
+
+// weight: ws[r] = nra^2 * inz(sum_ra inz(w[r, ra])); out[m, s, r] = ws[r] * wscale[m].
+// One wave per row; the broadcast over (m, s) is written by the same block with
+// consecutive threads on consecutive rows.
+constexpr int kWRows = 16;  // rows per block (4 waves x 4 rows each)
+__global__ __launch_bounds__(kThreads) void k_mmode_weight(const float* __restrict__ w, int64_t nrow,
+                                                           int nra, double* __restrict__ out, int mmax,
+                                                           const double* __restrict__ wscale) {
+  __shared__ double ws[kWRows];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kWRows;
+  for (int rr = wave; rr < kWRows; rr += kThreads / 64) {
+    const int64_t r = r0 + rr;
+    double acc = 0.0;
+    if (r < nrow) {
+      const float* row = w + r * (int64_t)nra;
+      for (int k = lane; k < nra; k += 64) {
+        const float x = row[k];
+        acc += (x != 0.f) ? 1.0 / (double)x : 0.0;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) ws[rr] = (acc != 0.0) ? (double)nra * (double)nra / acc : 0.0;
+  }
+  __syncthreads();
+  const int nslot = (mmax + 1) * 2;
+  for (int idx = threadIdx.x; idx < nslot * kWRows; idx += kThreads) {
+    const int rr = idx % kWRows, ms = idx / kWRows;
+    if (r0 + rr >= nrow) continue;
+    double v = ws[rr];
+    if (wscale) v *= wscale[ms >> 1];
+    out[(int64_t)ms * nrow + r0 + rr] = v;
+  }
+}
+
+__global__ void k_row_is_zero(const double2* __restrict__ x, int64_t n, int* flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int nz = 0;
+  for (; i < n; i += stride) nz |= (x[i].x != 0.0 || x[i].y != 0.0);
+  if (nz) atomicOr(flag, 1);
+}
+
+// ---- host side: tables
+template <typename T2>
+int upload(const std::vector<T2>& h, T2** d) {
+  DMM_HIP(hipMalloc((void**)d, h.size() * sizeof(T2)));
+  DMM_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T2), hipMemcpyHostToDevice));
+  return DMM_OK;
+}
+
+inline int ilog2(int n) {
+  int l = 0;
+  while ((1 << l) < n) ++l;
+  return l;
+}
+
+void host_fft(std::vector<double>& re, std::vector<double>& im) {  // in-place radix-2, forward
+  const int M = (int)re.size(), logM = ilog2(M);
+  for (int i = 0; i < M; ++i) {
+    int j = 0;
+    for (int b = 0; b < logM; ++b) j |= ((i >> b) & 1) << (logM - 1 - b);
+    if (j > i) {
+      std::swap(re[i], re[j]);
+      std::swap(im[i], im[j]);
+    }
+  }
+  for (int half = 1; half < M; half <<= 1)
+    for (int g = 0; g < M; g += 2 * half)
+      for (int t = 0; t < half; ++t) {
+        const double ang = -M_PI * (double)t / (double)half;
+        const double wr = cos(ang), wi = sin(ang);
+        const int a = g + t, b = a + half;
+        const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+        re[b] = re[a] - xr;
+        im[b] = im[a] - xi;
+        re[a] += xr;
+        im[a] += xi;
+      }
+}
+
+// Build (or fetch) the tables for length n.  T2 = float2 (forward) / double2 (inverse).
+template <typename T2, typename T>
+int get_tables(std::map<int, dmm_fft_tables>& cache, int n, dmm_fft_tables** out) {
+  auto it = cache.find(n);
+  if (it != cache.end()) {
+    *out = &it->second;
+    return DMM_OK;
+  }
+  dmm_fft_tables t;
+  t.n = n;
+  const bool pow2 = dmm_is_pow2(n);
+  t.M = pow2 ? n : (1 << ilog2(2 * n - 1));
+  const int M = t.M, logM = ilog2(M);
+  std::vector<T2> tw(M / 2 > 0 ? M / 2 : 1);
+  for (int k = 0; k < M / 2; ++k) {
+    const double a = -2.0 * M_PI * (double)k / (double)M;
+    tw[k].x = (T)cos(a);
+    tw[k].y = (T)sin(a);
+  }
+  int rc = upload<T2>(tw, reinterpret_cast<T2**>(&t.tw));
+  if (rc) return rc;
+  if (!pow2) {
+    std::vector<T2> chirp(n);
+    std::vector<double> br(M, 0.0), bi(M, 0.0);
+    for (int k = 0; k < n; ++k) {
+      const int64_t k2 = ((int64_t)k * k) % (2 * (int64_t)n);  // exact phase reduction
+      const double a = -M_PI * (double)k2 / (double)n;
+      chirp[k].x = (T)cos(a);
+      chirp[k].y = (T)sin(a);
+      br[k] = cos(a);  // b[j] = conj(chirp[|j|]) wrapped to length M
+      bi[k] = -sin(a);
+      if (k > 0) {
+        br[M - k] = cos(a);
+        bi[M - k] = -sin(a);
+      }
+    }
+    host_fft(br, bi);
+    std::vector<T2> bf(M);
+    for (int pidx = 0; pidx < M; ++pidx) {
+      int j = 0;
+      for (int b = 0; b < logM; ++b) j |= ((pidx >> b) & 1) << (logM - 1 - b);
+      bf[pidx].x = (T)(br[j] / (double)M);
+      bf[pidx].y = (T)(bi[j] / (double)M);
+    }
+    rc = upload<T2>(chirp, reinterpret_cast<T2**>(&t.chirp));
+    if (rc) return rc;
+    rc = upload<T2>(bf, reinterpret_cast<T2**>(&t.bfilt));
+    if (rc) return rc;
+  }
+  auto ins = cache.emplace(n, t);
+  *out = &ins.first->second;
+  return DMM_OK;
+}
+
+// rows per block and LDS bytes for an M-point transform with elem-byte elements
+bool choose_rb(int M, size_t elem, int64_t nrow, int* RB, int* P, size_t* lds) {
+  const size_t tw = (size_t)(M / 2) * elem;
+  *P = M + 1;
+  int rb = 16;
+  while (rb > 1 && (size_t)rb * (*P) * elem + tw > 80 * 1024) rb >>= 1;
+  while (rb > 1 && rb / 2 >= nrow) rb >>= 1;
+  *lds = (size_t)rb * (*P) * elem + tw;
+  *RB = rb;
+  return *lds <= 160 * 1024;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmm_mfft_pack(dmm_ctx* ctx, const void* ts, int64_t nrow, int nra, void* out, int mmax,
+                  int out_dtype, const double* mscale) {
+  DMM_REQUIRE(ctx && ts && out, "dmm_mfft_pack: NULL argument");
+  DMM_REQUIRE(nrow >= 0 && nra >= 1 && mmax >= 0, "dmm_mfft_pack: bad sizes nrow=%lld nra=%d mmax=%d",
+              (long long)nrow, nra, mmax);
+  DMM_REQUIRE(out_dtype == DMM_C64 || out_dtype == DMM_C128, "dmm_mfft_pack: bad out_dtype %d", out_dtype);
+  if (nra > DMM_MAX_NRA) return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_mfft_pack: nra=%d > %d", nra, DMM_MAX_NRA);
+  if (nrow == 0) return DMM_OK;
+  DMM_HIP(hipSetDevice(ctx->device));
+  dmm_fft_tables* t = nullptr;
+  int rc = get_tables<float2, float>(ctx->fft, nra, &t);
+  if (rc) return rc;
+  MfftParams p;
+  p.ts = (const float2*)ts;
+  p.nrow = nrow;
+  p.N = nra;
+  p.M = t->M;
+  p.logM = ilog2(t->M);
+  size_t lds = 0;
+  if (!choose_rb(p.M, sizeof(float2), nrow, &p.RB, &p.P, &lds))
+    return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_mfft_pack: nra=%d needs %zu B of LDS", nra, lds);
+  p.tw = t->tw;
+  p.chirp = t->chirp;
+  p.bfilt = t->bfilt;
+  p.out = out;
+  p.out_c128 = out_dtype == DMM_C128;
+  p.mmax = mmax;
+  p.mlim = nra / 2 < mmax ? nra / 2 : mmax;                         // transform.py:678
+  p.mlim_neg = (mmax >= nra / 2) ? nra / 2 - 1 + nra % 2 : mmax;    // transform.py:679
+  p.mscale = mscale;
+  const int64_t nblk = (nrow + p.RB - 1) / p.RB;
+  DMM_REQUIRE(nblk <= 0x7fffffff, "dmm_mfft_pack: too many rows");
+  const bool blue = t->chirp != nullptr;
+  auto kern = blue ? k_mfft_pack<true> : k_mfft_pack<false>;
+  DMM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, ctx->stream, p);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+int dmm_mmode_weight(dmm_ctx* ctx, const float* weight, int64_t nrow, int nra, double* out, int mmax,
+                     const double* wscale) {
+  DMM_REQUIRE(ctx && weight && out, "dmm_mmode_weight: NULL argument");
+  DMM_REQUIRE(nrow >= 0 && nra >= 1 && mmax >= 0, "dmm_mmode_weight: bad sizes");
+  if (nrow == 0) return DMM_OK;
+  DMM_HIP(hipSetDevice(ctx->device));
+  const int64_t nblk = (nrow + kWRows - 1) / kWRows;
+  DMM_REQUIRE(nblk <= 0x7fffffff, "dmm_mmode_weight: too many rows");
+  hipLaunchKernelGGL(k_mmode_weight, dim3((unsigned)nblk), dim3(kThreads), 0, ctx->stream, weight, nrow, nra,
+                     out, mmax, wscale);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+int dmm_mifft_unpack(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int nra, int mmax_plus,
+                     int mmax_minus, const double* mscale, void* vis_out) {
+  DMM_REQUIRE(ctx && mvis && vis_out, "dmm_mifft_unpack: NULL argument");
+  DMM_REQUIRE(nrow >= 0 && nra >= 1 && n_m >= 1, "dmm_mifft_unpack: bad sizes");
+  DMM_REQUIRE(mmax_plus >= 0 && mmax_plus < n_m && mmax_minus >= 0 && mmax_minus <= mmax_plus,
+              "dmm_mifft_unpack: bad limits +%d -%d (n_m=%d)", mmax_plus, mmax_minus, n_m);
+  DMM_REQUIRE(mmax_plus <= nra / 2 && mmax_minus <= (nra - 1) / 2,
+              "dmm_mifft_unpack: limits +%d -%d exceed nra=%d", mmax_plus, mmax_minus, nra);
+  if (nra > DMM_MAX_NRA / 2 && !dmm_is_pow2(nra))
+    return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_mifft_unpack: non power-of-two nra=%d > %d", nra, DMM_MAX_NRA / 2);
+  if (nra > DMM_MAX_NRA) return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_mifft_unpack: nra=%d > %d", nra, DMM_MAX_NRA);
+  if (nrow == 0) return DMM_OK;
+  DMM_HIP(hipSetDevice(ctx->device));
+  dmm_fft_tables* t = nullptr;
+  int rc = get_tables<double2, double>(ctx->ifft, nra, &t);
+  if (rc) return rc;
+  MifftParams p;
+  p.mvis = (const double2*)mvis;
+  p.nrow = nrow;
+  p.N = nra;
+  p.M = t->M;
+  p.logM = ilog2(t->M);
+  size_t lds = 0;
+  if (!choose_rb(p.M, sizeof(double2), nrow, &p.RB, &p.P, &lds))
+    return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_mifft_unpack: nra=%d needs %zu B of LDS", nra, lds);
+  p.tw = (const double2*)t->tw;
+  p.chirp = (const double2*)t->chirp;
+  p.bfilt = (const double2*)t->bfilt;
+  p.mmax_plus = mmax_plus;
+  p.mmax_minus = mmax_minus;
+  p.mscale = mscale;
+  p.out = (float2*)vis_out;
+  const int64_t nblk = (nrow + p.RB - 1) / p.RB;
+  DMM_REQUIRE(nblk <= 0x7fffffff, "dmm_mifft_unpack: too many rows");
+  const bool blue = t->chirp != nullptr;
+  auto kern = blue ? k_mifft_unpack<true> : k_mifft_unpack<false>;
+  DMM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, ctx->stream, p);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+int dmm_mrow_is_zero(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int m, int sign, int* is_zero) {
+  DMM_REQUIRE(ctx && mvis && is_zero, "dmm_mrow_is_zero: NULL argument");
+  DMM_REQUIRE(m >= 0 && m < n_m && (sign == 0 || sign == 1) && nrow >= 0, "dmm_mrow_is_zero: bad index");
+  DMM_HIP(hipSetDevice(ctx->device));
+  int* flag = nullptr;
+  DMM_HIP(hipMalloc((void**)&flag, sizeof(int)));
+  DMM_HIP(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+  if (nrow > 0) {
+    const double2* x = (const double2*)mvis + ((int64_t)m * 2 + sign) * nrow;
+    int64_t nb = (nrow + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_row_is_zero, dim3((unsigned)nb), dim3(256), 0, ctx->stream, x, nrow, flag);
+  }
+  int h = 0;
+  hipError_t e = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(flag);
+  if (e != hipSuccess) return dmm_set_error((int)e, "dmm_mrow_is_zero: %s", hipGetErrorString(e));
+  *is_zero = h ? 0 : 1;
+  return DMM_OK;
+}
+
+}  // extern "C"

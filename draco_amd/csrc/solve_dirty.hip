@@ -1,0 +1,390 @@
+// Batched beam-transfer contractions over (m, freq) tiles.
+//
+//   k_dirty    a = B^H (Ni o v)     DirtyMapMaker._solve_m     reference mapmaker.py:156-168
+//   k_project  v = B a              bt.project_vector_sky_to_telescope as called at
+//                                   reference stream.py:109-112 [driftscan, 3P]
+//
+// This is THE bandwidth kernel of the path: B_m[f] (ntel x npol*(lmax+1-m) complex) is
+// read exactly once per solve and is ~99 % of the bytes, so the
+// design goal is nothing but streaming B at the HBM rate:
+//   * a block = one tile x 256*CPL adjacent output columns; each of its 4 waves owns 64*CPL
+//     columns and walks down ALL ntel rows, so every wave-load is one contiguous
+//     1 KiB piece of a B row (16 B per lane) and there is NO cross-lane or cross-wave
+//     reduction -- each lane keeps its own complex accumulator in registers;
+//   * w = Ni o v (ntel complex doubles, <= 24 KB) is formed once per block in LDS and
+//     read back as a wave-uniform broadcast, the l<m columns are never touched;
+//   * rows are issued UNROLL deep so 8 x 1 KiB per wave (x up to 32 waves per CU) are in
+//     flight -- far more than the ~32 KB per CU the HBM latency-bandwidth product needs;
+//   * the grid is a fixed 256 CUs x 8 blocks that stride over a prefix-summed task list,
+//     found by a scalar binary search, so uneven tiles (the triangle in m) stay balanced.
+// Accumulation is always float64, whatever the storage type of B.
+#include "dmm_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kUnroll = 8;
+
+struct SolveParams {
+  const dmm_tile* tiles;
+  const int32_t* work_start;  // [ntile+1]
+  int64_t ntile;
+  int64_t nwork;
+  int npairs, ntel, npol, lmax, nfreq, n_m;
+  int full_layout;  // 1: tile [ntel, npol, lmax+1]; 0: [ntel, npol, lmax+1-m]
+};
+
+__device__ __forceinline__ int64_t find_tile(const int32_t* __restrict__ ws, int64_t ntile, int64_t w) {
+  int64_t lo = 0, hi = ntile;  // largest t with ws[t] <= w
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (ws[mid] <= w) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <typename BT>
+__device__ __forceinline__ void load_b(const BT* p, double& re, double& im);
+template <>
+__device__ __forceinline__ void load_b<double2>(const double2* p, double& re, double& im) {
+  const double2 v = *p;
+  re = v.x;
+  im = v.y;
+}
+template <>
+__device__ __forceinline__ void load_b<float2>(const float2* p, double& re, double& im) {
+  const float2 v = *p;
+  re = (double)v.x;
+  im = (double)v.y;
+}
+
+// CPL adjacent columns per lane.  CPL == 2 exists only for packed complex64 tiles whose
+// rows are 16-byte aligned (plan->pair_ok): one 16-byte load brings both columns.
+template <typename BT, int CPL>
+__device__ __forceinline__ void load_cols(const BT* p, const int64_t (&off)[CPL], int64_t roff, double (&re)[CPL],
+                                          double (&im)[CPL]) {
+  if constexpr (CPL == 2) {
+    const float4 v = *reinterpret_cast<const float4*>(p + off[0] + roff);
+    re[0] = (double)v.x;
+    im[0] = (double)v.y;
+    re[1] = (double)v.z;
+    im[1] = (double)v.w;
+  } else {
+    load_b<BT>(p + off[0] + roff, re[0], im[0]);
+  }
+}
+
+// a[pol, l] = sum_i conj(B[i, pol, l]) * Ni[i] * v[i]
+template <typename BT, int CPL>
+__global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __restrict__ B,
+                                                    const double2* __restrict__ mvis,
+                                                    const double* __restrict__ mweight,
+                                                    double2* __restrict__ alm) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* w = reinterpret_cast<double2*>(smem);  // [ntel]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntel = p.ntel, npairs = p.npairs;
+
+  for (int64_t work = blockIdx.x; work < p.nwork; work += gridDim.x) {
+    const int64_t t = find_tile(p.work_start, p.ntile, work);
+    const dmm_tile tile = p.tiles[t];
+    const int cb = (int)(work - p.work_start[t]);
+    const int m = tile.m, f = tile.f;
+    const int L = p.lmax + 1 - m;
+    const int ncol = p.npol * L;
+    const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+    const int col0 = p.full_layout ? m : 0;
+    const int64_t row_stride = (int64_t)p.npol * pol_stride;
+
+    __syncthreads();  // previous task's readers of w are done
+    for (int i = threadIdx.x; i < ntel; i += kThreads) {
+      const int s = i >= npairs, pp = i - s * npairs;
+      const int64_t o = (((int64_t)m * 2 + s) * p.nfreq + f) * npairs + pp;
+      const double2 v = mvis[o];
+      const double ni = mweight[o];
+      w[i] = make_double2(ni * v.x, ni * v.y);
+    }
+    __syncthreads();
+
+    // structural zeros l < m (mapmaker.py:76 zero fill): written by the first column block
+    if (cb == 0)
+      for (int idx = threadIdx.x; idx < p.npol * m; idx += kThreads) {
+        const int pol = idx / m, l = idx - pol * m;
+        alm[(((int64_t)f * p.npol + pol) * p.n_m + m) * (p.lmax + 1) + l] = make_double2(0.0, 0.0);
+      }
+
+    const int jbase = (cb * kWaves + wave) * 64 * CPL + lane * CPL;
+    if (jbase >= ncol) continue;  // tail lanes/waves idle; they still meet the barriers above
+
+    int64_t off[CPL];
+    bool ok[CPL];
+    int opol[CPL], ol[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int j = jbase + c;
+      ok[c] = j < ncol;
+      const int jj = ok[c] ? j : ncol - 1;
+      opol[c] = jj / L;
+      const int lrel = jj - opol[c] * L;
+      ol[c] = m + lrel;
+      off[c] = tile.b_off + (int64_t)opol[c] * pol_stride + col0 + lrel;
+    }
+    double are[CPL], aim[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) are[c] = aim[c] = 0.0;
+
+    int i = 0;
+    for (; i + kUnroll <= ntel; i += kUnroll) {
+      double br[kUnroll][CPL], bi[kUnroll][CPL];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) load_cols<BT, CPL>(B, off, (int64_t)(i + u) * row_stride, br[u], bi[u]);
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const double2 wv = w[i + u];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {  // conj(b) * w
+          are[c] = fma(br[u][c], wv.x, fma(bi[u][c], wv.y, are[c]));
+          aim[c] = fma(br[u][c], wv.y, fma(-bi[u][c], wv.x, aim[c]));
+        }
+      }
+    }
+    for (; i < ntel; ++i) {
+      const double2 wv = w[i];
+      double br[CPL], bi[CPL];
+      load_cols<BT, CPL>(B, off, (int64_t)i * row_stride, br, bi);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        are[c] = fma(br[c], wv.x, fma(bi[c], wv.y, are[c]));
+        aim[c] = fma(br[c], wv.y, fma(-bi[c], wv.x, aim[c]));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      if (ok[c]) {
+        const int64_t o = (((int64_t)f * p.npol + opol[c]) * p.n_m + m) * (p.lmax + 1) + ol[c];
+        alm[o] = make_double2(are[c], aim[c]);
+      }
+  }
+}
+
+// v[i] = sum_{pol,l} B[i, pol, l] * a[pol, l]: one wave per row, lanes across the
+// contiguous row (coalesced), shuffle reduction; a (<= 64 KB) staged in LDS per block.
+template <typename BT>
+__global__ __launch_bounds__(kThreads) void k_project(SolveParams p, const BT* __restrict__ B,
+                                                      const double2* __restrict__ alm,
+                                                      double2* __restrict__ vis) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* a = reinterpret_cast<double2*>(smem);  // [npol * L], packed (pol, l-m) order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t work = blockIdx.x; work < p.nwork; work += gridDim.x) {
+    const int64_t t = find_tile(p.work_start, p.ntile, work);
+    const dmm_tile tile = p.tiles[t];
+    const int rb = (int)(work - p.work_start[t]);  // block of 64 rows
+    const int m = tile.m, f = tile.f;
+    const int L = p.lmax + 1 - m;
+    const int ncol = p.npol * L;
+    const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+    const int col0 = p.full_layout ? m : 0;
+    const int64_t row_stride = (int64_t)p.npol * pol_stride;
+    __syncthreads();
+    for (int j = threadIdx.x; j < ncol; j += kThreads) {
+      const int pol = j / L, lrel = j - pol * L;
+      a[j] = alm[(((int64_t)f * p.npol + pol) * p.n_m + m) * (p.lmax + 1) + m + lrel];
+    }
+    __syncthreads();
+    for (int rr = wave; rr < 64; rr += kWaves) {
+      const int i = rb * 64 + rr;
+      if (i >= p.ntel) break;
+      const BT* row = B + tile.b_off + (int64_t)i * row_stride + col0;
+      double sre = 0.0, sim = 0.0;
+      for (int pol = 0; pol < p.npol; ++pol) {
+        const BT* seg = row + (int64_t)pol * pol_stride;
+        const double2* as = a + pol * L;
+#pragma unroll 4
+        for (int lrel = lane; lrel < L; lrel += 64) {
+          double br, bi;
+          load_b<BT>(seg + lrel, br, bi);
+          const double2 av = as[lrel];
+          sre = fma(br, av.x, fma(-bi, av.y, sre));
+          sim = fma(br, av.y, fma(bi, av.x, sim));
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        sre += __shfl_down(sre, off, 64);
+        sim += __shfl_down(sim, off, 64);
+      }
+      if (lane == 0) {
+        const int s = i >= p.npairs, pp = i - s * p.npairs;
+        vis[(((int64_t)m * 2 + s) * p.nfreq + f) * p.npairs + pp] = make_double2(sre, sim);
+      }
+    }
+  }
+}
+
+// tasks per tile: by column blocks (cols > 0) or by blocks of 64 rows (cols == 0)
+int make_work(const dmm_plan* pl, int cols, std::vector<int32_t>& ws, int64_t* nwork) {
+  ws.resize(pl->ntile + 1);
+  int64_t acc = 0;
+  for (int64_t t = 0; t < pl->ntile; ++t) {
+    ws[t] = (int32_t)acc;
+    const int ncol = pl->npol * (pl->lmax + 1 - pl->tiles_h[t].m);
+    acc += cols > 0 ? (ncol + cols - 1) / cols : (2 * pl->npairs + 63) / 64;
+    if (acc > 0x7fffffff) return dmm_set_error(DMM_E_UNSUPPORTED, "plan too large: split the batch");
+  }
+  ws[pl->ntile] = (int32_t)acc;
+  *nwork = acc;
+  return DMM_OK;
+}
+
+SolveParams base_params(const dmm_plan* pl) {
+  SolveParams p;
+  p.tiles = pl->tiles_d;
+  p.work_start = pl->work_start_d;
+  p.ntile = pl->ntile;
+  p.nwork = pl->nwork;
+  p.npairs = pl->npairs;
+  p.ntel = 2 * pl->npairs;
+  p.npol = pl->npol;
+  p.lmax = pl->lmax;
+  p.nfreq = pl->nfreq;
+  p.n_m = pl->n_m;
+  p.full_layout = pl->b_layout == DMM_B_FULL;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmm_solve_plan_create(dmm_ctx* ctx, const dmm_tile* tiles, int64_t ntile, int npairs, int npol,
+                          int lmax, int nfreq, int n_m, int b_dtype, int b_layout, dmm_plan** out) {
+  DMM_REQUIRE(ctx && out && (tiles || ntile == 0), "dmm_solve_plan_create: NULL argument");
+  *out = nullptr;
+  DMM_REQUIRE(ntile >= 0 && npairs >= 1 && npol >= 1 && lmax >= 0 && nfreq >= 1 && n_m >= 1,
+              "dmm_solve_plan_create: bad sizes");
+  DMM_REQUIRE(b_dtype == DMM_C64 || b_dtype == DMM_C128, "dmm_solve_plan_create: bad b_dtype %d", b_dtype);
+  DMM_REQUIRE(b_layout == DMM_B_FULL || b_layout == DMM_B_PACKED, "dmm_solve_plan_create: bad b_layout %d", b_layout);
+  DMM_REQUIRE((size_t)2 * npairs * sizeof(double2) <= 96 * 1024, "dmm_solve_plan_create: npairs=%d too large for the LDS stage", npairs);
+  bool even_off = true;
+  for (int64_t t = 0; t < ntile; ++t) {
+    DMM_REQUIRE(tiles[t].m >= 0 && tiles[t].m < n_m && tiles[t].m <= lmax, "tile %lld: m=%d out of range (n_m=%d, lmax=%d)",
+                (long long)t, tiles[t].m, n_m, lmax);
+    DMM_REQUIRE(tiles[t].f >= 0 && tiles[t].f < nfreq, "tile %lld: f=%d out of range (nfreq=%d)", (long long)t, tiles[t].f, nfreq);
+    DMM_REQUIRE(tiles[t].b_off >= 0, "tile %lld: negative b_off", (long long)t);
+    even_off = even_off && (tiles[t].b_off % 2 == 0);
+  }
+  DMM_HIP(hipSetDevice(ctx->device));
+  dmm_plan* pl = new (std::nothrow) dmm_plan();
+  if (!pl) return dmm_set_error(DMM_E_NOMEM, "dmm_solve_plan_create: out of host memory");
+  pl->ctx = ctx;
+  pl->ntile = ntile;
+  pl->npairs = npairs;
+  pl->npol = npol;
+  pl->lmax = lmax;
+  pl->nfreq = nfreq;
+  pl->n_m = n_m;
+  pl->b_dtype = b_dtype;
+  pl->b_layout = b_layout;
+  pl->tiles_h.assign(tiles, tiles + ntile);
+  const size_t es = b_dtype == DMM_C128 ? 16 : 8;
+  for (int64_t t = 0; t < ntile; ++t)
+    pl->b_bytes += (int64_t)2 * npairs * npol * (lmax + 1 - tiles[t].m) * (int64_t)es;
+  // two columns per lane (one 16-byte load) when every packed complex64 row is 16-byte aligned
+  pl->pair_ok = b_dtype == DMM_C64 && b_layout == DMM_B_PACKED && npol % 2 == 0 && even_off;
+  pl->cols_per_block = kThreads * (pl->pair_ok ? 2 : 1);
+  std::vector<int32_t> ws, wr;
+  int rc = make_work(pl, pl->cols_per_block, ws, &pl->nwork);
+  if (!rc) rc = make_work(pl, 0, wr, &pl->nwork_rows);
+  if (rc) {
+    delete pl;
+    return rc;
+  }
+  if (ntile > 0) {
+    const size_t wb = (ntile + 1) * sizeof(int32_t);
+    hipError_t e = hipMalloc((void**)&pl->tiles_d, ntile * sizeof(dmm_tile));
+    if (e == hipSuccess) e = hipMalloc((void**)&pl->work_start_d, wb);
+    if (e == hipSuccess) e = hipMalloc((void**)&pl->work_rows_d, wb);
+    if (e == hipSuccess) e = hipMemcpy(pl->tiles_d, tiles, ntile * sizeof(dmm_tile), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->work_start_d, ws.data(), wb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->work_rows_d, wr.data(), wb, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      dmm_plan_destroy(pl);
+      return dmm_set_error((int)e, "dmm_solve_plan_create: %s", hipGetErrorString(e));
+    }
+  }
+  *out = pl;
+  return DMM_OK;
+}
+
+int dmm_plan_destroy(dmm_plan* pl) {
+  if (!pl) return DMM_OK;
+  (void)hipSetDevice(pl->ctx->device);
+  if (pl->tiles_d) (void)hipFree(pl->tiles_d);
+  if (pl->work_start_d) (void)hipFree(pl->work_start_d);
+  if (pl->work_rows_d) (void)hipFree(pl->work_rows_d);
+  delete pl;
+  return DMM_OK;
+}
+
+int64_t dmm_plan_b_bytes(const dmm_plan* pl) { return pl ? pl->b_bytes : 0; }
+
+int dmm_dirty_run(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, void* alm) {
+  DMM_REQUIRE(pl && B && mvis && mweight && alm, "dmm_dirty_run: NULL argument");
+  DMM_REQUIRE(((uintptr_t)B & 15) == 0 && ((uintptr_t)mvis & 15) == 0 && ((uintptr_t)alm & 15) == 0,
+              "dmm_dirty_run: B, mvis and alm must be 16-byte aligned");
+  if (pl->ntile == 0) return DMM_OK;
+  dmm_ctx* ctx = pl->ctx;
+  DMM_HIP(hipSetDevice(ctx->device));
+  SolveParams p = base_params(pl);
+  const size_t lds = (size_t)p.ntel * sizeof(double2);
+  int64_t grid = (int64_t)ctx->num_cu * 8;
+  if (grid > p.nwork) grid = p.nwork;
+  const double2* v = (const double2*)mvis;
+  double2* a = (double2*)alm;
+  if (pl->b_dtype == DMM_C128) {
+    auto k = k_dirty<double2, 1>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B, v, mweight, a);
+  } else if (pl->pair_ok) {
+    auto k = k_dirty<float2, 2>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, v, mweight, a);
+  } else {
+    auto k = k_dirty<float2, 1>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, v, mweight, a);
+  }
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+int dmm_project_run(dmm_plan* pl, const void* B, const void* alm_in, void* vis_out) {
+  DMM_REQUIRE(pl && B && alm_in && vis_out, "dmm_project_run: NULL argument");
+  DMM_REQUIRE(((uintptr_t)B & 15) == 0 && ((uintptr_t)alm_in & 15) == 0 && ((uintptr_t)vis_out & 15) == 0,
+              "dmm_project_run: B, alm and vis must be 16-byte aligned");
+  if (pl->ntile == 0) return DMM_OK;
+  dmm_ctx* ctx = pl->ctx;
+  DMM_HIP(hipSetDevice(ctx->device));
+  SolveParams p = base_params(pl);
+  p.work_start = pl->work_rows_d;
+  p.nwork = pl->nwork_rows;
+  const size_t lds = (size_t)p.npol * (p.lmax + 1) * sizeof(double2);
+  if (lds > 160 * 1024)
+    return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_project_run: nsky=%d too large for the LDS stage", p.npol * (p.lmax + 1));
+  int64_t grid = (int64_t)ctx->num_cu * 8;
+  if (grid > p.nwork) grid = p.nwork;
+  if (pl->b_dtype == DMM_C128) {
+    auto k = k_project<double2>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B, (const double2*)alm_in, (double2*)vis_out);
+  } else {
+    auto k = k_project<float2>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, (const double2*)alm_in, (double2*)vis_out);
+  }
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+}  // extern "C"

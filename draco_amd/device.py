@@ -1,0 +1,99 @@
+"""Device plumbing: one :class:`Context` per GPU.
+
+PyTorch is used for what it is good at here -- device memory, streams and (in
+``draco_amd.parallel``) ``torch.distributed`` -- and nothing else: every number the path
+produces comes out of a kernel in ``libdraco_amd.so``.  Raises if there is no GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_NP2TORCH = {
+    np.dtype(np.complex64): torch.complex64,
+    np.dtype(np.complex128): torch.complex128,
+    np.dtype(np.float32): torch.float32,
+    np.dtype(np.float64): torch.float64,
+}
+
+
+class Context:
+    """Owns a ``dmm_ctx`` bound to ``cuda:<device>`` and torch's current stream on it."""
+
+    _cache: dict[int, "Context"] = {}
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "draco_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback."
+            )
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        _lib.check(_lib.lib.dmm_ctx_create(self.device_index, C.byref(h)))
+        self.handle = h
+        self.bind_stream()
+
+    @classmethod
+    def get(cls, device: int | None = None) -> "Context":
+        if device is None:
+            device = torch.cuda.current_device()
+        if device not in cls._cache:
+            cls._cache[device] = cls(device)
+        ctx = cls._cache[device]
+        ctx.bind_stream()
+        return ctx
+
+    def bind_stream(self):
+        """Launch on torch's current stream of this device (so torch allocations/copies order with kernels)."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib.dmm_ctx_set_stream(self.handle, C.c_void_p(s)))
+
+    def sync(self):
+        _lib.check(_lib.lib.dmm_ctx_sync(self.handle))
+
+    def timer_start(self):
+        _lib.check(_lib.lib.dmm_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _lib.check(_lib.lib.dmm_timer_stop(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- memory helpers
+    def empty(self, shape, dtype) -> torch.Tensor:
+        return torch.empty(tuple(int(s) for s in shape), dtype=_NP2TORCH[np.dtype(dtype)], device=self.device)
+
+    def zeros(self, shape, dtype) -> torch.Tensor:
+        return torch.zeros(tuple(int(s) for s in shape), dtype=_NP2TORCH[np.dtype(dtype)], device=self.device)
+
+    def to_device(self, arr, dtype=None) -> torch.Tensor:
+        """ndarray / tensor -> contiguous device tensor of ``dtype`` (H2D copy if needed)."""
+        if isinstance(arr, torch.Tensor):
+            t = arr
+            if dtype is not None and t.dtype != _NP2TORCH[np.dtype(dtype)]:
+                t = t.to(_NP2TORCH[np.dtype(dtype)])
+            return t.to(self.device).contiguous()
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        return torch.from_numpy(a).to(self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib.dmm_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def ptr(t) -> C.c_void_p:
+    """Raw device pointer of a tensor (``None`` -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous()
+    return C.c_void_p(t.data_ptr())

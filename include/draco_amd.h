@@ -1,0 +1,168 @@
+/*
+ * draco_amd.h -- C ABI of the MI355X (gfx950) m-mode map-making path.
+ *
+ * This is the drop-in boundary: every entry point is `extern "C"`, takes plain
+ * pointers and sizes (no torch / C++ types) and is what a ctypes binding of the
+ * reference's hot path binds (INTEGRATION.md shows the binding).  Each function
+ * names the reference interface (radiocosmology/draco, file:line) it replaces.
+ *
+ * Conventions
+ *   - every call returns an int status: 0 = ok, <0 = argument error (DMM_E_*),
+ *     >0 = a hipError_t; the message is in dmm_last_error() (thread local);
+ *   - the CALLER owns every data buffer; pointers marked [dev] are device pointers
+ *     valid on the context's device, [host] are ordinary host pointers; the
+ *     library never frees caller memory and keeps no caller pointer after a call
+ *     returns (work is enqueued on the context's stream: the caller must keep the
+ *     buffers alive until dmm_ctx_sync / a stream sync of its own);
+ *   - row-major (C order) everywhere, matching NumPy; complex = interleaved
+ *     (re, im); complex64 = 2 x float, complex128 = 2 x double;
+ *   - a context is not thread-safe; distinct contexts are independent;
+ *   - no exceptions or longjmp cross this boundary.
+ */
+#ifndef DRACO_AMD_H
+#define DRACO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMM_VERSION 100 /* 0.1.0 */
+
+typedef struct dmm_ctx dmm_ctx;
+typedef struct dmm_plan dmm_plan;
+
+enum {
+  DMM_OK = 0,
+  DMM_E_ARG = -1,      /* invalid argument (null pointer, bad size, bad enum) */
+  DMM_E_UNSUPPORTED = -2, /* valid request this build cannot serve (e.g. nra too long) */
+  DMM_E_NOMEM = -3,
+  DMM_E_STATE = -4
+};
+
+/* element types of the beam-transfer pool and of m-mode outputs */
+enum { DMM_C64 = 0, DMM_C128 = 1 };
+
+/* layout of one beam-transfer tile B_m[f] (what `bt.beam_m(m, fi=f)` returns,
+ * reference mapmaker.py:162, reshaped to [ntel, npol, lmax+1]):
+ *   DMM_B_FULL   [ntel, npol, lmax+1]     -- the l<m columns are stored (zeros), never read
+ *   DMM_B_PACKED [ntel, npol, lmax+1-m]   -- only the l>=m columns are stored           */
+enum { DMM_B_FULL = 0, DMM_B_PACKED = 1 };
+
+/* one (m, freq) solve: which tile, which data column */
+typedef struct {
+  int64_t b_off; /* element offset of the tile inside the B buffer */
+  int32_t m;     /* m of this tile (row of the m axis of mvis/mweight/alm) */
+  int32_t f;     /* frequency index into mvis/mweight/alm */
+} dmm_tile;
+
+/* ---------------------------------------------------------------- context */
+int dmm_version(void);
+const char* dmm_last_error(void);
+int dmm_ctx_create(int device, dmm_ctx** ctx);
+int dmm_ctx_destroy(dmm_ctx* ctx);
+/* run on the caller's HIP stream (hipStream_t passed as void*; NULL = default stream) */
+int dmm_ctx_set_stream(dmm_ctx* ctx, void* hip_stream);
+int dmm_ctx_sync(dmm_ctx* ctx);
+/* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
+int dmm_timer_start(dmm_ctx* ctx);
+int dmm_timer_stop(dmm_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
+
+/* ------------------------------------------------- m-mode transform (a2, a3)
+ * dmm_mfft_pack replaces `_make_marray` (reference transform.py:644-705) together
+ * with the zero fill at :623 and the optional window at :630-636:
+ *   F = fft(ts, axis=-1) in single precision; for every row r
+ *     out[m, 0, r] = F[r, m] / nra              0 <= m <= mlim
+ *     out[m, 1, r] = conj(F[r, nra-m]) / nra    1 <= m <= mlim_neg
+ *     out[.]       = 0 elsewhere                (mlim, mlim_neg: transform.py:678-679)
+ *   then out[m, :, :] *= mscale[m] if mscale != NULL.
+ * ts      [dev] complex64 [nrow, nra]
+ * out     [dev] complex  [mmax+1, 2, nrow] of out_dtype (DMM_C128 = MModes.vis)
+ * mscale  [dev] double [mmax+1] or NULL
+ * Any nra >= 1 up to DMM_MAX_NRA is served (power of two: in-LDS radix FFT;
+ * otherwise Bluestein).                                                          */
+#define DMM_MAX_NRA 8192
+int dmm_mfft_pack(dmm_ctx* ctx, const void* ts, int64_t nrow, int nra, void* out,
+                  int mmax, int out_dtype, const double* mscale);
+
+/* dmm_mmode_weight replaces transform.py:599-602 + :627 (+ :638-639):
+ *   ws[r] = nra^2 * inz( sum_ra inz(weight[r, ra]) ),  out[m, s, r] = ws[r] * wscale[m]
+ * weight [dev] float32 [nrow, nra]; out [dev] double [mmax+1, 2, nrow];
+ * wscale [dev] double [mmax+1] or NULL.                                           */
+int dmm_mmode_weight(dmm_ctx* ctx, const float* weight, int64_t nrow, int nra,
+                     double* out, int mmax, const double* wscale);
+
+/* inverse: `_unpack_marray` + `_make_ssarray` (transform.py:814-851) and the weight
+ * rule of MModeInverseTransform.process (:790).
+ * mvis [dev] complex128 [n_m, 2, nrow]; vis_out [dev] complex64 [nrow, nra];
+ * mmax_plus/mmax_minus are the limits computed by the caller per :825-836
+ * (the "is the top -m row all zero" test of :826 is done by dmm_mrow_is_zero).     */
+int dmm_mifft_unpack(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int nra,
+                     int mmax_plus, int mmax_minus, const double* mscale, void* vis_out);
+int dmm_mrow_is_zero(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int m,
+                     int sign, int* is_zero /*[host]*/);
+
+/* ------------------------------------------------------ map-maker solves (a5-a8)
+ * A plan fixes the batch of (m, f) solves (the double loop at mapmaker.py:79-94)
+ * and the shapes; it owns a device copy of the tile table.
+ *   mvis    [dev] complex128 [n_m, 2, nfreq, npairs]   (MModes.vis,    containers.py:1178)
+ *   mweight [dev] double     [n_m, 2, nfreq, npairs]   (MModes.weight)
+ *   alm     [dev] complex128 [nfreq, npol, n_m, lmax+1]  (m-major: l is the fast axis;
+ *           the reference's [nfreq, 4, lmax+1, mmax+1] at mapmaker.py:70 is its
+ *           transpose, produced by the Python layer on request)
+ *   B       [dev] pool of tiles, dtype/layout fixed by the plan, tile i at b_off.
+ * Only entries alm[f, :, m, :] of tiles in the plan are written (l<m -> 0).         */
+int dmm_solve_plan_create(dmm_ctx* ctx, const dmm_tile* tiles /*[host]*/, int64_t ntile,
+                          int npairs, int npol, int lmax, int nfreq, int n_m, int b_dtype,
+                          int b_layout, dmm_plan** plan);
+int dmm_plan_destroy(dmm_plan* plan);
+/* bytes of B the plan's tiles cover (algorithmic: l>=m columns only) */
+int64_t dmm_plan_b_bytes(const dmm_plan* plan);
+
+/* DirtyMapMaker._solve_m (mapmaker.py:156-168): a = B^H (Ni o v) for every tile */
+int dmm_dirty_run(dmm_plan* plan, const void* B, const void* mvis, const double* mweight,
+                  void* alm);
+
+/* WienerMapMaker._solve_m (mapmaker.py:235-284):
+ *   a = (S^-1 + B~^H B~)^-1 B~^H v~,  B~ = sqrt(Ni) o B[:, l>=m],  S = amp^2 l^-tilt (l[0]:=1)
+ * factored on whichever side is smaller (the two branches at :267/:275 are the same
+ * estimator).  workspace [dev]: dmm_wiener_workspace_bytes() bytes.                 */
+int64_t dmm_wiener_workspace_bytes(const dmm_plan* plan);
+int dmm_wiener_run(dmm_plan* plan, const void* B, const void* mvis, const double* mweight,
+                   double prior_amp, double prior_tilt, void* workspace, void* alm);
+
+/* MaximumLikelihoodMapMaker._solve_m (mapmaker.py:184-201) with pinv_svd's rank rule
+ * (mapmaker.py:287-300): keep sigma > rcond*sigma_max and sigma > acond.           */
+int64_t dmm_ml_workspace_bytes(const dmm_plan* plan);
+int dmm_ml_run(dmm_plan* plan, const void* B, const void* mvis, const double* mweight,
+               double acond, double rcond, void* workspace, void* alm);
+
+/* forward: bt.project_vector_sky_to_telescope (stream.py:109-112): v = B a per tile.
+ *   alm_in [dev] complex128 [nfreq, npol, n_m, lmax+1]; vis_out [dev] complex128
+ *   [n_m, 2, nfreq, npairs]                                                         */
+int dmm_project_run(dmm_plan* plan, const void* B, const void* alm_in, void* vis_out);
+
+/* --------------------------------------------- spherical-harmonic transforms (a10)
+ * hputil.sphtrans_inv_sky(alm, nside) (mapmaker.py:112) and hputil.sphtrans_sky
+ * (stream.py:85) [cora -> healpy], HEALPix RING ordering.
+ *   alm [dev] complex128 [nfreq, npol, mmax+1, lmax+1] (m-major)
+ *   map [dev] double     [nfreq, npol, 12*nside^2]
+ * npol = 1 (T) or 4 (T,E,B,V <-> I,Q,U,V).                                          */
+int dmm_alm2map(dmm_ctx* ctx, const void* alm, int nfreq, int npol, int lmax, int mmax,
+                int nside, double* map);
+int dmm_map2alm(dmm_ctx* ctx, const double* map, int nfreq, int npol, int lmax, int mmax,
+                int nside, int niter, void* alm);
+
+/* ------------------------------------------------ synthetic beam-transfer tiles
+ * Fill tiles with the counter-hash generator shared with oracle/synth.py
+ * (bit-identical in float64): value(seed, m, f, row, pol, l) with l<m -> 0.
+ * Used by SyntheticProvider / bench.py; not part of the reference.                  */
+int dmm_synth_beam_fill(dmm_ctx* ctx, const dmm_tile* tiles /*[host]*/, int64_t ntile,
+                        int npairs, int npol, int lmax, int b_dtype, int b_layout,
+                        uint64_t seed, void* B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRACO_AMD_H */

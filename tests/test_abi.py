@@ -1,0 +1,58 @@
+"""The C-ABI library loads and exports every symbol include/draco_amd.h declares (no GPU needed)."""
+
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "draco_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    lib = ctypes.CDLL(os.path.join(ROOT, "draco_amd", "libdraco_amd.so"))
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in draco_amd.h but not exported"
+
+
+def test_binding_matches_header():
+    from draco_amd import _lib
+
+    assert sorted(_lib.EXPORTED) == _declared()
+    assert _lib.lib.dmm_version() == 100
+
+
+def test_errors_without_gpu_are_loud():
+    """No silent fallback: without a GPU the context refuses, with a message."""
+    import torch
+
+    from draco_amd import _lib
+
+    if torch.cuda.is_available():
+        return
+    h = ctypes.c_void_p()
+    rc = _lib.lib.dmm_ctx_create(0, ctypes.byref(h))
+    assert rc != 0 and _lib.lib.dmm_last_error()
+    import pytest
+
+    from draco_amd.device import Context
+
+    with pytest.raises(RuntimeError):
+        Context(0)
+
+
+def test_argument_errors():
+    from draco_amd import _lib
+
+    import pytest
+
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib.dmm_ctx_sync(None))
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib.dmm_mfft_pack(None, None, 1, 8, None, 4, 1, None))

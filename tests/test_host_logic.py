@@ -1,0 +1,102 @@
+"""Host-side logic that needs no GPU: containers, adapters, telescope, provider protocol."""
+
+import numpy as np
+import pytest
+
+from draco_amd.core import containers, io
+from draco_amd.core.products import ArrayProvider, ProductManager, SyntheticProvider, TransitTelescope, synth_beam_tile
+from draco_amd.util import tools
+from oracle import synth as osyn
+
+
+def test_find_keys_and_invert():
+    assert tools.find_keys([400.0, 401.0, 402.0], [402.0, 400.0]) == [2, 0]
+    with pytest.raises(ValueError, match="Could not find all of the keys"):
+        tools.find_keys([400.0], [401.0], require_match=True)
+    x = np.array([0.0, 2.0, -4.0], np.float32)
+    r = tools.invert_no_zero(x)
+    assert r.dtype == np.float32 and np.array_equal(r, np.array([0.0, 0.5, -0.25], np.float32))
+
+
+def test_telescope_pairs_match_survey_formula():
+    for ncyl, nf in ((1, 8), (2, 16), (2, 4)):
+        tel = TransitTelescope(np.arange(3.0), lmax=4, ncyl=ncyl, nfeed_cyl=nf)
+        assert tel.npairs == osyn.npairs_of(ncyl, nf)
+        assert tel.nfeed == ncyl * nf * 2
+        assert len(tel.index_map_prod) == tel.nfeed * (tel.nfeed + 1) // 2
+        assert tel.uniquepairs.shape == (tel.npairs, 2)
+        # every product maps to a stack entry and back
+        rev = tel.reverse_map_stack
+        assert rev["stack"].max() == tel.npairs - 1
+        st = tel.index_map_stack
+        assert np.all(rev["stack"][st["prod"]] == np.arange(tel.npairs))
+
+
+def test_adapters():
+    tel = TransitTelescope(np.arange(3.0), lmax=4, ncyl=1, nfeed_cyl=2)
+    bt = SyntheticProvider(tel)
+    assert io.get_beamtransfer(bt) is bt
+    assert io.get_beamtransfer(ProductManager(bt)) is bt
+    assert io.get_telescope(bt) is tel and io.get_telescope(tel) is tel
+    with pytest.raises(RuntimeError, match="Could not get BeamTransfer instance"):
+        io.get_beamtransfer(object())
+    with pytest.raises(RuntimeError, match="Could not get telescope instance"):
+        io.get_telescope(42)
+
+    class Foreign:  # looks like driftscan's BeamTransfer
+        telescope = tel
+        ntel, nsky = 2 * tel.npairs, 4 * 5
+
+        def beam_m(self, m, fi=None):
+            return np.zeros((2, tel.npairs, 4, 5), complex)
+
+    f = io.get_beamtransfer(Foreign())
+    assert f.ntel == 2 * tel.npairs and f.beam_m(0, fi=0).shape == (2, tel.npairs, 4, 5)
+
+
+def test_synthetic_tiles_twin():
+    a = osyn.beam_tile(3000, 3, 2, 7, 4, 9)
+    b = synth_beam_tile(3000, 3, 2, 7, 4, 9)
+    assert np.array_equal(a, b)
+    assert np.all(a[..., :3] == 0) and np.all(a[..., 3:] != 0)
+    assert abs(a[..., 3:].var() * 14 - 1) < 0.1
+    assert not np.array_equal(a, osyn.beam_tile(3000, 3, 1, 7, 4, 9))
+
+
+def test_containers_axes_and_dtypes():
+    tel = TransitTelescope(np.linspace(400, 800, 5, endpoint=False), lmax=4, ncyl=1, nfeed_cyl=2)
+    ss = containers.SiderealStream(freq=tel.frequencies, ra=16, stack=tel.npairs)
+    assert ss.vis.shape == (5, tel.npairs, 16) and ss.vis.dtype == np.complex64
+    assert ss.weight.dtype == np.float32
+    assert ss.ra[1] == 360.0 / 16
+    ss.attrs["tag"] = "x"
+    mm = containers.MModes(mmax=8, oddra=False, axes_from=ss, attrs_from=ss)
+    assert mm.vis.shape == (9, 2, 5, tel.npairs) and mm.vis.dtype == np.complex128 and mm.weight.dtype == np.float64
+    assert mm.mmax == 8 and mm.oddra is False and mm.attrs["tag"] == "x"
+    assert list(mm.index_map["msign"]) == ["+", "-"]
+    assert np.array_equal(mm.index_map["freq"]["centre"], tel.frequencies)
+    mp = containers.Map(nside=4, axes_from=mm)
+    assert mp.map.shape == (5, 4, 192) and mp.map.dtype == np.float64 and mp.nside == 4
+    ss.vis[0, 0, 0] = 1 + 2j
+    assert ss.vis[:][0, 0, 0] == np.complex64(1 + 2j)
+
+
+def test_array_provider():
+    tel = TransitTelescope(np.arange(2.0), lmax=3, ncyl=1, nfeed_cyl=1)
+    tiles = {(m, f): osyn.beam_tile(1, m, f, tel.npairs, 4, 3) for m in range(4) for f in range(2)}
+    bt = ArrayProvider(tel, lambda m, f: tiles[(m, f)])
+    assert bt.ntel == 2 * tel.npairs and bt.nsky == 16
+    assert bt.beam_m(2).shape == (2, 2, tel.npairs, 4, 4)
+    assert np.array_equal(bt.beam_m(1, fi=1), tiles[(1, 1)])
+
+
+def test_task_config():
+    from draco_amd.analysis.mapmaker import WienerMapMaker
+    from draco_amd.analysis.transform import MModeTransform
+
+    t = MModeTransform()
+    assert t.remove_integration_window is False and t.use_fftw is True
+    w = WienerMapMaker(prior_amp=2, nside=64)
+    assert w.prior_amp == 2.0 and isinstance(w.prior_amp, float) and w.prior_tilt == 0.5 and w.nside == 64
+    with pytest.raises(AttributeError):
+        WienerMapMaker(bogus=1)
