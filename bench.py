@@ -1,0 +1,316 @@
+#!/usr/bin/env python
+"""Headline benchmark: m-modes/sec through MModeTransform + DirtyMapMaker.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one full pass of the hot path over one sidereal day of synthetic
+CHIME-pathfinder-shaped data at BASELINE.json's metric configuration (128 feeds ->
+379 stacked baselines, 256 frequencies, 1024 RA samples, lmax = mmax = 512; cfg 3 of
+SURVEY.md section 8d): sidereal-time -> m FFT + pack + noise weights for all 97 024
+(freq, baseline) rows, then all 131 328 (m, freq) Dirty solves a = B^H N^-1 v.
+Inputs (SiderealStream arrays and the B pool) are resident in HBM when the clock starts;
+the clock stops when the a_lm of every (m, f) is resident in HBM (SURVEY.md 8d metric).
+
+B residency (stated with every number): all B_m[f] of cfg 3 are 1.64 TB in complex128
+(l >= m columns only) and cannot be resident at once, so the job streams its 256
+frequencies through an HBM pool holding `pool_freqs` frequencies' worth of DISTINCT tiles
+(default 32 -> 205 GB, >> 256 MiB Infinity Cache), cycled 256/pool_freqs times per step:
+every byte of B is read from HBM exactly once per solve, but tile contents repeat
+between cycles ("B=hbm-pool").
+
+Multi-GPU (torchrun, one rank per GPU): weak scaling -- every rank owns its own 256
+frequencies of a 256*N-frequency job (frequency is the path's natural shard axis; no
+collective inside the timed region), value = N * (mmax+1) / T with T the max over ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=3, help="SURVEY 8d config number (metric is quoted on 3)")
+    ap.add_argument("--b-dtype", default="complex128", choices=["complex128", "complex64"])
+    ap.add_argument("--pool-freqs", type=int, default=0, help="frequencies' worth of distinct B tiles resident (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (c64 pool, cfg2 all-resident)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, seconds):
+    """Oracle (NumPy restatement of the reference) timed on this box's host cores.
+
+    Bounded sample of the SAME workload: the complex64 FFT + pack of a slice of rows, and
+    Dirty solves (complex128 np.dot) over an m-stratified set of tiles drawn from a RAM
+    pool; extrapolated linearly to the full job.  HDF5 I/O of B (dominant in real
+    reference runs) is excluded, as on the GPU side.
+    """
+    from oracle import mapmaker as omm
+    from oracle import synth as osyn
+    from oracle import transform as otr
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        nthreads = 1
+    npairs = osyn.npairs_of(cfg["ncyl"], cfg["nfeed_cyl"])
+    nfreq, nra, lmax = cfg["nfreq"], cfg["nra"], cfg["lmax"]
+    rng = np.random.default_rng(0)
+
+    # (1) transform: time a slice of frequencies
+    nf_s = max(1, min(nfreq, 4))
+    vis = (rng.standard_normal((nf_s, npairs, nra), dtype=np.float32) + 1j * rng.standard_normal((nf_s, npairs, nra), dtype=np.float32)).astype(np.complex64)
+    w = rng.uniform(0.5, 1.5, (nf_s, npairs, nra)).astype(np.float32)
+    t0 = time.perf_counter()
+    otr.mmode_transform(vis, w, mmax=lmax)
+    t_fft_per_freq = (time.perf_counter() - t0) / nf_s
+
+    # (2) solves: RAM pool of distinct tiles at stratified m, cycled until `seconds` of work
+    ms = np.unique(np.linspace(0, lmax, 24).astype(int))
+    tiles = [osyn.beam_tile(3000, int(m), 0, npairs, 4, lmax) for m in ms]
+    v = rng.standard_normal((2, npairs)) + 1j * rng.standard_normal((2, npairs))
+    Ni = rng.uniform(0.5, 1.5, (2, npairs))
+    per_m = np.zeros(len(ms))
+    cnt = np.zeros(len(ms))
+    t_end = time.perf_counter() + seconds
+    nsolve = 0
+    while time.perf_counter() < t_end:
+        for i, bm in enumerate(tiles):
+            t0 = time.perf_counter()
+            omm.dirty_solve(bm, v, Ni)
+            per_m[i] += time.perf_counter() - t0
+            cnt[i] += 1
+            nsolve += 1
+    per_m /= np.maximum(cnt, 1)
+    # the reference multiplies the FULL tile (zeros included), cost is m-independent: mean
+    t_solve = float(per_m.mean())
+    t_job = t_fft_per_freq * nfreq + t_solve * (lmax + 1) * nfreq
+    return {
+        "value": (lmax + 1) / t_job,
+        "unit": "m-modes/s",
+        "cores": int(nthreads),
+        "kind": "port",
+        "sample": f"FFT+pack of {nf_s}/{nfreq} freqs; {nsolve} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from a {len(tiles)}-tile RAM pool) in {seconds:.0f}s; extrapolated linearly",
+        "t_solve_ms": t_solve * 1e3,
+        "t_fft_per_freq_ms": t_fft_per_freq * 1e3,
+    }
+
+
+class Job:
+    """Device-resident inputs + plans for one rank's share of the job."""
+
+    def __init__(self, cfg, rank, b_dtype, pool_freqs, seed=3003):
+        import torch
+
+        from draco_amd import _lib
+        from draco_amd.analysis._solve import Slab
+        from draco_amd.core.products import SyntheticProvider, TransitTelescope
+        from draco_amd.device import Context
+        from oracle import synth as osyn  # shapes only (CONFIGS); no oracle compute here
+
+        self.torch = torch
+        self.ctx = ctx = Context.get()
+        self.cfg = cfg
+        nfreq, nra, lmax = cfg["nfreq"], cfg["nra"], cfg["lmax"]
+        self.nfreq, self.nra, self.lmax = nfreq, nra, lmax
+        # this rank's frequencies of the weak-scaled job
+        freqs = osyn.frequencies(nfreq) + 400.0 * rank
+        self.tel = tel = TransitTelescope(freqs, lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+        self.bt = SyntheticProvider(tel, seed=seed + rank)
+        self.npairs = npairs = tel.npairs
+        self.dt = {"complex128": _lib.DMM_C128, "complex64": _lib.DMM_C64}[b_dtype]
+        es = 16 if self.dt == _lib.DMM_C128 else 8
+
+        gen = torch.Generator(device=ctx.device).manual_seed(1000 + rank)
+        self.vis = torch.randn((nfreq, npairs, nra), dtype=torch.complex64, device=ctx.device, generator=gen)
+        self.weight = torch.rand((nfreq, npairs, nra), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
+        self.n_m = lmax + 1
+        self.alm = torch.empty((nfreq, 4, self.n_m, lmax + 1), dtype=torch.complex128, device=ctx.device)
+
+        per_freq = sum(2 * npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * es
+        if pool_freqs <= 0:
+            free, _ = torch.cuda.mem_get_info(ctx.device)
+            reserve = (self.n_m * 2 * nfreq * npairs) * 24 + (8 << 30)  # m-modes + slack
+            pool_freqs = 1
+            while pool_freqs * 2 <= nfreq and pool_freqs * 2 * per_freq <= (free - reserve) * 0.9:
+                pool_freqs *= 2
+            pool_freqs = min(pool_freqs, 32)
+        while nfreq % pool_freqs:
+            pool_freqs -= 1
+        self.pool_freqs = pool_freqs
+        ms = np.tile(np.arange(lmax + 1, dtype=np.int32), pool_freqs)
+        fs = np.repeat(np.arange(pool_freqs, dtype=np.int32), lmax + 1)
+        self.slab = Slab(ctx, self.bt, ms, fs, fs, self.dt, _lib.DMM_B_PACKED, nfreq, self.n_m)
+        self.pool_bytes = self.slab.pool.numel() * es
+        ntel = 2 * npairs
+        # algorithmic bytes of ONE dirty launch: B (l>=m) + v, Ni + a per tile
+        self.dirty_bytes = self.slab.b_bytes + self.slab.ntile * ntel * (16 + 8) + sum(4 * (lmax + 1 - int(m)) * 16 for m in ms)
+        self.ncycle = nfreq // pool_freqs
+        self._lib = _lib
+        ctx.sync()
+
+    def step(self, time_dirty=False):
+        """One pass; returns the HIP-event time of the Dirty launches if asked."""
+        from draco_amd.analysis.transform import mmode_forward
+        from draco_amd.device import ptr
+
+        lib, ctx = self._lib.lib, self.ctx
+        mv, mw = mmode_forward(ctx, self.vis, self.weight, self.lmax)
+        if time_dirty:
+            ctx.timer_start()
+        for c in range(self.ncycle):
+            f0 = c * self.pool_freqs
+            mv_c = mv[:, :, f0:, :]  # pointer offset only: strides stay those of the full array
+            mw_c = mw[:, :, f0:, :]
+            alm_c = self.alm[f0:]
+            self._lib.check(
+                lib.dmm_dirty_run(
+                    self.slab.plan,
+                    ptr(self.slab.pool),
+                    mv_c.data_ptr(),
+                    mw_c.data_ptr(),
+                    alm_c.data_ptr(),
+                )
+            )
+        return ctx.timer_stop() if time_dirty else None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+
+    from oracle import synth as osyn
+
+    cfg = osyn.CONFIGS[args.config]
+    job = Job(cfg, rank, args.b_dtype, args.pool_freqs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.step()
+    barrier()
+    t0 = time.perf_counter()
+    dirty_ms = 0.0
+    for _ in range(args.steps):
+        dirty_ms += job.step(time_dirty=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * (cfg["lmax"] + 1) / (elapsed / args.steps)
+    nlaunch = job.ncycle * args.steps
+    dirty_avg_ms = dirty_ms / nlaunch
+    achieved = job.dirty_bytes / (dirty_avg_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "m-modes/sec through MModeTransform+DirtyMapMaker (128-feed, 256-freq)",
+        "value": value,
+        "unit": "m-modes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64 accumulate; B stored " + args.b_dtype + "; FFT complex64 (as the reference)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"cfg{args.config}: {job.tel.nfeed}-feed ({job.npairs} stacked baselines), {cfg['nfreq']} freq per GPU, {cfg['nra']} RA, lmax=mmax={cfg['lmax']}: MModeTransform + DirtyMapMaker solves ({(cfg['lmax']+1)*cfg['nfreq']} (m,f) tiles)",
+            "b_residency": f"hbm-pool: {job.pool_freqs} of {cfg['nfreq']} frequencies' B tiles resident ({job.pool_bytes/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), cycled {job.ncycle}x per step",
+            "solves_per_s": world * (cfg["lmax"] + 1) * cfg["nfreq"] / (elapsed / args.steps),
+            "parallelism": f"freq-sharded x{world} (no collective in the timed region)",
+        },
+        "roofline": {
+            "kernel": "k_dirty (a = B^H N^-1 v, batched over (m,f))",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_launch": job.dirty_bytes,
+            "avg_launch_ms": dirty_avg_ms,
+            "launches": nlaunch,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+        try:
+            # complex64 storage of B (half the bytes, float64 accumulation)
+            if args.b_dtype == "complex128":
+                del job
+                torch.cuda.empty_cache()
+                j2 = Job(cfg, rank, "complex64", args.pool_freqs)
+                j2.step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dms = 0.0
+                for _ in range(args.steps):
+                    dms += j2.step(time_dirty=True)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                extra["b_complex64"] = {
+                    "value": (cfg["lmax"] + 1) / (el / args.steps),
+                    "unit": "m-modes/s",
+                    "roofline_GBs": j2.dirty_bytes / (dms / (j2.ncycle * args.steps) * 1e-3) / 1e9,
+                    "pool_freqs": j2.pool_freqs,
+                }
+                del j2
+                torch.cuda.empty_cache()
+        except Exception as e:  # secondary numbers must never break the headline line
+            extra["error"] = repr(e)
+        out["extra"] = extra
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so (SONAME
+# libamdhip64.so.7) and libdraco_amd.so is linked against the same SONAME, so importing
+# torch FIRST makes the dynamic loader resolve our dependency to the runtime torch already
+# loaded.  In the other order two runtimes coexist and the second one sees no device.
+import torch  # noqa: F401  (must precede the CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdraco_amd.so")
 

@@ -111,6 +111,7 @@ class ContainerBase:
         self.attrs = {}
         self.comm = comm
         self.reverse_map = {}
+        axes = {k: v for k, v in axes.items() if v is not None}
         if axes_from is not None:
             for ax in self._axes:
                 if ax in axes_from.index_map and ax not in axes:

@@ -40,6 +40,7 @@ def _mix64(z):
 
 
 def _tile_key(seed, m, f):
+    m, f = int(m), int(f)
     with np.errstate(over="ignore"):
         a = _mix64(np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(m + 1))
         return _mix64(a ^ (np.uint64(0xD1B54A32D192ED03) * np.uint64(f + 1)))
@@ -47,6 +48,7 @@ def _tile_key(seed, m, f):
 
 def synth_beam_tile(seed, m, f, npairs, npol, lmax):
     """Host twin of ``k_synth_fill`` (``csrc/synth.hip``): complex128 ``[2, npairs, npol, lmax+1]``."""
+    m = int(m)
     ntel = 2 * npairs
     scale = np.sqrt(3.0 / (2.0 * ntel))
     key = _tile_key(seed, m, f)

@@ -30,12 +30,14 @@ def _mix64(z):
 
 
 def tile_key(seed: int, m: int, f: int) -> int:
+    seed, m, f = int(seed), int(m), int(f)
     a = _mix64_int(seed + 0x9E3779B97F4A7C15 * (m + 1))
     return _mix64_int(a ^ ((0xD1B54A32D192ED03 * (f + 1)) & MASK))
 
 
 def beam_tile(seed, m, f, npairs, npol, lmax):
     """complex128 ``[2, npairs, npol, lmax+1]``, uniform real/imag parts, variance 1/ntel, zero for l<m."""
+    m = int(m)
     ntel = 2 * npairs
     scale = np.sqrt(3.0 / (2.0 * ntel))
     key = np.uint64(tile_key(seed, m, f))

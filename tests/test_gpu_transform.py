@@ -165,9 +165,9 @@ def test_roundtrip_full_size(T):
     back = T.mmode_inverse(ctx, mv, nra)
     err = (back - vis).abs().max().item() / vis.abs().max().item()
     assert err < 3e-6
-    # Parseval: sum |x|^2 / N == N * sum |modes|^2 ... per row, in float64
+    # Parseval with modes = F/N: sum_t |x|^2 / N == sum_m |modes|^2, per row, in float64
     p_t = (vis.to(torch.complex128).abs() ** 2).sum(-1) / nra
-    p_m = (mv.abs() ** 2).sum((0, 1)) * nra
+    p_m = (mv.abs() ** 2).sum((0, 1))
     assert ((p_t - p_m).abs().max() / p_t.max()).item() < 1e-5
     # weights: nra^2 / sum(1/w), identical for every (m, sign)
     ws = nra**2 / (1.0 / w.double()).sum(-1)
