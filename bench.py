@@ -240,6 +240,14 @@ def main():
     dirty_avg_ms = dirty_ms / nlaunch
     achieved = job.dirty_bytes / (dirty_avg_ms * 1e-3) / 1e9
 
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC profile of this same command, if it matches
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["k_dirty"]
+        if rec["config"] == args.config and rec["b_dtype"] == args.b_dtype and rec["pool_freqs"] == job.pool_freqs:
+            traffic = rec["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "m-modes/sec through MModeTransform+DirtyMapMaker (128-feed, 256-freq)",
         "value": value,
@@ -266,7 +274,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "bytes_per_launch": job.dirty_bytes,
             "avg_launch_ms": dirty_avg_ms,
             "launches": nlaunch,
