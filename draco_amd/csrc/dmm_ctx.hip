@@ -14,6 +14,21 @@ int dmm_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+int dmm_get_scratch(dmm_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->scratch_bytes < bytes) {
+    if (ctx->scratch) {
+      DMM_HIP(hipStreamSynchronize(ctx->stream));  // kernels may still be reading the old block
+      (void)hipFree(ctx->scratch);
+      ctx->scratch = nullptr;
+      ctx->scratch_bytes = 0;
+    }
+    DMM_HIP(hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+  }
+  *out = ctx->scratch;
+  return DMM_OK;
+}
+
 extern "C" {
 
 int dmm_version(void) { return DMM_VERSION; }
@@ -54,6 +69,7 @@ int dmm_ctx_destroy(dmm_ctx* c) {
   free_tables(c->ifft);
   for (auto& kv : c->sht)
     if (kv.second) (void)hipFree(kv.second);
+  if (c->scratch) (void)hipFree(c->scratch);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;

@@ -24,7 +24,12 @@ struct dmm_ctx {
   std::map<int, dmm_fft_tables> fft;       // forward tables by nra
   std::map<int, dmm_fft_tables> ifft;      // inverse tables by nra
   std::map<int64_t, void*> sht;            // SHT geometry caches keyed by (nside,lmax,mmax)
+  void* scratch = nullptr;                 // grow-only workspace (ring coefficients, Gram matrices ...)
+  size_t scratch_bytes = 0;
 };
+
+// library-owned scratch of at least `bytes` (valid until the next call that asks for more)
+int dmm_get_scratch(dmm_ctx* ctx, size_t bytes, void** out);
 
 struct dmm_plan {
   dmm_ctx* ctx = nullptr;

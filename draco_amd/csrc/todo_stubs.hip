@@ -11,10 +11,4 @@ int64_t dmm_ml_workspace_bytes(const dmm_plan*) { return 0; }
 int dmm_ml_run(dmm_plan*, const void*, const void*, const double*, double, double, void*, void*) {
   return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_ml_run: not built yet");
 }
-int dmm_alm2map(dmm_ctx*, const void*, int, int, int, int, int, double*) {
-  return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_alm2map: not built yet");
-}
-int dmm_map2alm(dmm_ctx*, const double*, int, int, int, int, int, int, void*) {
-  return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_map2alm: not built yet");
-}
 }
