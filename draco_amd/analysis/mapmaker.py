@@ -207,9 +207,22 @@ _BUILTIN_SOLVERS = (BaseMapMaker._solve_m,)
 def pinv_svd(M, acond=1e-4, rcond=1e-3):
     """Pseudo-inverse with the reference's rank rule (``mapmaker.py:287-300``), on the GPU.
 
-    Realised through the ML kernel: column ``j`` of ``pinv(M)`` is the ML solve of the unit
-    vector ``e_j`` with unit weights.
+    Realised through the ML kernel (``dmm_ml_run``): column ``i`` of ``pinv(M)`` is the ML
+    solve of the unit vector ``e_i`` with unit weights, all ``nrow`` solves in one batch.
     """
+    from ..core.products import ArrayProvider, TransitTelescope
+
     M = np.asarray(M, dtype=np.complex128)
     nrow, ncol = M.shape
-    raise NotImplementedError("pinv_svd as a standalone helper is served by dmm_ml_run; see MaximumLikelihoodMapMaker")
+    npairs = (nrow + 1) // 2
+    Mp = np.zeros((2 * npairs, ncol), dtype=np.complex128)  # an odd row count is padded with a zero row
+    Mp[:nrow] = M
+    tel = TransitTelescope(np.arange(float(2 * npairs)), lmax=ncol - 1, mmax=0, num_pol_sky=1, npairs=npairs)
+    bt = ArrayProvider(tel, lambda m, f: Mp)
+    ctx = Context.get()
+    eng = _solve.SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=False)
+    eye = np.eye(2 * npairs, dtype=np.complex128).reshape(2 * npairs, 2, npairs).transpose(1, 0, 2)  # [sign, f, pair]
+    mvis = ctx.to_device(eye[np.newaxis], np.complex128)
+    mw = torch.ones(mvis.shape, dtype=torch.float64, device=ctx.device)
+    alm = eng.solve("ml", mvis, mw, list(range(2 * npairs)), 0, acond=acond, rcond=rcond)  # [f, 1, 1, ncol]
+    return alm[:nrow, 0, 0, :].cpu().numpy().T.copy()

@@ -36,6 +36,7 @@ struct dmm_plan {
   int64_t ntile = 0;
   int npairs = 0, npol = 0, lmax = 0, nfreq = 0, n_m = 0, b_dtype = 0, b_layout = 0;
   std::vector<dmm_tile> tiles_h;
+  std::vector<int32_t> work_start_h;   // host copy of work_start_d
   dmm_tile* tiles_d = nullptr;
   int32_t* work_start_d = nullptr;   // [ntile+1] first column-block task of each tile (dirty)
   int32_t* work_rows_d = nullptr;    // [ntile+1] first 64-row-block task of each tile (project)

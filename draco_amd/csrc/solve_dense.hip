@@ -1,0 +1,723 @@
+// Dense per-(m, freq) solves: Wiener filter (Gram + Cholesky) and maximum likelihood
+// (Gram + Hermitian Jacobi eigensolver with the reference's singular-value cut).
+//
+//   dmm_wiener_run  WienerMapMaker._solve_m             reference mapmaker.py:235-284
+//   dmm_ml_run      MaximumLikelihoodMapMaker._solve_m  reference mapmaker.py:184-201
+//                   + pinv_svd                          reference mapmaker.py:287-300
+//
+// Both are formed on the TELESCOPE side (ntel x ntel), which is the reference's own
+// branch whenever ntel <= nsky (mapmaker.py:267,275-278: every BASELINE config) and is
+// algebraically the same estimator otherwise:
+//   Wiener:  G = I + D B S B^H D,  a = S o B^H D G^-1 D v            (D = diag sqrt(Ni))
+//   ML:      G =     D B   B^H D = U L U^H,  a = B^H D U_r L_r^-1 U_r^H D v
+//            with the columns kept where sqrt(L) > rcond*sqrt(L_max) and sqrt(L) > acond.
+// Rows with Ni = 0 decouple (unit diagonal / zero eigenvalue): no NaN, like the reference.
+//
+// Kernel structure (all batched over the matrices of a sub-batch):
+//   k_nt<GRAM>    G(I,J)  = [delta] + d_i d_j sum_k B[i,k] S_k conj(B[j,k])   64x64 tiles, f64 MFMA
+//   k_nt<UPDATE>  A(I,J) -= sum_{k<64J} L[i,k] conj(L[j,k])                   (left-looking Cholesky)
+//   k_chol_diag   A(J,J) = L L^H in LDS, Linv_J = L^-1
+//   k_nt<PANEL>   L(I,J)  = A(I,J) Linv_J^H
+//   k_chol_solve  y = L^-H L^-1 (D v);  w = D y
+//   k_dirty (w mode, solve_dirty.hip)  a = S o B^H w
+// The complex products run on v_mfma_f64_16x16x4_f64 through the real embedding
+//   Re = [Xr Xi].[Yr Yi]^T,  Im = [Xr Xi].[-Yi Yr]^T   (4 real k per 2 complex k).
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "dmm_internal.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int TB = 64;        // tile edge (rows and columns of an output tile)
+constexpr int KC = 16;        // complex columns per staged chunk
+constexpr int LP = 2 * KC + 2;  // LDS row pitch in doubles: == 2 (mod 32) -> conflict-free ds_read_b64
+
+enum { MODE_GRAM = 0, MODE_UPDATE = 1, MODE_PANEL = 2 };
+
+struct DenseParams {
+  // batch
+  const dmm_tile* tiles;   // plan tiles (device), this sub-batch starts at tile0
+  int64_t tile0;
+  int nmat;
+  int N, Np, T;            // matrix order, padded order (multiple of 64), Np/64
+  // gram sources
+  const void* B;
+  int b_c128, full_layout;
+  int npairs, npol, lmax, nfreq;
+  const double2* mvis;
+  const double* mweight;
+  const double* Sl;        // [lmax+1] prior per l, or nullptr (S = 1)
+  int add_identity;
+  // storage
+  double2* A;              // [nmat][Np][Np]
+  double2* Linv;           // [nmat][T][64][64]
+  double2* wbuf;           // [nmat][N]
+  int J;                   // current column block (update / panel / diag)
+};
+
+__device__ __forceinline__ double2 load_bc(const void* B, int c128, int64_t off) {
+  if (c128) return reinterpret_cast<const double2*>(B)[off];
+  const float2 v = reinterpret_cast<const float2*>(B)[off];
+  return make_double2((double)v.x, (double)v.y);
+}
+
+// Stage rows [row0, row0+64) x complex columns [k0, k0+KC) of an operand into LDS as doubles
+// [64][LP] (re, im interleaved).  SRC: 0 = beam tile (gram), 1 = matrix A, 2 = Linv block.
+template <int SRC>
+__device__ __forceinline__ void stage(double* lds, const DenseParams& p, const dmm_tile& tile, int mat, int row0,
+                                      int k0, int K, bool scale_s) {
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
+  const int row = row0 + r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = k0 + c0 + c;
+    double2 v = make_double2(0.0, 0.0);
+    if (SRC == 0) {
+      if (row < p.N && k < K) {
+        const int L = p.lmax + 1 - tile.m;
+        const int pol = k / L, lrel = k - pol * L;
+        const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+        const int64_t off = tile.b_off + (int64_t)row * p.npol * pol_stride + (int64_t)pol * pol_stride +
+                            (p.full_layout ? tile.m : 0) + lrel;
+        v = load_bc(p.B, p.b_c128, off);
+        if (scale_s && p.Sl) {
+          const double s = p.Sl[tile.m + lrel];
+          v.x *= s;
+          v.y *= s;
+        }
+      }
+    } else if (SRC == 1) {
+      if (k < K) v = p.A[((int64_t)mat * p.Np + row) * p.Np + k];
+    } else {
+      v = p.Linv[(((int64_t)mat * p.T + p.J) * TB + (row - row0)) * TB + k];
+    }
+    *reinterpret_cast<double2*>(lds + r * LP + 2 * (c0 + c)) = v;
+  }
+}
+
+// One 64x64 complex output tile C(I,J) per block; 4 waves, each a 32x32 quadrant = 2x2 MFMA tiles.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
+  __shared__ __align__(16) double xs[TB * LP];
+  __shared__ __align__(16) double ys[TB * LP];
+  const int mat = blockIdx.y;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  int bi, bj;
+  if (MODE == MODE_GRAM) {
+    const int tt = blockIdx.x;
+    bi = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= tt) ++bi;
+    while (bi * (bi + 1) / 2 > tt) --bi;
+    bj = tt - bi * (bi + 1) / 2;
+  } else if (MODE == MODE_UPDATE) {
+    bi = p.J + blockIdx.x;
+    bj = p.J;
+  } else {
+    bi = p.J + 1 + blockIdx.x;
+    bj = p.J;
+  }
+  const int I0 = bi * TB, J0 = bj * TB;
+  const int K = MODE == MODE_GRAM ? p.npol * (p.lmax + 1 - tile.m) : (MODE == MODE_UPDATE ? p.J * TB : TB);
+  const int kbase = MODE == MODE_PANEL ? J0 : 0;  // panel: X = A(I, J-block columns)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  v4d cre[2][2], cim[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();
+    if (MODE == MODE_GRAM) {
+      stage<0>(xs, p, tile, mat, I0, k0, K, false);
+      stage<0>(ys, p, tile, mat, J0, k0, K, true);
+    } else if (MODE == MODE_UPDATE) {
+      stage<1>(xs, p, tile, mat, I0, k0, K, false);
+      stage<1>(ys, p, tile, mat, J0, k0, K, false);
+    } else {
+      stage<1>(xs, p, tile, mat, I0, kbase + k0, kbase + K, false);
+      stage<2>(ys, p, tile, mat, 0, k0, K, false);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2 * KC; kk += 4) {
+      double a[2], b[2], b2[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = xs[(32 * wr + 16 * t + lr) * LP + kk + lk];
+        b[t] = ys[(32 * wc + 16 * t + lr) * LP + kk + lk];
+        const double o = ys[(32 * wc + 16 * t + lr) * LP + kk + (lk ^ 1)];
+        b2[t] = (lk & 1) ? o : -o;
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], cre[ti][tj], 0, 0, 0);
+          cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b2[tj], cim[ti][tj], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue: lane holds rows (lk + 4*reg), column lr of each 16x16 tile
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = I0 + 32 * wr + 16 * ti + lk + 4 * reg;
+        const int j = J0 + 32 * wc + 16 * tj + lr;
+        double2* dst = p.A + ((int64_t)mat * p.Np + i) * p.Np + j;
+        double re = cre[ti][tj][reg], im = cim[ti][tj][reg];
+        if (MODE == MODE_GRAM) {
+          double di = 0.0, dj = 0.0;
+          if (i < p.N) {
+            const int s = i >= p.npairs, pp = i - s * p.npairs;
+            di = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+          }
+          if (j < p.N) {
+            const int s = j >= p.npairs, pp = j - s * p.npairs;
+            dj = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+          }
+          re *= di * dj;
+          im *= di * dj;
+          if (i == j) {
+            im = 0.0;  // Hermitian diagonal is real by construction; drop rounding dust
+            if (p.add_identity) re += 1.0;  // padded rows (d = 0): unit diagonal for Cholesky, zero eigenvalue for ML
+          }
+          *dst = make_double2(re, im);
+        } else if (MODE == MODE_UPDATE) {
+          const double2 old = *dst;
+          *dst = make_double2(old.x - re, old.y - im);
+        } else {
+          *dst = make_double2(re, im);
+        }
+      }
+}
+
+// Factor the 64x64 diagonal block J of every matrix in LDS and invert the factor.
+__global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
+  extern __shared__ __align__(16) unsigned char smem_cd[];
+  double2(*a)[TB + 1] = reinterpret_cast<double2(*)[TB + 1]>(smem_cd);
+  double2(*li)[TB + 1] = a + TB;
+  const int mat = blockIdx.x;
+  const int J0 = p.J * TB;
+  double2* Ablk = p.A + ((int64_t)mat * p.Np + J0) * p.Np + J0;
+  for (int idx = threadIdx.x; idx < TB * TB; idx += kThreads) {
+    const int i = idx >> 6, j = idx & 63;
+    a[i][j] = j <= i ? Ablk[(int64_t)i * p.Np + j] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  for (int k = 0; k < TB; ++k) {
+    const double d = sqrt(a[k][k].x);
+    const double inv = 1.0 / d;
+    __syncthreads();
+    if (threadIdx.x == 0) a[k][k] = make_double2(d, 0.0);
+    for (int i = k + 1 + threadIdx.x; i < TB; i += kThreads) {
+      a[i][k].x *= inv;
+      a[i][k].y *= inv;
+    }
+    __syncthreads();
+    // trailing update of the lower triangle: a[i][j] -= a[i][k] conj(a[j][k]),  k < j <= i
+    const int n = TB - 1 - k;
+    for (int idx = threadIdx.x; idx < n * n; idx += kThreads) {
+      const int i = k + 1 + idx / n, j = k + 1 + idx % n;
+      if (j <= i) {
+        const double2 x = a[i][k], y = a[j][k];
+        a[i][j].x -= x.x * y.x + x.y * y.y;
+        a[i][j].y -= x.y * y.x - x.x * y.y;
+      }
+    }
+    __syncthreads();
+  }
+  // inverse of the lower-triangular factor: column j by forward substitution (one thread per column)
+  if (threadIdx.x < TB) {
+    const int j = threadIdx.x;
+    for (int i = 0; i < TB; ++i) li[i][j] = make_double2(0.0, 0.0);
+    li[j][j] = make_double2(1.0 / a[j][j].x, 0.0);
+    for (int i = j + 1; i < TB; ++i) {
+      double sx = 0.0, sy = 0.0;
+      for (int q = j; q < i; ++q) {
+        const double2 l = a[i][q], x = li[q][j];
+        sx += l.x * x.x - l.y * x.y;
+        sy += l.x * x.y + l.y * x.x;
+      }
+      const double inv = 1.0 / a[i][i].x;
+      li[i][j] = make_double2(-sx * inv, -sy * inv);
+    }
+  }
+  __syncthreads();
+  double2* Lout = p.Linv + ((int64_t)mat * p.T + p.J) * TB * TB;
+  for (int idx = threadIdx.x; idx < TB * TB; idx += kThreads) {
+    const int i = idx >> 6, j = idx & 63;
+    Ablk[(int64_t)i * p.Np + j] = a[i][j];  // upper part zeroed
+    Lout[idx] = li[i][j];
+  }
+}
+
+// y = L^-H L^-1 (D v); w = D y.  One block per matrix, the vector lives in LDS.
+__global__ __launch_bounds__(kThreads) void k_chol_solve(DenseParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* y = reinterpret_cast<double2*>(smem);  // [Np]
+  double2* t = y + p.Np;                          // [64]
+  double2* red = t + TB;                          // [4][64]
+  const int mat = blockIdx.x;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  const double2* A = p.A + (int64_t)mat * p.Np * p.Np;
+  for (int i = threadIdx.x; i < p.Np; i += kThreads) {
+    double2 b = make_double2(0.0, 0.0);
+    if (i < p.N) {
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
+      const double d = sqrt(p.mweight[o]);
+      const double2 v = p.mvis[o];
+      b = make_double2(d * v.x, d * v.y);
+    }
+    y[i] = b;
+  }
+  __syncthreads();
+  const int i64 = threadIdx.x & 63, part = threadIdx.x >> 6;
+  // forward: L z = b, block row by block row
+  for (int J = 0; J < p.T; ++J) {
+    const int r = J * TB + i64;
+    double sx = 0.0, sy = 0.0;
+    for (int k = part; k < J * TB; k += 4) {  // each of 4 thread groups takes every 4th column
+      const double2 l = A[(int64_t)r * p.Np + k], z = y[k];
+      sx += l.x * z.x - l.y * z.y;
+      sy += l.x * z.y + l.y * z.x;
+    }
+    red[part * TB + i64] = make_double2(sx, sy);
+    __syncthreads();
+    if (part == 0) {
+      double2 s = y[r];
+      for (int q = 0; q < 4; ++q) {
+        s.x -= red[q * TB + i64].x;
+        s.y -= red[q * TB + i64].y;
+      }
+      t[i64] = s;
+    }
+    __syncthreads();
+    if (part == 0) {  // z_J = Linv_J t   (lower triangular)
+      const double2* Li = p.Linv + (((int64_t)mat * p.T + J) * TB + i64) * TB;
+      double zx = 0.0, zy = 0.0;
+      for (int q = 0; q <= i64; ++q) {
+        const double2 l = Li[q], v = t[q];
+        zx += l.x * v.x - l.y * v.y;
+        zy += l.x * v.y + l.y * v.x;
+      }
+      y[r] = make_double2(zx, zy);
+    }
+    __syncthreads();
+  }
+  // backward: L^H x = z
+  for (int J = p.T - 1; J >= 0; --J) {
+    const int c = J * TB + i64;
+    double sx = 0.0, sy = 0.0;
+    for (int k = (J + 1) * TB + part; k < p.Np; k += 4) {  // conj(L[k][c]) * x[k]; lanes -> adjacent c: coalesced
+      const double2 l = A[(int64_t)k * p.Np + c], z = y[k];
+      sx += l.x * z.x + l.y * z.y;
+      sy += l.x * z.y - l.y * z.x;
+    }
+    red[part * TB + i64] = make_double2(sx, sy);
+    __syncthreads();
+    if (part == 0) {
+      double2 s = y[c];
+      for (int q = 0; q < 4; ++q) {
+        s.x -= red[q * TB + i64].x;
+        s.y -= red[q * TB + i64].y;
+      }
+      t[i64] = s;
+    }
+    __syncthreads();
+    if (part == 0) {  // x_J = Linv_J^H t
+      const double2* Lb = p.Linv + ((int64_t)mat * p.T + J) * TB * TB;
+      double zx = 0.0, zy = 0.0;
+      for (int q = i64; q < TB; ++q) {
+        const double2 l = Lb[q * TB + i64], v = t[q];
+        zx += l.x * v.x + l.y * v.y;
+        zy += l.x * v.y - l.y * v.x;
+      }
+      y[c] = make_double2(zx, zy);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < p.N; i += kThreads) {
+    const int s = i >= p.npairs, pp = i - s * p.npairs;
+    const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+    p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * y[i].x, d * y[i].y);
+  }
+}
+
+// ---------------------------------------------------------------- Hermitian Jacobi (ML)
+// Cyclic two-sided Jacobi on G (Np x Np, full storage after mirroring), eigenvectors
+// accumulated in V; one block per matrix, rotations of a round applied by rows then columns.
+// Round-robin ordering gives Np/2 disjoint pairs per round.  O(sweeps * Np^3): meant for the
+// moderate orders of the parity configs; see DESIGN.md for the blocked successor.
+struct JacobiParams {
+  DenseParams d;
+  double2* V;      // [nmat][Np][Np]
+  double acond, rcond;
+  int max_sweeps;
+};
+
+__global__ __launch_bounds__(kThreads) void k_mirror(DenseParams p) {  // fill the upper triangle: A[j][i] = conj(A[i][j])
+  const int mat = blockIdx.y;
+  double2* A = p.A + (int64_t)mat * p.Np * p.Np;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)p.Np * p.Np;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / p.Np), j = (int)(idx % p.Np);
+    if (j > i) {
+      const double2 v = A[(int64_t)j * p.Np + i];
+      A[idx] = make_double2(v.x, -v.y);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_jacobi(JacobiParams jp) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DenseParams& p = jp.d;
+  const int n = p.Np, half = n / 2;
+  int* top = reinterpret_cast<int*>(smem);        // [half]
+  int* bot = top + half;                          // [half]
+  double* cs = reinterpret_cast<double*>(bot + half);  // [half] cos
+  double2* sn = reinterpret_cast<double2*>(cs + half); // [half] complex sin
+  __shared__ double off_norm;
+  __shared__ int changed;
+  const int mat = blockIdx.x;
+  double2* A = p.A + (int64_t)mat * n * n;
+  double2* V = jp.V + (int64_t)mat * n * n;
+  for (int64_t idx = threadIdx.x; idx < (int64_t)n * n; idx += kThreads) {
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    V[idx] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+  }
+  for (int i = threadIdx.x; i < half; i += kThreads) {
+    top[i] = 2 * i;
+    bot[i] = 2 * i + 1;
+  }
+  if (threadIdx.x == 0) {
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(A[(int64_t)i * n + i].x));
+    off_norm = mx;  // scale of the spectrum (trace bound): rotations below 1e-15 of it are skipped
+  }
+  __syncthreads();
+  const double scale = off_norm;
+  for (int sweep = 0; sweep < jp.max_sweeps; ++sweep) {
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    for (int round = 0; round < n - 1; ++round) {
+      // rotation angles for the round's disjoint pairs (p < q)
+      for (int k = threadIdx.x; k < half; k += kThreads) {
+        int pi = top[k], qi = bot[k];
+        if (pi > qi) {
+          const int tmp = pi;
+          pi = qi;
+          qi = tmp;
+        }
+        const double app = A[(int64_t)pi * n + pi].x, aqq = A[(int64_t)qi * n + qi].x;
+        const double2 apq = A[(int64_t)pi * n + qi];
+        const double mag = hypot(apq.x, apq.y);
+        double c = 1.0;
+        double2 s = make_double2(0.0, 0.0);
+        if (mag > 1e-300 && mag > 1e-15 * scale) {
+          // Hermitian 2x2: [app apq; conj(apq) aqq]; phase e = apq/|apq|
+          const double tau = (aqq - app) / (2.0 * mag);
+          const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+          c = 1.0 / sqrt(1.0 + tt * tt);
+          const double sr = tt * c;
+          s = make_double2(sr * apq.x / mag, sr * apq.y / mag);  // s = sr * e
+          changed = 1;
+        }
+        cs[k] = c;
+        sn[k] = s;
+      }
+      __syncthreads();
+      // columns: A <- A R, V <- V R with R acting on columns (p, q):
+      //   new_p = c*col_p - conj(s)*col_q ; new_q = s*col_p + c*col_q
+      for (int64_t idx = threadIdx.x; idx < (int64_t)n * half; idx += kThreads) {
+        const int row = (int)(idx / half), k = (int)(idx % half);
+        int pi = top[k], qi = bot[k];
+        if (pi > qi) {
+          const int tmp = pi;
+          pi = qi;
+          qi = tmp;
+        }
+        const double c = cs[k];
+        const double2 s = sn[k];
+        if (s.x == 0.0 && s.y == 0.0) continue;
+        {
+          double2* ap = A + (int64_t)row * n + pi;
+          double2* aq = A + (int64_t)row * n + qi;
+          const double2 x = *ap, y = *aq;
+          *ap = make_double2(c * x.x - (s.x * y.x + s.y * y.y), c * x.y - (s.x * y.y - s.y * y.x));
+          *aq = make_double2(s.x * x.x - s.y * x.y + c * y.x, s.x * x.y + s.y * x.x + c * y.y);
+        }
+        {
+          double2* vp = V + (int64_t)row * n + pi;
+          double2* vq = V + (int64_t)row * n + qi;
+          const double2 x = *vp, y = *vq;
+          *vp = make_double2(c * x.x - (s.x * y.x + s.y * y.y), c * x.y - (s.x * y.y - s.y * y.x));
+          *vq = make_double2(s.x * x.x - s.y * x.y + c * y.x, s.x * x.y + s.y * x.x + c * y.y);
+        }
+      }
+      __syncthreads();
+      // rows: A <- R^H A:  new_p = c*row_p - s*row_q ; new_q = conj(s)*row_p + c*row_q
+      for (int64_t idx = threadIdx.x; idx < (int64_t)n * half; idx += kThreads) {
+        const int k = (int)(idx / n), col = (int)(idx % n);
+        int pi = top[k], qi = bot[k];
+        if (pi > qi) {
+          const int tmp = pi;
+          pi = qi;
+          qi = tmp;
+        }
+        const double c = cs[k];
+        const double2 s = sn[k];
+        if (s.x == 0.0 && s.y == 0.0) continue;
+        double2* ap = A + (int64_t)pi * n + col;
+        double2* aq = A + (int64_t)qi * n + col;
+        const double2 x = *ap, y = *aq;
+        *ap = make_double2(c * x.x - (s.x * y.x - s.y * y.y), c * x.y - (s.x * y.y + s.y * y.x));
+        *aq = make_double2(s.x * x.x + s.y * x.y + c * y.x, s.x * x.y - s.y * x.x + c * y.y);
+      }
+      __syncthreads();
+      // round-robin rotation of the index sets (players 1..n-1 rotate, top[0] fixed)
+      if (threadIdx.x == 0) {
+        const int last_top = top[half - 1], first_bot = bot[0];
+        for (int k = half - 1; k > 1; --k) top[k] = top[k - 1];
+        if (half > 1) top[1] = first_bot;
+        for (int k = 0; k < half - 1; ++k) bot[k] = bot[k + 1];
+        bot[half - 1] = last_top;
+      }
+      __syncthreads();
+    }
+    // converged when no rotation was applied in a whole sweep
+    __syncthreads();
+    if (!changed) break;
+    __syncthreads();
+  }
+}
+
+// w = D U_r L_r^-1 U_r^H D v with the reference's cut on sigma = sqrt(lambda)
+__global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DenseParams& p = jp.d;
+  const int n = p.Np;
+  double2* b = reinterpret_cast<double2*>(smem);  // [n]  D v
+  double2* c = b + n;                             // [n]  coefficients
+  __shared__ double lam_max;
+  const int mat = blockIdx.x;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  const double2* A = p.A + (int64_t)mat * n * n;
+  const double2* V = jp.V + (int64_t)mat * n * n;
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    double2 v = make_double2(0.0, 0.0);
+    if (i < p.N) {
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
+      const double d = sqrt(p.mweight[o]);
+      const double2 x = p.mvis[o];
+      v = make_double2(d * x.x, d * x.y);
+    }
+    b[i] = v;
+  }
+  if (threadIdx.x == 0) {
+    double mx = 0.0;
+    for (int i = 0; i < n; ++i) mx = fmax(mx, A[(int64_t)i * n + i].x);
+    lam_max = mx;
+  }
+  __syncthreads();
+  const double smax = sqrt(fmax(lam_max, 0.0));
+  // c_k = (u_k^H b) / lambda_k for kept k.  Eigenvector k = column k of V.  Padded
+  // coordinates (i >= N) never mix with the rest (their rows/cols are those of the identity).
+  for (int k = threadIdx.x; k < n; k += kThreads) {
+    const double lam = A[(int64_t)k * n + k].x;
+    const double sig = sqrt(fmax(lam, 0.0));
+    double2 acc = make_double2(0.0, 0.0);
+    if (sig > jp.rcond * smax && sig > jp.acond) {  // pinv_svd's rank rule, mapmaker.py:296
+      for (int i = 0; i < n; ++i) {
+        const double2 u = V[(int64_t)i * n + k], x = b[i];
+        acc.x += u.x * x.x + u.y * x.y;
+        acc.y += u.x * x.y - u.y * x.x;
+      }
+      acc.x /= lam;
+      acc.y /= lam;
+    }
+    c[k] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.N; i += kThreads) {
+    double2 acc = make_double2(0.0, 0.0);
+    for (int k = 0; k < n; ++k) {
+      const double2 u = V[(int64_t)i * n + k], x = c[k];
+      acc.x += u.x * x.x - u.y * x.y;
+      acc.y += u.x * x.y + u.y * x.x;
+    }
+    const int s = i >= p.npairs, pp = i - s * p.npairs;
+    const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+    p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * acc.x, d * acc.y);
+  }
+}
+
+__global__ void k_prior(double* Sl, int lmax, double amp, double tilt) {
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
+    const double dl = l == 0 ? 1.0 : (double)l;  // mapmaker.py:261: l[0] = 1
+    Sl[l] = amp * amp * pow(dl, -tilt);
+  }
+}
+
+// ---------------------------------------------------------------- host
+struct Layout {
+  int N, Np, T;
+  size_t per_mat;   // bytes per matrix (A + Linv/V + wbuf)
+  size_t header;    // Sl table
+};
+
+Layout layout_of(const dmm_plan* pl, bool ml) {
+  Layout L;
+  L.N = 2 * pl->npairs;
+  L.Np = (L.N + TB - 1) / TB * TB;
+  L.T = L.Np / TB;
+  const size_t a = (size_t)L.Np * L.Np * sizeof(double2);
+  const size_t aux = ml ? a : (size_t)L.T * TB * TB * sizeof(double2);
+  L.per_mat = a + aux + (size_t)L.N * sizeof(double2);
+  L.header = ((size_t)(pl->lmax + 1) * sizeof(double) + 255) / 256 * 256;
+  return L;
+}
+
+constexpr size_t kTargetWs = (size_t)6 << 30;  // ~6 GiB of matrices in flight per sub-batch
+
+int64_t workspace_bytes(const dmm_plan* pl, bool ml) {
+  if (!pl) return 0;
+  const Layout L = layout_of(pl, ml);
+  size_t nmat = kTargetWs / L.per_mat;
+  if (nmat < 1) nmat = 1;
+  if (nmat > (size_t)pl->ntile) nmat = pl->ntile > 0 ? pl->ntile : 1;
+  return (int64_t)(L.header + nmat * L.per_mat);
+}
+
+DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, const void* mvis, const double* mweight,
+                        unsigned char* ws, int nmat_cap) {
+  DenseParams p;
+  p.tiles = pl->tiles_d;
+  p.tile0 = 0;
+  p.nmat = 0;
+  p.N = L.N;
+  p.Np = L.Np;
+  p.T = L.T;
+  p.B = B;
+  p.b_c128 = pl->b_dtype == DMM_C128;
+  p.full_layout = pl->b_layout == DMM_B_FULL;
+  p.npairs = pl->npairs;
+  p.npol = pl->npol;
+  p.lmax = pl->lmax;
+  p.nfreq = pl->nfreq;
+  p.mvis = (const double2*)mvis;
+  p.mweight = mweight;
+  p.Sl = nullptr;
+  p.add_identity = 0;
+  unsigned char* q = ws + L.header;
+  p.A = (double2*)q;
+  q += (size_t)nmat_cap * L.Np * L.Np * sizeof(double2);
+  p.Linv = (double2*)q;  // (the ML path reuses this region as V: sized accordingly)
+  q += (size_t)nmat_cap * (L.per_mat - (size_t)L.Np * L.Np * sizeof(double2) - (size_t)L.N * sizeof(double2));
+  p.wbuf = (double2*)q;
+  p.J = 0;
+  return p;
+}
+
+}  // namespace
+
+// implemented in solve_dirty.hip: a = S o B^H w over tiles [tile0, tile0+nmat)
+int dmm_dirty_w_launch(dmm_plan* pl, const void* B, const double2* wbuf, const double* Sl, int64_t tile0, int nmat,
+                       void* alm);
+
+extern "C" {
+
+int64_t dmm_wiener_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, false); }
+int64_t dmm_ml_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, true); }
+
+int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, double prior_amp,
+                   double prior_tilt, void* workspace, void* alm) {
+  DMM_REQUIRE(pl && B && mvis && mweight && workspace && alm, "dmm_wiener_run: NULL argument");
+  DMM_REQUIRE(((uintptr_t)workspace & 255) == 0, "dmm_wiener_run: workspace must be 256-byte aligned");
+  if (pl->ntile == 0) return DMM_OK;
+  dmm_ctx* ctx = pl->ctx;
+  DMM_HIP(hipSetDevice(ctx->device));
+  const Layout L = layout_of(pl, false);
+  const int64_t wsb = dmm_wiener_workspace_bytes(pl);
+  const int cap = (int)((wsb - L.header) / L.per_mat);
+  unsigned char* ws = (unsigned char*)workspace;
+  double* Sl = (double*)ws;
+  hipLaunchKernelGGL(k_prior, dim3(4), dim3(256), 0, ctx->stream, Sl, pl->lmax, prior_amp, prior_tilt);
+  DenseParams p = make_params(pl, L, B, mvis, mweight, ws, cap);
+  p.Sl = Sl;
+  p.add_identity = 1;
+  const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);
+  DMM_HIP(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
+  const size_t diag_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
+  DMM_HIP(hipFuncSetAttribute((const void*)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+  for (int64_t t0 = 0; t0 < pl->ntile; t0 += cap) {
+    const int nmat = (int)std::min<int64_t>(cap, pl->ntile - t0);
+    p.tile0 = t0;
+    p.nmat = nmat;
+    hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(L.T * (L.T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+    for (int J = 0; J < L.T; ++J) {
+      p.J = J;
+      if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(L.T - J, nmat), dim3(kThreads), 0, ctx->stream, p);
+      hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, ctx->stream, p);
+      if (J < L.T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(L.T - J - 1, nmat), dim3(kThreads), 0, ctx->stream, p);
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, p);
+    DMM_HIP(hipGetLastError());
+    int rc = dmm_dirty_w_launch(pl, B, p.wbuf, Sl, t0, nmat, alm);
+    if (rc) return rc;
+  }
+  return DMM_OK;
+}
+
+int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, double acond, double rcond,
+               void* workspace, void* alm) {
+  DMM_REQUIRE(pl && B && mvis && mweight && workspace && alm, "dmm_ml_run: NULL argument");
+  DMM_REQUIRE(((uintptr_t)workspace & 255) == 0, "dmm_ml_run: workspace must be 256-byte aligned");
+  if (pl->ntile == 0) return DMM_OK;
+  dmm_ctx* ctx = pl->ctx;
+  DMM_HIP(hipSetDevice(ctx->device));
+  const Layout L = layout_of(pl, true);
+  const int64_t wsb = dmm_ml_workspace_bytes(pl);
+  const int cap = (int)((wsb - L.header) / L.per_mat);
+  unsigned char* ws = (unsigned char*)workspace;
+  JacobiParams jp;
+  jp.d = make_params(pl, L, B, mvis, mweight, ws, cap);
+  jp.V = jp.d.Linv;
+  jp.acond = acond;
+  jp.rcond = rcond;
+  jp.max_sweeps = 30;
+  const size_t jac_lds = (size_t)(L.Np / 2) * (2 * sizeof(int) + sizeof(double) + sizeof(double2));
+  const size_t fil_lds = (size_t)2 * L.Np * sizeof(double2);
+  DMM_HIP(hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jac_lds));
+  DMM_HIP(hipFuncSetAttribute((const void*)k_ml_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fil_lds));
+  for (int64_t t0 = 0; t0 < pl->ntile; t0 += cap) {
+    const int nmat = (int)std::min<int64_t>(cap, pl->ntile - t0);
+    jp.d.tile0 = t0;
+    jp.d.nmat = nmat;
+    hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(L.T * (L.T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
+    hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
+    hipLaunchKernelGGL(k_jacobi, dim3(nmat), dim3(kThreads), jac_lds, ctx->stream, jp);
+    hipLaunchKernelGGL(k_ml_filter, dim3(nmat), dim3(kThreads), fil_lds, ctx->stream, jp);
+    DMM_HIP(hipGetLastError());
+    int rc = dmm_dirty_w_launch(pl, B, jp.d.wbuf, nullptr, t0, nmat, alm);
+    if (rc) return rc;
+  }
+  return DMM_OK;
+}
+
+}  // extern "C"

@@ -33,6 +33,12 @@ struct SolveParams {
   int64_t nwork;
   int npairs, ntel, npol, lmax, nfreq, n_m;
   int full_layout;  // 1: tile [ntel, npol, lmax+1]; 0: [ntel, npol, lmax+1-m]
+  // "w mode" (Wiener / ML back-projection): w comes from wbuf[(t - tile0) * ntel + i]
+  // instead of Ni o v, the output is scaled by Sl[l] if given, tasks start at work_base
+  const double2* wbuf;
+  const double* Sl;
+  int64_t tile0;
+  int64_t work_base;
 };
 
 __device__ __forceinline__ int64_t find_tile(const int32_t* __restrict__ ws, int64_t ntile, int64_t w) {
@@ -76,7 +82,7 @@ __device__ __forceinline__ void load_cols(const BT* p, const int64_t (&off)[CPL]
 }
 
 // a[pol, l] = sum_i conj(B[i, pol, l]) * Ni[i] * v[i]
-template <typename BT, int CPL>
+template <typename BT, int CPL, bool WMODE>
 __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __restrict__ B,
                                                     const double2* __restrict__ mvis,
                                                     const double* __restrict__ mweight,
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntel = p.ntel, npairs = p.npairs;
 
-  for (int64_t work = blockIdx.x; work < p.nwork; work += gridDim.x) {
+  for (int64_t work0 = blockIdx.x; work0 < p.nwork; work0 += gridDim.x) {
+    const int64_t work = work0 + (WMODE ? p.work_base : 0);
     const int64_t t = find_tile(p.work_start, p.ntile, work);
     const dmm_tile tile = p.tiles[t];
     const int cb = (int)(work - p.work_start[t]);
@@ -99,11 +106,15 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
 
     __syncthreads();  // previous task's readers of w are done
     for (int i = threadIdx.x; i < ntel; i += kThreads) {
-      const int s = i >= npairs, pp = i - s * npairs;
-      const int64_t o = (((int64_t)m * 2 + s) * p.nfreq + f) * npairs + pp;
-      const double2 v = mvis[o];
-      const double ni = mweight[o];
-      w[i] = make_double2(ni * v.x, ni * v.y);
+      if (WMODE) {
+        w[i] = p.wbuf[(t - p.tile0) * ntel + i];
+      } else {
+        const int s = i >= npairs, pp = i - s * npairs;
+        const int64_t o = (((int64_t)m * 2 + s) * p.nfreq + f) * npairs + pp;
+        const double2 v = mvis[o];
+        const double ni = mweight[o];
+        w[i] = make_double2(ni * v.x, ni * v.y);
+      }
     }
     __syncthreads();
 
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
     for (int c = 0; c < CPL; ++c)
       if (ok[c]) {
         const int64_t o = (((int64_t)f * p.npol + opol[c]) * p.n_m + m) * (p.lmax + 1) + ol[c];
-        alm[o] = make_double2(are[c], aim[c]);
+        const double sc = (WMODE && p.Sl) ? p.Sl[ol[c]] : 1.0;
+        alm[o] = make_double2(sc * are[c], sc * aim[c]);
       }
   }
 }
@@ -250,7 +262,35 @@ SolveParams base_params(const dmm_plan* pl) {
   p.nfreq = pl->nfreq;
   p.n_m = pl->n_m;
   p.full_layout = pl->b_layout == DMM_B_FULL;
+  p.wbuf = nullptr;
+  p.Sl = nullptr;
+  p.tile0 = 0;
+  p.work_base = 0;
   return p;
+}
+
+template <bool WMODE>
+int launch_dirty(dmm_plan* pl, const SolveParams& p, const void* B, const double2* v, const double* mweight, double2* a) {
+  dmm_ctx* ctx = pl->ctx;
+  const size_t lds = (size_t)p.ntel * sizeof(double2);
+  int64_t grid = (int64_t)ctx->num_cu * 8;
+  if (grid > p.nwork) grid = p.nwork;
+  if (grid <= 0) return DMM_OK;
+  if (pl->b_dtype == DMM_C128) {
+    auto k = k_dirty<double2, 1, WMODE>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B, v, mweight, a);
+  } else if (pl->pair_ok) {
+    auto k = k_dirty<float2, 2, WMODE>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, v, mweight, a);
+  } else {
+    auto k = k_dirty<float2, 1, WMODE>;
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, v, mweight, a);
+  }
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
 }
 
 }  // namespace
@@ -300,6 +340,7 @@ int dmm_solve_plan_create(dmm_ctx* ctx, const dmm_tile* tiles, int64_t ntile, in
     delete pl;
     return rc;
   }
+  pl->work_start_h = ws;
   if (ntile > 0) {
     const size_t wb = (ntile + 1) * sizeof(int32_t);
     hipError_t e = hipMalloc((void**)&pl->tiles_d, ntile * sizeof(dmm_tile));
@@ -337,26 +378,7 @@ int dmm_dirty_run(dmm_plan* pl, const void* B, const void* mvis, const double* m
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
   SolveParams p = base_params(pl);
-  const size_t lds = (size_t)p.ntel * sizeof(double2);
-  int64_t grid = (int64_t)ctx->num_cu * 8;
-  if (grid > p.nwork) grid = p.nwork;
-  const double2* v = (const double2*)mvis;
-  double2* a = (double2*)alm;
-  if (pl->b_dtype == DMM_C128) {
-    auto k = k_dirty<double2, 1>;
-    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B, v, mweight, a);
-  } else if (pl->pair_ok) {
-    auto k = k_dirty<float2, 2>;
-    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, v, mweight, a);
-  } else {
-    auto k = k_dirty<float2, 1>;
-    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, v, mweight, a);
-  }
-  DMM_HIP(hipGetLastError());
-  return DMM_OK;
+  return launch_dirty<false>(pl, p, B, (const double2*)mvis, mweight, (double2*)alm);
 }
 
 int dmm_project_run(dmm_plan* pl, const void* B, const void* alm_in, void* vis_out) {
@@ -388,3 +410,16 @@ int dmm_project_run(dmm_plan* pl, const void* B, const void* alm_in, void* vis_o
 }
 
 }  // extern "C"
+
+// a = Sl o B^H w for tiles [tile0, tile0 + nmat) of the plan (Wiener / ML back-projection)
+int dmm_dirty_w_launch(dmm_plan* pl, const void* B, const double2* wbuf, const double* Sl, int64_t tile0, int nmat,
+                       void* alm) {
+  DMM_HIP(hipSetDevice(pl->ctx->device));
+  SolveParams p = base_params(pl);
+  p.wbuf = wbuf;
+  p.Sl = Sl;
+  p.tile0 = tile0;
+  p.work_base = pl->work_start_h[tile0];
+  p.nwork = (int64_t)pl->work_start_h[tile0 + nmat] - p.work_base;
+  return launch_dirty<true>(pl, p, B, nullptr, nullptr, (double2*)alm);
+}
