@@ -112,6 +112,8 @@ class TransitTelescope:
             for pidx, conj in groups[k]:
                 rev[pidx] = (s, conj)
         self.reverse_map_stack = rev
+        self.nbase = self.npairs
+        self.redundancy = np.array([len(groups[k]) for k in keys], dtype=np.float64)
         up = self.index_map_prod[self.index_map_stack["prod"]]
         self.uniquepairs = np.stack([up["input_a"].astype(int), up["input_b"].astype(int)], axis=1)
 

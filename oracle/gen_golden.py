@@ -275,14 +275,122 @@ def gen_mapmaker(mapmaker, out):
     np.savez_compressed(os.path.join(out, "mapmaker_solve_m.npz"), **cases)
 
 
+class _EnumArr(np.ndarray):
+    """ndarray with the two MPIArray methods the noise tasks use (single process)."""
+
+    def enumerate(self, axis):
+        return [(i, i) for i in range(self.shape[axis])]
+
+    @property
+    def local_shape(self):
+        return self.shape
+
+
+class _NoiseDS:
+    def __init__(self, arr):
+        self.arr = arr.view(_EnumArr)
+
+    def __getitem__(self, k):
+        return self.arr[k]
+
+    def __setitem__(self, k, v):
+        self.arr[k] = v
+
+    @property
+    def local_shape(self):
+        return self.arr.shape
+
+
+class FakeNoiseStream(FakeSiderealStream):
+    def __init__(self, vis, weight, freq_width, prod, ninput):
+        self.vis = _NoiseDS(vis)
+        self.weight = _NoiseDS(weight)
+        nra = vis.shape[-1]
+        self.ra = np.linspace(0.0, 360.0, nra, endpoint=False)
+        fm = np.zeros(vis.shape[0], dtype=[("centre", float), ("width", float)])
+        fm["centre"] = 400.0 + np.arange(vis.shape[0])
+        fm["width"] = freq_width
+        self.index_map = {"freq": fm, "input": np.arange(ninput), "prod": prod}
+        self.prodstack = prod
+        self.attrs = {}
+
+
+def _unpack_product_array(utv, mat, feeds, nfeed):
+    """NumPy stand-in for the compiled helper draco/util/_fast_tools.pyx:91-128 (index shuffle only)."""
+    for i, fi in enumerate(feeds):
+        for j, fj in enumerate(feeds):
+            a, b = (fi, fj) if fi <= fj else (fj, fi)
+            pi = (nfeed * (nfeed + 1) // 2) - ((nfeed - a) * (nfeed - a + 1) // 2) + (b - a)
+            mat[i, j] = utv[pi] if fi <= fj else np.conj(utv[pi])
+
+
+def gen_noise(out):
+    import importlib
+
+    from draco.util import random as rrandom
+
+    astro = importlib.import_module("caput.astro.constants")
+    astro.STELLAR_S = 1.0 / 1.002737909350795
+    from draco.synthesis import noise as rnoise
+
+    rnoise.STELLAR_S = astro.STELLAR_S
+    rnoise.containers = type("NS", (), {"SiderealStream": FakeSiderealStream})
+    ft = importlib.import_module("draco.util._fast_tools")
+    ft._unpack_product_array_fast = _unpack_product_array
+
+    cases = {}
+    rng = np.random.default_rng(77)
+    cases["cn"] = rrandom.complex_normal(size=(3, 4), scale=np.array([1.0, 2.0, 3.0, 4.0]), rng=np.random.default_rng(5))
+    cases["cn64"] = rrandom.complex_normal(size=(2, 5), dtype=np.complex64, loc=1 + 2j, rng=np.random.default_rng(6))
+    cases["scw"] = rrandom.standard_complex_wishart(4, 50, rng=np.random.default_rng(7))
+    X = crandn(rng, (5, 30))
+    C = X @ X.T.conj() / 30
+    cases["cw_C"] = C
+    cases["cw"] = rrandom.complex_wishart(C, 100, rng=np.random.default_rng(8))
+
+    # GaussianNoise on a full-triangle stream of 3 inputs (6 products)
+    ninput, nfreq, nra = 3, 2, 8
+    prod = np.array([(i, j) for i in range(ninput) for j in range(i, ninput)], dtype=[("input_a", int), ("input_b", int)])
+    vis = crandn(rng, (nfreq, len(prod), nra), np.complex64)
+    w = np.ones(vis.shape, np.float32)
+    t = rnoise.GaussianNoise.__new__(rnoise.GaussianNoise)
+    t.recv_temp, t.ndays, t.set_weights, t.add_noise, t.telescope = 50.0, 2.0, True, True, None
+    t.rng = np.random.default_rng(9)
+    d = FakeNoiseStream(vis.copy(), w.copy(), 0.390625, prod, ninput)
+    t.process(d)
+    cases["gn_vis_in"] = vis
+    cases["gn_vis"] = d.vis.arr.view(np.ndarray)
+    cases["gn_weight"] = d.weight.arr.view(np.ndarray)
+
+    # SampleNoise: expectation = positive-definite covariance per (freq, time)
+    exp = np.zeros((nfreq, len(prod), nra), np.complex128)
+    for f in range(nfreq):
+        for ti in range(nra):
+            Y = crandn(rng, (ninput, 12))
+            Cm = Y @ Y.T.conj() / 12 + np.eye(ninput)
+            exp[f, :, ti] = Cm[np.triu_indices(ninput)]
+    w2 = np.ones(exp.shape, np.float64)
+    s_ = rnoise.SampleNoise.__new__(rnoise.SampleNoise)
+    s_.sample_frac, s_.set_weights = 1e-4, True
+    s_.rng = np.random.default_rng(10)
+    d2 = FakeNoiseStream(exp.copy(), w2.copy(), 0.390625, prod, ninput)
+    s_.process(d2)
+    cases["sn_vis_in"] = exp
+    cases["sn_vis"] = d2.vis.arr.view(np.ndarray)
+    cases["sn_weight"] = d2.weight.arr.view(np.ndarray)
+    np.savez_compressed(os.path.join(out, "noise.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
 
     transform, mapmaker = load_reference()
     os.makedirs(GOLDEN, exist_ok=True)
-    gen_transform(transform, GOLDEN)
-    gen_mapmaker(mapmaker, GOLDEN)
+    if "--only-noise" not in sys.argv:
+        gen_transform(transform, GOLDEN)
+        gen_mapmaker(mapmaker, GOLDEN)
+    gen_noise(GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 
