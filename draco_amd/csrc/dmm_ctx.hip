@@ -82,6 +82,14 @@ int dmm_ctx_set_stream(dmm_ctx* c, void* s) {
   return DMM_OK;
 }
 
+int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
+  DMM_REQUIRE(c != nullptr && name != nullptr, "dmm_ctx_set_option: NULL argument");
+  if (!strcmp(name, "dirty_variant")) c->opt_dirty_variant = (int)value;
+  else if (!strcmp(name, "grid_mult")) c->opt_grid_mult = (int)value;
+  else return dmm_set_error(DMM_E_ARG, "dmm_ctx_set_option: unknown option '%s'", name);
+  return DMM_OK;
+}
+
 int dmm_ctx_sync(dmm_ctx* c) {
   DMM_REQUIRE(c != nullptr, "dmm_ctx_sync: ctx is NULL");
   DMM_HIP(hipStreamSynchronize(c->stream));

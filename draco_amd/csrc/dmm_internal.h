@@ -24,6 +24,8 @@ struct dmm_ctx {
   std::map<int, dmm_fft_tables> fft;       // forward tables by nra
   std::map<int, dmm_fft_tables> ifft;      // inverse tables by nra
   std::map<int64_t, void*> sht;            // SHT geometry caches keyed by (nside,lmax,mmax)
+  int opt_dirty_variant = 0;               // tuning knobs, see dmm_ctx_set_option
+  int opt_grid_mult = 0;
   void* scratch = nullptr;                 // grow-only workspace (ring coefficients, Gram matrices ...)
   size_t scratch_bytes = 0;
 };

@@ -24,7 +24,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kUnroll = 8;
 
 struct SolveParams {
   const dmm_tile* tiles;
@@ -50,39 +49,43 @@ __device__ __forceinline__ int64_t find_tile(const int32_t* __restrict__ ws, int
   return lo;
 }
 
-template <typename BT>
-__device__ __forceinline__ void load_b(const BT* p, double& re, double& im);
-template <>
-__device__ __forceinline__ void load_b<double2>(const double2* p, double& re, double& im) {
-  const double2 v = *p;
-  re = v.x;
-  im = v.y;
-}
-template <>
-__device__ __forceinline__ void load_b<float2>(const float2* p, double& re, double& im) {
-  const float2 v = *p;
-  re = (double)v.x;
-  im = (double)v.y;
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// NT: non-temporal (streaming) load -- B is read exactly once, keep it out of the caches' way
+template <typename BT, bool NT = false>
+__device__ __forceinline__ void load_b(const BT* p, double& re, double& im) {
+  if constexpr (sizeof(BT) == 16) {
+    const v2d v = NT ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p)) : *reinterpret_cast<const v2d*>(p);
+    re = v.x;
+    im = v.y;
+  } else {
+    const v2f v = NT ? __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p)) : *reinterpret_cast<const v2f*>(p);
+    re = (double)v.x;
+    im = (double)v.y;
+  }
 }
 
 // CPL adjacent columns per lane.  CPL == 2 exists only for packed complex64 tiles whose
 // rows are 16-byte aligned (plan->pair_ok): one 16-byte load brings both columns.
-template <typename BT, int CPL>
+template <typename BT, int CPL, bool NT>
 __device__ __forceinline__ void load_cols(const BT* p, const int64_t (&off)[CPL], int64_t roff, double (&re)[CPL],
                                           double (&im)[CPL]) {
   if constexpr (CPL == 2) {
-    const float4 v = *reinterpret_cast<const float4*>(p + off[0] + roff);
+    const v4f* q = reinterpret_cast<const v4f*>(p + off[0] + roff);
+    const v4f v = NT ? __builtin_nontemporal_load(q) : *q;
     re[0] = (double)v.x;
     im[0] = (double)v.y;
     re[1] = (double)v.z;
     im[1] = (double)v.w;
   } else {
-    load_b<BT>(p + off[0] + roff, re[0], im[0]);
+    load_b<BT, NT>(p + off[0] + roff, re[0], im[0]);
   }
 }
 
 // a[pol, l] = sum_i conj(B[i, pol, l]) * Ni[i] * v[i]
-template <typename BT, int CPL, bool WMODE>
+template <typename BT, int CPL, bool WMODE, bool NT = false, int kUnroll = 8>
 __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __restrict__ B,
                                                     const double2* __restrict__ mvis,
                                                     const double* __restrict__ mweight,
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
     for (; i + kUnroll <= ntel; i += kUnroll) {
       double br[kUnroll][CPL], bi[kUnroll][CPL];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) load_cols<BT, CPL>(B, off, (int64_t)(i + u) * row_stride, br[u], bi[u]);
+      for (int u = 0; u < kUnroll; ++u) load_cols<BT, CPL, NT>(B, off, (int64_t)(i + u) * row_stride, br[u], bi[u]);
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const double2 wv = w[i + u];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
     for (; i < ntel; ++i) {
       const double2 wv = w[i];
       double br[CPL], bi[CPL];
-      load_cols<BT, CPL>(B, off, (int64_t)i * row_stride, br, bi);
+      load_cols<BT, CPL, NT>(B, off, (int64_t)i * row_stride, br, bi);
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         are[c] = fma(br[c], wv.x, fma(bi[c], wv.y, are[c]));
@@ -273,17 +276,35 @@ template <bool WMODE>
 int launch_dirty(dmm_plan* pl, const SolveParams& p, const void* B, const double2* v, const double* mweight, double2* a) {
   dmm_ctx* ctx = pl->ctx;
   const size_t lds = (size_t)p.ntel * sizeof(double2);
-  int64_t grid = (int64_t)ctx->num_cu * 8;
+  // defaults from tools/tune_dirty.py on MI355X (profiles/r01_tune_dirty.txt): non-temporal loads, 8 row
+  // loads in flight per wave and ONE 4-wave block per CU (one wave per SIMD, 32 KB in flight per CU) --
+  // more resident waves only add contention at the memory side (6.7 vs 6.0 TB/s at 8 blocks per CU)
+  const int gm_default = 1;
+  int64_t grid = (int64_t)ctx->num_cu * (ctx->opt_grid_mult > 0 ? ctx->opt_grid_mult : gm_default);
   if (grid > p.nwork) grid = p.nwork;
   if (grid <= 0) return DMM_OK;
+#define DMM_LAUNCH_DIRTY(KERN, BTYPE)                                                                            \
+  do {                                                                                                           \
+    auto k = KERN;                                                                                               \
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const BTYPE*)B, v, mweight, a); \
+  } while (0)
   if (pl->b_dtype == DMM_C128) {
-    auto k = k_dirty<double2, 1, WMODE>;
-    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B, v, mweight, a);
+    switch (WMODE ? 0 : ctx->opt_dirty_variant) {  // tuning variants (tools/tune_dirty.py); 0 = shipped default
+      case 1: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, false, 8>), double2); break;
+      case 2: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 16>), double2); break;
+      case 3: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 4>), double2); break;
+      case 4: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 12>), double2); break;
+      default: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 8>), double2); break;
+    }
   } else if (pl->pair_ok) {
-    auto k = k_dirty<float2, 2, WMODE>;
-    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, v, mweight, a);
+    switch (WMODE ? 0 : ctx->opt_dirty_variant) {
+      case 1: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, false, 8>), float2); break;
+      case 2: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 8>), float2); break;
+      case 3: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 24>), float2); break;
+      case 4: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 16>), float2); break;
+      default: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 8>), float2); break;
+    }
   } else {
     auto k = k_dirty<float2, 1, WMODE>;
     DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

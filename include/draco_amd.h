@@ -65,6 +65,8 @@ int dmm_ctx_destroy(dmm_ctx* ctx);
 /* run on the caller's HIP stream (hipStream_t passed as void*; NULL = default stream) */
 int dmm_ctx_set_stream(dmm_ctx* ctx, void* hip_stream);
 int dmm_ctx_sync(dmm_ctx* ctx);
+/* tuning knobs (performance only, never results): "dirty_variant" (0 = default), "grid_mult" */
+int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
 int dmm_timer_start(dmm_ctx* ctx);
 int dmm_timer_stop(dmm_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
