@@ -383,127 +383,258 @@ __global__ __launch_bounds__(kThreads) void k_mirror(DenseParams p) {  // fill t
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_jacobi(JacobiParams jp) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const DenseParams& p = jp.d;
-  const int n = p.Np, half = n / 2;
-  int* top = reinterpret_cast<int*>(smem);        // [half]
-  int* bot = top + half;                          // [half]
-  double* cs = reinterpret_cast<double*>(bot + half);  // [half] cos
-  double2* sn = reinterpret_cast<double2*>(cs + half); // [half] complex sin
-  __shared__ double off_norm;
-  __shared__ int changed;
-  const int mat = blockIdx.x;
-  double2* A = p.A + (int64_t)mat * n * n;
-  double2* V = jp.V + (int64_t)mat * n * n;
-  for (int64_t idx = threadIdx.x; idx < (int64_t)n * n; idx += kThreads) {
+// ---- blocked two-sided Jacobi.  Blocks of 32 rows/columns; a "pair" (P, Q) is a 64x64
+// Hermitian sub-problem solved to convergence in LDS (k_bj_sub); its unitary W is applied
+// to the block columns of A and V and to the block rows of A with the f64-MFMA tile product
+// (k_bj_apply).  Round-robin over block pairs: nb-1 rounds of nb/2 disjoint pairs per sweep.
+constexpr int JB = 32;  // block size
+
+__device__ __forceinline__ void rr_pair(int round, int k, int players, int& a, int& b) {
+  // round-robin tournament: player `players-1` is fixed, the others rotate
+  const int m1 = players - 1;
+  if (k == 0) {
+    a = m1;
+    b = round % m1;
+  } else {
+    a = (round + k) % m1;
+    b = (round - k + m1) % m1;
+  }
+  if (a > b) {
+    const int t = a;
+    a = b;
+    b = t;
+  }
+}
+
+struct BjParams {
+  DenseParams d;
+  double2* V;       // [nmat][Np][Np]
+  double2* Wh;      // [nmat][npairs_blk][64][64]  W^H of each pair's sub-problem (row-major)
+  int* flag;        // [nmat][npairs_blk] 1 = rotation to apply
+  double* scale;    // [nmat] spectrum scale (max diagonal)
+  int round;        // current outer round
+  int nb;           // number of 32-blocks
+  int target;       // k_bj_apply: 0 = A columns, 1 = V columns, 2 = A rows
+  int inner_sweeps; // cap on the in-LDS Jacobi sweeps per visit (W stays exactly unitary either way)
+};
+
+__global__ __launch_bounds__(kThreads) void k_bj_init(BjParams bp) {  // V = I, scale = max diag
+  const DenseParams& p = bp.d;
+  const int mat = blockIdx.y, n = p.Np;
+  double2* V = bp.V + (int64_t)mat * n * n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n;
+       idx += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx / n), j = (int)(idx % n);
     V[idx] = make_double2(i == j ? 1.0 : 0.0, 0.0);
   }
-  for (int i = threadIdx.x; i < half; i += kThreads) {
-    top[i] = 2 * i;
-    bot[i] = 2 * i + 1;
-  }
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0) {
+    __shared__ double red[kThreads];
+    const double2* A = p.A + (int64_t)mat * n * n;
     double mx = 0.0;
-    for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(A[(int64_t)i * n + i].x));
-    off_norm = mx;  // scale of the spectrum (trace bound): rotations below 1e-15 of it are skipped
-  }
-  __syncthreads();
-  const double scale = off_norm;
-  for (int sweep = 0; sweep < jp.max_sweeps; ++sweep) {
-    if (threadIdx.x == 0) changed = 0;
+    for (int i = threadIdx.x; i < n; i += kThreads) mx = fmax(mx, fabs(A[(int64_t)i * n + i].x));
+    red[threadIdx.x] = mx;
     __syncthreads();
-    for (int round = 0; round < n - 1; ++round) {
-      // rotation angles for the round's disjoint pairs (p < q)
-      for (int k = threadIdx.x; k < half; k += kThreads) {
-        int pi = top[k], qi = bot[k];
-        if (pi > qi) {
-          const int tmp = pi;
-          pi = qi;
-          qi = tmp;
-        }
-        const double app = A[(int64_t)pi * n + pi].x, aqq = A[(int64_t)qi * n + qi].x;
-        const double2 apq = A[(int64_t)pi * n + qi];
-        const double mag = hypot(apq.x, apq.y);
+    for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
+      if (threadIdx.x < s2) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s2]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) bp.scale[mat] = red[0];
+  }
+}
+
+// Solve one 64x64 Hermitian sub-problem per block entirely in LDS (cyclic Jacobi, parallel
+// ordering: 63 rounds of 32 disjoint rotations per sweep), emit W^H.
+__global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
+  extern __shared__ __align__(16) unsigned char smem_bj[];
+  constexpr int M = 2 * JB, MP = M + 1;
+  double2(*s)[MP] = reinterpret_cast<double2(*)[MP]>(smem_bj);
+  double2(*w)[MP] = s + M;
+  __shared__ double rc[M / 2];
+  __shared__ double2 rs[M / 2];
+  __shared__ int pa[M / 2], pb[M / 2];
+  __shared__ int any_rot, need;
+  const DenseParams& p = bp.d;
+  const int pr = blockIdx.x, mat = blockIdx.y, n = p.Np;
+  int P, Q;
+  rr_pair(bp.round, pr, bp.nb, P, Q);
+  const int P0 = P * JB, Q0 = Q * JB;
+  const double2* A = p.A + (int64_t)mat * n * n;
+  const double scale = bp.scale[mat];
+  // off-diagonals below 1e-14 of the spectrum's scale are converged (the MFMA block updates
+  // re-inject O(eps * sqrt(n)) noise, a tighter test would never settle); the eigenvalue cut of the
+  // ML filter sits at 1e-6 of the scale, eight digits above this
+  const double tol2 = 1e-28 * scale * scale;
+  if (threadIdx.x == 0) need = 0;
+  __syncthreads();
+  int my_need = 0;
+  for (int idx = threadIdx.x; idx < M * M; idx += kThreads) {
+    const int i = idx / M, j = idx % M;
+    const int gi = i < JB ? P0 + i : Q0 + i - JB, gj = j < JB ? P0 + j : Q0 + j - JB;
+    const double2 v = A[(int64_t)gi * n + gj];
+    s[i][j] = v;
+    w[i][j] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+    if (i != j && v.x * v.x + v.y * v.y > tol2) my_need = 1;
+  }
+  if (my_need) need = 1;
+  __syncthreads();
+  int* flag = bp.flag + (int64_t)mat * (bp.nb / 2) + pr;
+  if (!need) {  // already diagonal to working precision: nothing to rotate
+    if (threadIdx.x == 0) *flag = 0;
+    return;
+  }
+  for (int sweep = 0; sweep < bp.inner_sweeps; ++sweep) {
+    if (threadIdx.x == 0) any_rot = 0;
+    __syncthreads();
+    for (int r = 0; r < M - 1; ++r) {
+      if (threadIdx.x < M / 2) {
+        int a, b;
+        rr_pair(r, threadIdx.x, M, a, b);
+        const double app = s[a][a].x, aqq = s[b][b].x;
+        const double2 apq = s[a][b];
+        const double mag2 = apq.x * apq.x + apq.y * apq.y;
         double c = 1.0;
-        double2 s = make_double2(0.0, 0.0);
-        if (mag > 1e-300 && mag > 1e-15 * scale) {
-          // Hermitian 2x2: [app apq; conj(apq) aqq]; phase e = apq/|apq|
+        double2 sn = make_double2(0.0, 0.0);
+        if (mag2 > tol2 * (1.0 / 64.0)) {
+          const double mag = sqrt(mag2);
           const double tau = (aqq - app) / (2.0 * mag);
           const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
           c = 1.0 / sqrt(1.0 + tt * tt);
           const double sr = tt * c;
-          s = make_double2(sr * apq.x / mag, sr * apq.y / mag);  // s = sr * e
-          changed = 1;
+          sn = make_double2(sr * apq.x / mag, sr * apq.y / mag);
+          any_rot = 1;
         }
-        cs[k] = c;
-        sn[k] = s;
+        rc[threadIdx.x] = c;
+        rs[threadIdx.x] = sn;
+        pa[threadIdx.x] = a;
+        pb[threadIdx.x] = b;
       }
       __syncthreads();
-      // columns: A <- A R, V <- V R with R acting on columns (p, q):
-      //   new_p = c*col_p - conj(s)*col_q ; new_q = s*col_p + c*col_q
-      for (int64_t idx = threadIdx.x; idx < (int64_t)n * half; idx += kThreads) {
-        const int row = (int)(idx / half), k = (int)(idx % half);
-        int pi = top[k], qi = bot[k];
-        if (pi > qi) {
-          const int tmp = pi;
-          pi = qi;
-          qi = tmp;
-        }
-        const double c = cs[k];
-        const double2 s = sn[k];
-        if (s.x == 0.0 && s.y == 0.0) continue;
+      // columns of S and W:  new_p = c col_p - conj(s) col_q ; new_q = s col_p + c col_q
+      for (int idx = threadIdx.x; idx < M * (M / 2); idx += kThreads) {
+        const int row = idx / (M / 2), k = idx % (M / 2);
+        const double2 sn = rs[k];
+        if (sn.x == 0.0 && sn.y == 0.0) continue;
+        const double c = rc[k];
+        const int a = pa[k], b = pb[k];
         {
-          double2* ap = A + (int64_t)row * n + pi;
-          double2* aq = A + (int64_t)row * n + qi;
-          const double2 x = *ap, y = *aq;
-          *ap = make_double2(c * x.x - (s.x * y.x + s.y * y.y), c * x.y - (s.x * y.y - s.y * y.x));
-          *aq = make_double2(s.x * x.x - s.y * x.y + c * y.x, s.x * x.y + s.y * x.x + c * y.y);
+          const double2 x = s[row][a], y = s[row][b];
+          s[row][a] = make_double2(c * x.x - (sn.x * y.x + sn.y * y.y), c * x.y - (sn.x * y.y - sn.y * y.x));
+          s[row][b] = make_double2(sn.x * x.x - sn.y * x.y + c * y.x, sn.x * x.y + sn.y * x.x + c * y.y);
         }
         {
-          double2* vp = V + (int64_t)row * n + pi;
-          double2* vq = V + (int64_t)row * n + qi;
-          const double2 x = *vp, y = *vq;
-          *vp = make_double2(c * x.x - (s.x * y.x + s.y * y.y), c * x.y - (s.x * y.y - s.y * y.x));
-          *vq = make_double2(s.x * x.x - s.y * x.y + c * y.x, s.x * x.y + s.y * x.x + c * y.y);
+          const double2 x = w[row][a], y = w[row][b];
+          w[row][a] = make_double2(c * x.x - (sn.x * y.x + sn.y * y.y), c * x.y - (sn.x * y.y - sn.y * y.x));
+          w[row][b] = make_double2(sn.x * x.x - sn.y * x.y + c * y.x, sn.x * x.y + sn.y * x.x + c * y.y);
         }
       }
       __syncthreads();
-      // rows: A <- R^H A:  new_p = c*row_p - s*row_q ; new_q = conj(s)*row_p + c*row_q
-      for (int64_t idx = threadIdx.x; idx < (int64_t)n * half; idx += kThreads) {
-        const int k = (int)(idx / n), col = (int)(idx % n);
-        int pi = top[k], qi = bot[k];
-        if (pi > qi) {
-          const int tmp = pi;
-          pi = qi;
-          qi = tmp;
-        }
-        const double c = cs[k];
-        const double2 s = sn[k];
-        if (s.x == 0.0 && s.y == 0.0) continue;
-        double2* ap = A + (int64_t)pi * n + col;
-        double2* aq = A + (int64_t)qi * n + col;
-        const double2 x = *ap, y = *aq;
-        *ap = make_double2(c * x.x - (s.x * y.x - s.y * y.y), c * x.y - (s.x * y.y + s.y * y.x));
-        *aq = make_double2(s.x * x.x + s.y * x.y + c * y.x, s.x * x.y - s.y * x.x + c * y.y);
-      }
-      __syncthreads();
-      // round-robin rotation of the index sets (players 1..n-1 rotate, top[0] fixed)
-      if (threadIdx.x == 0) {
-        const int last_top = top[half - 1], first_bot = bot[0];
-        for (int k = half - 1; k > 1; --k) top[k] = top[k - 1];
-        if (half > 1) top[1] = first_bot;
-        for (int k = 0; k < half - 1; ++k) bot[k] = bot[k + 1];
-        bot[half - 1] = last_top;
+      // rows of S:  new_p = c row_p - s row_q ; new_q = conj(s) row_p + c row_q
+      for (int idx = threadIdx.x; idx < (M / 2) * M; idx += kThreads) {
+        const int k = idx / M, col = idx % M;
+        const double2 sn = rs[k];
+        if (sn.x == 0.0 && sn.y == 0.0) continue;
+        const double c = rc[k];
+        const int a = pa[k], b = pb[k];
+        const double2 x = s[a][col], y = s[b][col];
+        s[a][col] = make_double2(c * x.x - (sn.x * y.x - sn.y * y.y), c * x.y - (sn.x * y.y + sn.y * y.x));
+        s[b][col] = make_double2(sn.x * x.x + sn.y * x.y + c * y.x, sn.x * x.y - sn.y * x.x + c * y.y);
       }
       __syncthreads();
     }
-    // converged when no rotation was applied in a whole sweep
-    __syncthreads();
-    if (!changed) break;
+    if (!any_rot) break;
     __syncthreads();
   }
+  double2* Wh = bp.Wh + ((int64_t)mat * (bp.nb / 2) + pr) * M * M;
+  for (int idx = threadIdx.x; idx < M * M; idx += kThreads) {
+    const int j = idx / M, k = idx % M;
+    const double2 v = w[k][j];
+    Wh[idx] = make_double2(v.x, -v.y);  // W^H[j][k] = conj(W[k][j])
+  }
+  if (threadIdx.x == 0) *flag = 1;
+}
+
+// Apply the pair's rotation with the MFMA tile product (K = 64):
+//   target 0/1: T[I-tile rows, pair columns] <- T[:, pair columns] W      (T = A or V)
+//   target 2  : A[pair rows, J-tile columns] <- W^H A[pair rows, :]
+__global__ __launch_bounds__(kThreads) void k_bj_apply(BjParams bp) {
+  __shared__ __align__(16) double xs[TB * LP];
+  __shared__ __align__(16) double ys[TB * LP];
+  const DenseParams& p = bp.d;
+  const int tileidx = blockIdx.x, pr = blockIdx.y, mat = blockIdx.z, n = p.Np;
+  if (!bp.flag[(int64_t)mat * (bp.nb / 2) + pr]) return;
+  int P, Q;
+  rr_pair(bp.round, pr, bp.nb, P, Q);
+  const int P0 = P * JB, Q0 = Q * JB;
+  double2* T = (bp.target == 1 ? bp.V : p.A) + (int64_t)mat * n * n;
+  const double2* Wh = bp.Wh + ((int64_t)mat * (bp.nb / 2) + pr) * TB * TB;
+  const int T0 = tileidx * TB;  // first row (targets 0/1) or first column (target 2) of this tile
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  v4d cre[2][2], cim[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
+  for (int k0 = 0; k0 < TB; k0 += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c0 + c;                       // contraction index 0..63 over the pair's rows/cols
+      const int gk = k < JB ? P0 + k : Q0 + k - JB;    // its global row/column
+      double2 xv, yv;
+      if (bp.target != 2) {
+        xv = T[(int64_t)(T0 + r) * n + gk];            // X[i][k] = T[i][col(k)]
+        yv = Wh[r * TB + k];                           // Y[j][k] = W^H[j][k]
+      } else {
+        xv = Wh[r * TB + k];                           // X[r][k] = W^H[r][k]
+        const double2 t = T[(int64_t)gk * n + T0 + r];  // Y[j][k] = conj(A[row(k)][j])
+        yv = make_double2(t.x, -t.y);
+      }
+      *reinterpret_cast<double2*>(xs + r * LP + 2 * (c0 + c)) = xv;
+      *reinterpret_cast<double2*>(ys + r * LP + 2 * (c0 + c)) = yv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2 * KC; kk += 4) {
+      double a[2], b[2], b2[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = xs[(32 * wr + 16 * t + lr) * LP + kk + lk];
+        b[t] = ys[(32 * wc + 16 * t + lr) * LP + kk + lk];
+        const double o = ys[(32 * wc + 16 * t + lr) * LP + kk + (lk ^ 1)];
+        b2[t] = (lk & 1) ? o : -o;
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], cre[ti][tj], 0, 0, 0);
+          cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b2[tj], cim[ti][tj], 0, 0, 0);
+        }
+    }
+  }
+  __syncthreads();  // every input of this tile has been consumed: in-place store is safe
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = 32 * wr + 16 * ti + lk + 4 * reg;  // X-side index
+        const int j = 32 * wc + 16 * tj + lr;            // Y-side index
+        const double2 val = make_double2(cre[ti][tj][reg], cim[ti][tj][reg]);
+        if (bp.target != 2) {
+          const int gj = j < JB ? P0 + j : Q0 + j - JB;
+          T[(int64_t)(T0 + i) * n + gj] = val;
+        } else {
+          const int gi = i < JB ? P0 + i : Q0 + i - JB;
+          T[(int64_t)gi * n + T0 + j] = val;
+        }
+      }
 }
 
 // w = D U_r L_r^-1 U_r^H D v with the reference's cut on sigma = sqrt(lambda)
@@ -578,6 +709,7 @@ __global__ void k_prior(double* Sl, int lmax, double amp, double tilt) {
 struct Layout {
   int N, Np, T;
   size_t per_mat;   // bytes per matrix (A + Linv/V + wbuf)
+  size_t per_mat_extra;  // ML only: pair rotations W^H, flags, scale (kept behind the wbuf region)
   size_t header;    // Sl table
 };
 
@@ -589,6 +721,7 @@ Layout layout_of(const dmm_plan* pl, bool ml) {
   const size_t a = (size_t)L.Np * L.Np * sizeof(double2);
   const size_t aux = ml ? a : (size_t)L.T * TB * TB * sizeof(double2);
   L.per_mat = a + aux + (size_t)L.N * sizeof(double2);
+  L.per_mat_extra = ml ? (size_t)(L.Np / 64) * TB * TB * sizeof(double2) + (size_t)(L.Np / 64) * sizeof(int) + 16 : 0;
   L.header = ((size_t)(pl->lmax + 1) * sizeof(double) + 255) / 256 * 256;
   return L;
 }
@@ -598,10 +731,10 @@ constexpr size_t kTargetWs = (size_t)6 << 30;  // ~6 GiB of matrices in flight p
 int64_t workspace_bytes(const dmm_plan* pl, bool ml) {
   if (!pl) return 0;
   const Layout L = layout_of(pl, ml);
-  size_t nmat = kTargetWs / L.per_mat;
+  size_t nmat = kTargetWs / (L.per_mat + L.per_mat_extra);
   if (nmat < 1) nmat = 1;
   if (nmat > (size_t)pl->ntile) nmat = pl->ntile > 0 ? pl->ntile : 1;
-  return (int64_t)(L.header + nmat * L.per_mat);
+  return (int64_t)(L.header + nmat * (L.per_mat + L.per_mat_extra) + 1024);
 }
 
 DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, const void* mvis, const double* mweight,
@@ -654,7 +787,7 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   DMM_HIP(hipSetDevice(ctx->device));
   const Layout L = layout_of(pl, false);
   const int64_t wsb = dmm_wiener_workspace_bytes(pl);
-  const int cap = (int)((wsb - L.header) / L.per_mat);
+  const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
   double* Sl = (double*)ws;
   hipLaunchKernelGGL(k_prior, dim3(4), dim3(256), 0, ctx->stream, Sl, pl->lmax, prior_amp, prior_tilt);
@@ -693,25 +826,48 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   DMM_HIP(hipSetDevice(ctx->device));
   const Layout L = layout_of(pl, true);
   const int64_t wsb = dmm_ml_workspace_bytes(pl);
-  const int cap = (int)((wsb - L.header) / L.per_mat);
+  const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
   JacobiParams jp;
   jp.d = make_params(pl, L, B, mvis, mweight, ws, cap);
   jp.V = jp.d.Linv;
   jp.acond = acond;
   jp.rcond = rcond;
-  jp.max_sweeps = 30;
-  const size_t jac_lds = (size_t)(L.Np / 2) * (2 * sizeof(int) + sizeof(double) + sizeof(double2));
+  jp.max_sweeps = 14;
+  BjParams bp;
+  bp.inner_sweeps = 2;
+  bp.V = jp.V;
+  bp.nb = L.Np / JB;
+  const int npr = bp.nb / 2;
+  // pair buffers live behind the per-matrix regions (sized in layout_of)
+  unsigned char* extra = (unsigned char*)(jp.d.wbuf + (size_t)cap * L.N);
+  extra = (unsigned char*)(((uintptr_t)extra + 255) & ~(uintptr_t)255);
+  bp.Wh = (double2*)extra;
+  bp.flag = (int*)(bp.Wh + (size_t)cap * npr * TB * TB);
+  bp.scale = (double*)(bp.flag + (((size_t)cap * npr + 1) & ~(size_t)1));
+  const size_t sub_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
   const size_t fil_lds = (size_t)2 * L.Np * sizeof(double2);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_jacobi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jac_lds));
+  DMM_HIP(hipFuncSetAttribute((const void*)k_bj_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
   DMM_HIP(hipFuncSetAttribute((const void*)k_ml_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fil_lds));
   for (int64_t t0 = 0; t0 < pl->ntile; t0 += cap) {
     const int nmat = (int)std::min<int64_t>(cap, pl->ntile - t0);
     jp.d.tile0 = t0;
     jp.d.nmat = nmat;
+    bp.d = jp.d;
     hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(L.T * (L.T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
     hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
-    hipLaunchKernelGGL(k_jacobi, dim3(nmat), dim3(kThreads), jac_lds, ctx->stream, jp);
+    hipLaunchKernelGGL(k_bj_init, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, bp);
+    for (int sweep = 0; sweep < jp.max_sweeps; ++sweep)
+      for (int round = 0; round < bp.nb - 1; ++round) {
+        bp.round = round;
+        hipLaunchKernelGGL(k_bj_sub, dim3(npr, nmat), dim3(kThreads), sub_lds, ctx->stream, bp);
+        bp.target = 0;
+        hipLaunchKernelGGL(k_bj_apply, dim3(L.T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
+        bp.target = 2;
+        hipLaunchKernelGGL(k_bj_apply, dim3(L.T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
+        bp.target = 1;
+        hipLaunchKernelGGL(k_bj_apply, dim3(L.T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
+      }
     hipLaunchKernelGGL(k_ml_filter, dim3(nmat), dim3(kThreads), fil_lds, ctx->stream, jp);
     DMM_HIP(hipGetLastError());
     int rc = dmm_dirty_w_launch(pl, B, jp.d.wbuf, nullptr, t0, nmat, alm);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--dense-freqs", type=int, default=1, help="frequencies used for the Wiener sample")
     ap.add_argument("--ml-tiles", type=int, default=16)
+    ap.add_argument("--ml-batched", action="store_true")
     args = ap.parse_args()
     import torch
 
@@ -97,6 +98,16 @@ def main():
     ntel = 2 * npairs
     flops = sum(8.0 * ntel * ntel * 4 * (lmax + 1 - m) / 2 for m in range(lmax + 1)) * nf_d + ntile * (8.0 / 3.0) * ntel**3
     out["wiener"] = {"ms": t, "tiles": ntile, "ms_per_tile": t / ntile, "TFLOPs": flops / t / 1e9, "first_call_ms": (t1 - t0) * 1e3}
+
+    # ML batched over all m of one frequency
+    if args.ml_batched:
+        mv1 = mv[:, :, :1].contiguous()
+        mw1 = mw[:, :, :1].contiguous()
+        t1 = time.perf_counter()
+        eng.solve("ml", mv1, mw1, [0], lmax, acond=1e-4, rcond=1e-3)
+        ctx.sync()
+        t = (time.perf_counter() - t1) * 1e3
+        out["ml_batched"] = {"ms": t, "tiles": lmax + 1, "ms_per_tile": t / (lmax + 1)}
 
     # ML on a handful of tiles (Jacobi is O(n^3 * sweeps) from global memory)
     from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
