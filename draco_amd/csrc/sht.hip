@@ -52,8 +52,11 @@ struct LegParams {
 
 // LDS image of one (f, m): coefficient rows + npol a_lm columns
 //   coef[l] = {ra, rb, c, d}:  lam_l = x*lam_{l-1}*ra - lam_{l-2}*rb;  c, d: spin-2 factors
-struct Coef {
-  double ra, rb, c, d;
+struct Coef {  // wave-uniform per-l factors of one m
+  double ra, rb;   // lam_l = x*lam_{l-1}*ra - lam_{l-2}*rb
+  double c1, c2;   // F1 = -(c1*inv_s2 + c2)*lam + cd*(x*inv_s2)*lam_{l-1}
+  double cd, c3;   // F2 = c4*inv_s2*lam_{l-1} - c3*(x*inv_s2)*lam
+  double c4, pad;
 };
 
 __device__ __forceinline__ void fill_coef(Coef* coef, int m, int lmax) {
@@ -65,8 +68,14 @@ __device__ __forceinline__ void fill_coef(Coef* coef, int m, int lmax) {
     const double Ap = (l > m) ? sqrt((l1 * l1 - dm * dm) / (4.0 * l1 * l1 - 1.0)) : 0.0;
     q.ra = (l > m) ? 1.0 / A : 0.0;
     q.rb = (l > m) ? Ap / A : 0.0;
-    q.c = (l >= 2) ? 2.0 / sqrt((dl - 1.0) * dl * (dl + 1.0) * (dl + 2.0)) : 0.0;
-    q.d = (l >= 1) ? sqrt((2.0 * dl + 1.0) / (2.0 * dl - 1.0) * (dl * dl - dm * dm)) : 0.0;
+    const double c = (l >= 2) ? 2.0 / sqrt((dl - 1.0) * dl * (dl + 1.0) * (dl + 2.0)) : 0.0;
+    const double d = (l >= 1) ? sqrt((2.0 * dl + 1.0) / (2.0 * dl - 1.0) * (dl * dl - dm * dm)) : 0.0;
+    q.c1 = c * (dl - dm * dm);
+    q.c2 = c * 0.5 * dl * (dl - 1.0);
+    q.cd = c * d;
+    q.c3 = c * dm * (dl - 1.0);
+    q.c4 = c * dm * d;
+    q.pad = 0.0;
     coef[l - m] = q;
   }
 }
@@ -102,7 +111,6 @@ __global__ __launch_bounds__(kThreads) void k_leg_synth(LegParams p) {
 
   const int nring = p.g.nring, npair = (nring + 1) / 2;  // north rings incl. equator
   const double lfac_m = p.g.lfac[m];
-  const double dm = (double)m;
   for (int r = threadIdx.x; r < npair; r += kThreads) {
     const double x = p.g.z[r], sth = p.g.sth[r];
     const int rs = nring - 1 - r;  // southern mirror (== r on the equator)
@@ -110,14 +118,15 @@ __global__ __launch_bounds__(kThreads) void k_leg_synth(LegParams p) {
     double2 Ts = {0, 0}, Ta = {0, 0}, Vs = {0, 0}, Va = {0, 0};
     double2 Qs = {0, 0}, Qa = {0, 0}, Us = {0, 0}, Ua = {0, 0};
     if (!ring_skips_m(m, lmax, sth)) {
-      const double inv_s2 = 1.0 / (sth * sth);
+      const double inv_s2 = 1.0 / (sth * sth), xs2 = x * inv_s2;
       double lam, lam_prev = 0.0;
       int nsc;
       lam_start(lfac_m, m, sth, lam, nsc);
-      for (int k = 0; k < nl; ++k) {
-        const int l = m + k;
-        const Coef q = coef[k];
-        if (k > 0) {
+      // one l-step; the accumulator pairing is static per parity (no selects in the loop):
+      // lambda-parity terms go to (T, V, Q1, U1), opposite-parity (F2) terms to (Q2, U2)
+      auto step = [&](const Coef& q, const double2& aT, const double2& aE, const double2& aB, const double2& aV,
+                      bool first, double2& T, double2& V, double2& Q1, double2& Q2, double2& U1, double2& U2) {
+        if (!first) {
           const double nxt = x * lam * q.ra - lam_prev * q.rb;
           lam_prev = lam;
           lam = nxt;
@@ -128,38 +137,53 @@ __global__ __launch_bounds__(kThreads) void k_leg_synth(LegParams p) {
           }
         }
         if (nsc == 0) {
-          const bool even = !(k & 1);
-          const double2 aT = a[k];
-          double2& T = even ? Ts : Ta;
           T.x = fma(aT.x, lam, T.x);
           T.y = fma(aT.y, lam, T.y);
           if (NPOL == 4) {
-            const double2 aV = a[3 * nl + k];
-            double2& V = even ? Vs : Va;
             V.x = fma(aV.x, lam, V.x);
             V.y = fma(aV.y, lam, V.y);
-            if (l >= 2) {
-              const double dl = (double)l;
-              const double t = q.d * lam_prev;  // d_lm * lambda_{l-1,m}
-              const double F1 = q.c * (-((dl - dm * dm) * inv_s2 + 0.5 * dl * (dl - 1.0)) * lam + x * inv_s2 * t);
-              const double F2 = q.c * dm * inv_s2 * (-(dl - 1.0) * x * lam + t);
-              const double2 E = a[nl + k], B = a[2 * nl + k];
-              // Q: -(E F1 + i B F2), U: -(B F1 - i E F2); F1 has the parity of lambda, F2 the opposite
-              double2& Q1 = even ? Qs : Qa;
-              double2& Q2 = even ? Qa : Qs;
-              double2& U1 = even ? Us : Ua;
-              double2& U2 = even ? Ua : Us;
-              Q1.x = fma(-E.x, F1, Q1.x);
-              Q1.y = fma(-E.y, F1, Q1.y);
-              Q2.x = fma(B.y, F2, Q2.x);   // -i*B*F2 = (B.y, -B.x) * F2
-              Q2.y = fma(-B.x, F2, Q2.y);
-              U1.x = fma(-B.x, F1, U1.x);
-              U1.y = fma(-B.y, F1, U1.y);
-              U2.x = fma(-E.y, F2, U2.x);  // +i*E*F2 = (-E.y, E.x) * F2
-              U2.y = fma(E.x, F2, U2.y);
-            }
+            // l < 2: c1..c4 are zero, F1 = F2 = 0
+            const double F1 = fma(q.cd * xs2, lam_prev, -fma(q.c1, inv_s2, q.c2) * lam);
+            const double F2 = fma(q.c4 * inv_s2, lam_prev, -q.c3 * xs2 * lam);
+            Q1.x = fma(-aE.x, F1, Q1.x);   // Q: -(E F1 + i B F2)
+            Q1.y = fma(-aE.y, F1, Q1.y);
+            Q2.x = fma(aB.y, F2, Q2.x);    // -i*B*F2 = (B.y, -B.x) * F2
+            Q2.y = fma(-aB.x, F2, Q2.y);
+            U1.x = fma(-aB.x, F1, U1.x);   // U: -(B F1 - i E F2)
+            U1.y = fma(-aB.y, F1, U1.y);
+            U2.x = fma(-aE.y, F2, U2.x);   // +i*E*F2 = (-E.y, E.x) * F2
+            U2.y = fma(aE.x, F2, U2.y);
           }
         }
+      };
+      const double2 zero2 = {0.0, 0.0};
+      int k = 0;
+      for (; k + 1 < nl; k += 2) {
+        // all LDS operands of both steps first: one wait covers two steps
+        const Coef q0 = coef[k], q1 = coef[k + 1];
+        const double2 t0 = a[k], t1 = a[k + 1];
+        double2 e0 = zero2, b0 = zero2, v0 = zero2, e1 = zero2, b1 = zero2, v1 = zero2;
+        if (NPOL == 4) {
+          e0 = a[nl + k];
+          e1 = a[nl + k + 1];
+          b0 = a[2 * nl + k];
+          b1 = a[2 * nl + k + 1];
+          v0 = a[3 * nl + k];
+          v1 = a[3 * nl + k + 1];
+        }
+        step(q0, t0, e0, b0, v0, k == 0, Ts, Vs, Qs, Qa, Us, Ua);
+        step(q1, t1, e1, b1, v1, false, Ta, Va, Qa, Qs, Ua, Us);
+      }
+      if (k < nl) {
+        const Coef q0 = coef[k];
+        const double2 t0 = a[k];
+        double2 e0 = zero2, b0 = zero2, v0 = zero2;
+        if (NPOL == 4) {
+          e0 = a[nl + k];
+          b0 = a[2 * nl + k];
+          v0 = a[3 * nl + k];
+        }
+        step(q0, t0, e0, b0, v0, k == 0, Ts, Vs, Qs, Qa, Us, Ua);
       }
     }
     const int64_t mstride = p.g.mmax + 1;
@@ -308,7 +332,6 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nring = p.g.nring, npair = (nring + 1) / 2;
   const double lfac_m = p.g.lfac[m];
-  const double dm = (double)m;
   const int64_t mstride = p.g.mmax + 1;
 
   for (int r0 = 0; r0 < npair; r0 += kThreads) {  // uniform trip count: barriers inside
@@ -330,12 +353,11 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
       gs[q] = make_double2(n.x + s.x, n.y + s.y);
       ga[q] = make_double2(n.x - s.x, n.y - s.y);
     }
-    const double inv_s2 = 1.0 / (sth * sth);
+    const double inv_s2 = 1.0 / (sth * sth), xs2 = x * inv_s2;
     double lam = 0.0, lam_prev = 0.0;
     int nsc = 0;
     if (!skip) lam_start(lfac_m, m, sth, lam, nsc);
     for (int k = 0; k < nl; ++k) {
-      const int l = m + k;
       const Coef q = coef[k];
       if (k > 0 && !skip) {
         const double nxt = x * lam * q.ra - lam_prev * q.rb;
@@ -359,20 +381,16 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
           const double2 gV = even ? gs[3] : ga[3];
           v[6] = gV.x * lam;
           v[7] = gV.y * lam;
-          if (l >= 2) {
-            const double dl = (double)l;
-            const double t = q.d * lam_prev;
-            const double F1 = q.c * (-((dl - dm * dm) * inv_s2 + 0.5 * dl * (dl - 1.0)) * lam + x * inv_s2 * t);
-            const double F2 = q.c * dm * inv_s2 * (-(dl - 1.0) * x * lam + t);
-            // F1 pairs with the lambda-parity combination, F2 with the opposite one
-            const double2 Q1 = even ? gs[1] : ga[1], Q2 = even ? ga[1] : gs[1];
-            const double2 U1 = even ? gs[2] : ga[2], U2 = even ? ga[2] : gs[2];
-            // E = -(F1 gQ + i F2 gU),  B = -(F1 gU - i F2 gQ)
-            v[2] = -(F1 * Q1.x - F2 * U2.y);
-            v[3] = -(F1 * Q1.y + F2 * U2.x);
-            v[4] = -(F1 * U1.x + F2 * Q2.y);
-            v[5] = -(F1 * U1.y - F2 * Q2.x);
-          }
+          const double F1 = fma(q.cd * xs2, lam_prev, -fma(q.c1, inv_s2, q.c2) * lam);
+          const double F2 = fma(q.c4 * inv_s2, lam_prev, -q.c3 * xs2 * lam);
+          // F1 pairs with the lambda-parity combination, F2 with the opposite one
+          const double2 Q1 = even ? gs[1] : ga[1], Q2 = even ? ga[1] : gs[1];
+          const double2 U1 = even ? gs[2] : ga[2], U2 = even ? ga[2] : gs[2];
+          // E = -(F1 gQ + i F2 gU),  B = -(F1 gU - i F2 gQ)
+          v[2] = -(F1 * Q1.x - F2 * U2.y);
+          v[3] = -(F1 * Q1.y + F2 * U2.x);
+          v[4] = -(F1 * U1.x + F2 * Q2.y);
+          v[5] = -(F1 * U1.y - F2 * Q2.x);
         }
       }
 #pragma unroll
