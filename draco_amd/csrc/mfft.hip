@@ -404,7 +404,9 @@ extern "C" {
 
 int dmm_mfft_pack(dmm_ctx* ctx, const void* ts, int64_t nrow, int nra, void* out, int mmax,
                   int out_dtype, const double* mscale) {
-  DMM_REQUIRE(ctx && ts && out, "dmm_mfft_pack: NULL argument");
+  DMM_REQUIRE(ctx != nullptr, "dmm_mfft_pack: ctx is NULL");
+  if (nrow == 0) return DMM_OK;  // an empty batch is legal (and has no buffers)
+  DMM_REQUIRE(ts && out, "dmm_mfft_pack: NULL argument");
   DMM_REQUIRE(nrow >= 0 && nra >= 1 && mmax >= 0, "dmm_mfft_pack: bad sizes nrow=%lld nra=%d mmax=%d",
               (long long)nrow, nra, mmax);
   DMM_REQUIRE(out_dtype == DMM_C64 || out_dtype == DMM_C128, "dmm_mfft_pack: bad out_dtype %d", out_dtype);
@@ -444,7 +446,9 @@ int dmm_mfft_pack(dmm_ctx* ctx, const void* ts, int64_t nrow, int nra, void* out
 
 int dmm_mmode_weight(dmm_ctx* ctx, const float* weight, int64_t nrow, int nra, double* out, int mmax,
                      const double* wscale) {
-  DMM_REQUIRE(ctx && weight && out, "dmm_mmode_weight: NULL argument");
+  DMM_REQUIRE(ctx != nullptr, "dmm_mmode_weight: ctx is NULL");
+  if (nrow == 0) return DMM_OK;
+  DMM_REQUIRE(weight && out, "dmm_mmode_weight: NULL argument");
   DMM_REQUIRE(nrow >= 0 && nra >= 1 && mmax >= 0, "dmm_mmode_weight: bad sizes");
   if (nrow == 0) return DMM_OK;
   DMM_HIP(hipSetDevice(ctx->device));
@@ -458,7 +462,9 @@ int dmm_mmode_weight(dmm_ctx* ctx, const float* weight, int64_t nrow, int nra, d
 
 int dmm_mifft_unpack(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int nra, int mmax_plus,
                      int mmax_minus, const double* mscale, void* vis_out) {
-  DMM_REQUIRE(ctx && mvis && vis_out, "dmm_mifft_unpack: NULL argument");
+  DMM_REQUIRE(ctx != nullptr, "dmm_mifft_unpack: ctx is NULL");
+  if (nrow == 0) return DMM_OK;
+  DMM_REQUIRE(mvis && vis_out, "dmm_mifft_unpack: NULL argument");
   DMM_REQUIRE(nrow >= 0 && nra >= 1 && n_m >= 1, "dmm_mifft_unpack: bad sizes");
   DMM_REQUIRE(mmax_plus >= 0 && mmax_plus < n_m && mmax_minus >= 0 && mmax_minus <= mmax_plus,
               "dmm_mifft_unpack: bad limits +%d -%d (n_m=%d)", mmax_plus, mmax_minus, n_m);

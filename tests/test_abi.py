@@ -56,3 +56,6 @@ def test_argument_errors():
         _lib.check(_lib.lib.dmm_ctx_sync(None))
     with pytest.raises(ValueError):
         _lib.check(_lib.lib.dmm_mfft_pack(None, None, 1, 8, None, 4, 1, None))
+    h = ctypes.c_void_p(1)  # a non-NULL ctx is not dereferenced before the argument checks
+    with pytest.raises(ValueError, match="NULL argument"):
+        _lib.check(_lib.lib.dmm_mfft_pack(h, None, 1, 8, None, 4, 1, None))

@@ -1,0 +1,166 @@
+"""GPU edge cases the reference's semantics imply: empty/ragged batches, mmax < lmax, one polarisation,
+the `_solve_m` subclass hook, masked (zero-weight) m-modes, error paths of the C ABI."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mapmaker as omm
+from oracle import sht as osht
+from oracle import synth as osyn
+from oracle import transform as otr
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _tel(nfreq, lmax, **kw):
+    from draco_amd.core.products import TransitTelescope
+
+    kw.setdefault("ncyl", 1)
+    kw.setdefault("nfeed_cyl", 3)
+    return TransitTelescope(osyn.frequencies(nfreq), lmax=lmax, **kw)
+
+
+def test_empty_and_single_row_transform():
+    from draco_amd.analysis import transform as T
+
+    out = T._make_marray(np.zeros((0, 16), np.complex64), mmax=8)
+    assert out.shape == (9, 2, 0)
+    ts = (np.arange(16) + 1j).astype(np.complex64)[None]
+    assert _rel(T._make_marray(ts, mmax=8, dtype=np.complex128), otr.make_marray(ts, mmax=8, dtype=np.complex128)) < 2e-6
+
+
+def test_mmax_smaller_than_lmax_and_fewer_m_rows():
+    """telescope.mmax < lmax, and data with fewer m rows than the telescope: mmax = min(...) (mapmaker.py:52)."""
+    from draco_amd.analysis.mapmaker import DirtyMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+
+    nfreq, lmax, mmax_tel, nside = 2, 14, 9, 8
+    tel = _tel(nfreq, lmax, mmax=mmax_tel)
+    bt = SyntheticProvider(tel, seed=3)
+    rng = np.random.default_rng(3)
+    for n_m in (mmax_tel + 4, 6):  # more rows than the telescope's mmax / fewer
+        mv = rng.standard_normal((n_m, 2, nfreq, tel.npairs)) + 1j * rng.standard_normal((n_m, 2, nfreq, tel.npairs))
+        mw = rng.uniform(0.5, 1.5, mv.shape)
+        mm = containers.MModes(mmax=n_m - 1, freq=tel.frequencies, stack=tel.npairs)
+        mm.vis[:] = mv
+        mm.weight[:] = mw
+        task = DirtyMapMaker(nside=nside)
+        task.setup(bt)
+        alm = task.alm_square(task.make_alm(mm))
+        ref = omm.solve_alm("dirty", lambda m, f: osyn.beam_tile(3, m, f, tel.npairs, 4, lmax), mv, mw, lmax, mmax_tel, [0, 1])
+        assert _rel(alm, ref) < 1e-12
+        out = task.process(mm)
+        refmap = osht.sphtrans_inv_sky(ref, nside)
+        assert _rel(out.map[:], refmap) < 1e-11
+
+
+def test_single_polarisation_broadcasts_like_the_reference():
+    """num_pol_sky = 1: the reference's 4-slot alm receives the T solution in every slot (mapmaker.py:71,94)."""
+    from draco_amd.analysis.mapmaker import DirtyMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+
+    tel = _tel(2, 9, num_pol_sky=1)
+    bt = SyntheticProvider(tel, seed=4)
+    rng = np.random.default_rng(4)
+    mv = rng.standard_normal((10, 2, 2, tel.npairs)) + 1j * rng.standard_normal((10, 2, 2, tel.npairs))
+    mw = rng.uniform(0.5, 1.5, mv.shape)
+    mm = containers.MModes(mmax=9, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    task = DirtyMapMaker(nside=4)
+    task.setup(bt)
+    alm = task.alm_square(task.make_alm(mm))
+    ref = omm.solve_alm("dirty", lambda m, f: osyn.beam_tile(4, m, f, tel.npairs, 1, 9), mv, mw, 9, 9, [0, 1], npol=1)
+    ref[:, 1:] = ref[:, :1]  # NumPy broadcast of a [1, lmax+1] result into the 4 slots
+    assert _rel(alm, ref) < 1e-12
+    out = task.process(mm)
+    assert out.map.shape == (2, 4, 192)
+    assert _rel(out.map[:], osht.sphtrans_inv_sky(ref, 4)) < 1e-11
+
+
+def test_solve_m_subclass_hook_is_honoured():
+    """A user subclass overriding `_solve_m` (the reference's extension point, mapmaker.py:120-140) is called."""
+    from draco_amd.analysis.mapmaker import BaseMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+
+    calls = []
+
+    class HalfDirty(BaseMapMaker):
+        def _solve_m(self, m, f, v, Ni):
+            calls.append((m, f))
+            bt = self.beamtransfer
+            bm = bt.beam_m(m, fi=f).reshape(bt.ntel, bt.nsky)
+            return 0.5 * (bm.T.conj() @ (Ni.reshape(-1) * v.reshape(-1))).reshape(4, -1)
+
+    tel = _tel(2, 5)
+    bt = SyntheticProvider(tel, seed=6)
+    rng = np.random.default_rng(6)
+    mv = rng.standard_normal((6, 2, 2, tel.npairs)) + 1j * rng.standard_normal((6, 2, 2, tel.npairs))
+    mw = rng.uniform(0.5, 1.5, mv.shape)
+    mm = containers.MModes(mmax=5, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    task = HalfDirty(nside=4)
+    task.setup(bt)
+    out = task.process(mm)
+    assert len(calls) == 12
+    alm = omm.solve_alm("dirty", lambda m, f: osyn.beam_tile(6, m, f, tel.npairs, 4, 5), mv, mw, 5, 5, [0, 1])
+    assert _rel(out.map[:], 0.5 * osht.sphtrans_inv_sky(alm, 4)) < 1e-11
+
+
+def test_masked_mmodes_all_three_makers():
+    """MaskMModeData-style input (flagging.py:113-173): zero weights for autos, m = 0 and one sign: no NaNs, parity holds."""
+    from draco_amd.analysis.mapmaker import DirtyMapMaker, MaximumLikelihoodMapMaker, WienerMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+
+    tel = _tel(1, 10)
+    bt = SyntheticProvider(tel, seed=8)
+    rng = np.random.default_rng(8)
+    mv = rng.standard_normal((11, 2, 1, tel.npairs)) + 1j * rng.standard_normal((11, 2, 1, tel.npairs))
+    mw = rng.uniform(0.5, 1.5, mv.shape) * 40
+    mw[0] = 0.0          # m = 0 masked entirely
+    mw[:, 1, :, ::3] = 0  # a third of the baselines masked on the negative side
+    mw[5] = 0.0          # one whole m masked
+    mm = containers.MModes(mmax=10, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    beam = lambda m, f: osyn.beam_tile(8, m, f, tel.npairs, 4, 10)  # noqa: E731
+    for cls, kind, tol in ((DirtyMapMaker, "dirty", 1e-12), (WienerMapMaker, "wiener", 1e-10), (MaximumLikelihoodMapMaker, "ml", 1e-8)):
+        task = cls()
+        task.setup(bt)
+        alm = task.alm_square(task.make_alm(mm))
+        assert np.all(np.isfinite(alm))
+        ref = omm.solve_alm(kind, beam, mv, mw, 10, 10, [0])
+        assert _rel(alm, ref) < tol, kind
+        assert np.all(alm[:, :, :, 0] == 0) and np.all(alm[:, :, :, 5] == 0)
+
+
+def test_abi_argument_errors_on_gpu():
+    from draco_amd import _lib
+    from draco_amd.device import Context, ptr
+
+    ctx = Context.get()
+    x = ctx.zeros((4, 8), np.complex64)
+    out = ctx.zeros((5, 2, 4), np.complex128)
+    with pytest.raises(ValueError, match="bad out_dtype"):
+        _lib.check(_lib.lib.dmm_mfft_pack(ctx.handle, ptr(x), 4, 8, ptr(out), 4, 7, None))
+    with pytest.raises(_lib.DmmError, match="nra"):
+        _lib.check(_lib.lib.dmm_mfft_pack(ctx.handle, ptr(x), 4, 20000, ptr(out), 4, 1, None))
+    with pytest.raises(ValueError, match="nside must be a power of two"):
+        _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(out), 1, 4, 3, 3, 6, ptr(out)))
+    tiles = _lib.tile_array([9], [0], [0])
+    h = C.c_void_p()
+    with pytest.raises(ValueError, match="out of range"):
+        _lib.check(_lib.lib.dmm_solve_plan_create(ctx.handle, tiles, 1, 3, 4, 5, 1, 6, 1, 1, C.byref(h)))
+    with pytest.raises(ValueError, match="unknown option"):
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"nope", 1))
