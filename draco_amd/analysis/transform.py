@@ -37,10 +37,11 @@ def _dev_dataset(ds, ctx, dtype):
     return ctx.to_device(np.asarray(ds[:]), dtype)
 
 
-def mmode_forward(ctx, vis_d, weight_d, mmax, remove_integration_window=False):
+def mmode_forward(ctx, vis_d, weight_d, mmax, remove_integration_window=False, vis_dtype=np.complex128):
     """Device-level transform: ``vis [..., nra]`` c64 (+ weight f32) -> ``(mvis, mweight)``.
 
-    ``mvis [mmax+1, 2, ...]`` complex128 and ``mweight`` float64, as ``transform.py:594-639``.
+    ``mvis [mmax+1, 2, ...]`` complex128 (complex64 on request) and ``mweight`` float64, as
+    ``transform.py:594-639``.  ``weight`` may have fewer leading axes than ``vis`` (hybrid streams).
     """
     lead = tuple(vis_d.shape[:-1])
     nra = int(vis_d.shape[-1])
@@ -51,12 +52,15 @@ def mmode_forward(ctx, vis_d, weight_d, mmax, remove_integration_window=False):
         w = np.sinc(m / nra)  # transform.py:631-633
         mscale = ctx.to_device(tools.invert_no_zero(w), np.float64)
         wscale = ctx.to_device(w**2, np.float64)
-    mvis = ctx.empty((mmax + 1, 2, *lead), np.complex128)
-    _lib.check(_lib.lib.dmm_mfft_pack(ctx.handle, ptr(vis_d), nrow, nra, ptr(mvis), mmax, _lib.DMM_C128, ptr(mscale)))
+    mvis = ctx.empty((mmax + 1, 2, *lead), vis_dtype)
+    out_dt = _lib.DMM_C128 if np.dtype(vis_dtype) == np.complex128 else _lib.DMM_C64
+    _lib.check(_lib.lib.dmm_mfft_pack(ctx.handle, ptr(vis_d), nrow, nra, ptr(mvis), mmax, out_dt, ptr(mscale)))
     mweight = None
     if weight_d is not None:
-        mweight = ctx.empty((mmax + 1, 2, *lead), np.float64)
-        _lib.check(_lib.lib.dmm_mmode_weight(ctx.handle, ptr(weight_d), nrow, nra, ptr(mweight), mmax, ptr(wscale)))
+        wlead = tuple(weight_d.shape[:-1])
+        wrow = int(np.prod(wlead)) if wlead else 1
+        mweight = ctx.empty((mmax + 1, 2, *wlead), np.float64)
+        _lib.check(_lib.lib.dmm_mmode_weight(ctx.handle, ptr(weight_d), wrow, nra, ptr(mweight), mmax, ptr(wscale)))
     return mvis, mweight
 
 
@@ -89,7 +93,10 @@ class MModeTransform(ContainerTask):
 
     def process(self, sstream):
         """Perform the m-mode transform: ``SiderealStream -> MModes`` (``transform.py:573-641``)."""
-        contmap = {containers.SiderealStream: containers.MModes}
+        contmap = {
+            containers.SiderealStream: containers.MModes,
+            containers.HybridVisStream: containers.HybridVisMModes,
+        }
         out_cont = contmap[sstream.__class__]  # KeyError for unsupported containers, like :590
 
         sstream.redistribute("freq")
@@ -105,9 +112,10 @@ class MModeTransform(ContainerTask):
 
         ma = out_cont(mmax=mmax, oddra=bool(nra % 2), axes_from=sstream, attrs_from=sstream, comm=sstream.comm, allocate=False)
         ma.redistribute("freq")
-        mvis, mweight = mmode_forward(ctx, svis, sweight, mmax, self.remove_integration_window)
+        hybrid = out_cont is containers.HybridVisMModes  # keeps complex64 / float32 (containers.py:1559-1574)
+        mvis, mweight = mmode_forward(ctx, svis, sweight, mmax, self.remove_integration_window, np.complex64 if hybrid else np.complex128)
         ma.attach("vis", mvis)
-        ma.attach("vis_weight", mweight)
+        ma.attach("vis_weight", mweight.to(torch.float32) if hybrid else mweight)
         return ma
 
 

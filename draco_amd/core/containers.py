@@ -232,6 +232,33 @@ class MModes(MContainer, _FreqMixin, _VisMixin):
     }
 
 
+class HybridVisStream(ContainerBase, _FreqMixin, _VisMixin):
+    """NS-beamformed visibilities: ``vis [pol, freq, ew, el, ra]`` c64, ``vis_weight [pol, freq, ew, ra]`` f32
+    (``containers.py:1389-1428``; the optional datasets of the reference are not carried)."""
+
+    _axes = ("pol", "freq", "ew", "el", "ra")
+    _dataset_spec = {
+        "vis": {"axes": ["pol", "freq", "ew", "el", "ra"], "dtype": np.complex64},
+        "vis_weight": {"axes": ["pol", "freq", "ew", "ra"], "dtype": np.float32},
+    }
+
+    def __init__(self, ra=None, **kwargs):
+        if isinstance(ra, (int, np.integer)):
+            ra = np.linspace(0.0, 360.0, int(ra), endpoint=False)
+        super().__init__(ra=ra, **kwargs)
+
+
+class HybridVisMModes(MContainer, _FreqMixin, _VisMixin):
+    """m-mode transformed hybrid visibilities: ``vis [m, msign, pol, freq, ew, el]`` **complex64**,
+    ``vis_weight [m, msign, pol, freq, ew]`` **float32** (``containers.py:1550-1574``)."""
+
+    _axes = ("m", "msign", "pol", "freq", "ew", "el")
+    _dataset_spec = {
+        "vis": {"axes": ["m", "msign", "pol", "freq", "ew", "el"], "dtype": np.complex64},
+        "vis_weight": {"axes": ["m", "msign", "pol", "freq", "ew"], "dtype": np.float32},
+    }
+
+
 class Map(ContainerBase, _FreqMixin):
     """``map [freq, pol, pixel]`` float64, HEALPix RING (``containers.py:470-486``, cora ``Map`` [3P])."""
 

@@ -88,15 +88,27 @@ class FakeMModes(_FakeCont):
         self.oddra = bool(oddra)
 
 
+class FakeHybridVisStream(_FakeCont):
+    def __init__(self, vis, weight):
+        self.vis = _DS(vis)
+        self.weight = _DS(weight)
+        self.attrs = {}
+
+
+class FakeHybridVisMModes(_FakeCont):
+    """complex64 vis [m, msign, pol, freq, ew, el], float32 weight [m, msign, pol, freq, ew] (containers.py:1559-1574)."""
+
+    def __init__(self, mmax=None, oddra=None, axes_from=None, attrs_from=None, comm=None):
+        self.vis = _DS(np.zeros((mmax + 1, 2, *axes_from.vis.shape[:-1]), np.complex64))
+        self.weight = _DS(np.zeros((mmax + 1, 2, *axes_from.weight.shape[:-1]), np.float32))
+        self.attrs = {"oddra": bool(oddra)}
+
+
 class _FakeContainers:
     SiderealStream = FakeSiderealStream
     MModes = FakeMModes
-
-    class HybridVisStream(_FakeCont):
-        pass
-
-    class HybridVisMModes(_FakeCont):
-        pass
+    HybridVisStream = FakeHybridVisStream
+    HybridVisMModes = FakeHybridVisMModes
 
 
 class _Tel:
@@ -275,6 +287,32 @@ def gen_mapmaker(mapmaker, out):
     np.savez_compressed(os.path.join(out, "mapmaker_solve_m.npz"), **cases)
 
 
+def gen_hybrid(transform, out):
+    """MModeTransform.process on a HybridVisStream-shaped input (transform.py:585-590 contmap)."""
+    transform.containers = _FakeContainers
+    rng = np.random.default_rng(4004)
+    cases = {}
+    idx = 0
+    for nra, tel_mmax, window in ((16, None, False), (15, 5, True)):
+        vis = crandn(rng, (2, 3, 2, 5, nra), np.complex64)  # [pol, freq, ew, el, ra]
+        w = rng.uniform(0.5, 1.5, (2, 3, 2, nra)).astype(np.float32)  # [pol, freq, ew, ra]
+        w[rng.uniform(size=w.shape) < 0.1] = 0.0
+        task = transform.MModeTransform.__new__(transform.MModeTransform)
+        task.remove_integration_window = window
+        task.use_fftw = False
+        task.telescope = None if tel_mmax is None else _Tel(tel_mmax, tel_mmax, 3)
+        ma = task.process(FakeHybridVisStream(vis.copy(), w.copy()))
+        cases[f"c{idx}_vis"] = vis
+        cases[f"c{idx}_weight"] = w
+        cases[f"c{idx}_mmax"] = np.int64(-1 if tel_mmax is None else tel_mmax)
+        cases[f"c{idx}_window"] = np.bool_(window)
+        cases[f"c{idx}_mvis"] = ma.vis.arr.view(np.ndarray)
+        cases[f"c{idx}_mweight"] = ma.weight.arr.view(np.ndarray)
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "transform_hybrid_task.npz"), **cases)
+
+
 class _EnumArr(np.ndarray):
     """ndarray with the two MPIArray methods the noise tasks use (single process)."""
 
@@ -387,10 +425,14 @@ def main():
 
     transform, mapmaker = load_reference()
     os.makedirs(GOLDEN, exist_ok=True)
-    if "--only-noise" not in sys.argv:
+    only = [a for a in sys.argv[1:] if a.startswith("--only-")]
+    if not only:
         gen_transform(transform, GOLDEN)
         gen_mapmaker(mapmaker, GOLDEN)
-    gen_noise(GOLDEN)
+    if not only or "--only-hybrid" in only:
+        gen_hybrid(transform, GOLDEN)
+    if not only or "--only-noise" in only:
+        gen_noise(GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 

@@ -91,12 +91,15 @@ def mmode_weight(weight):
     return nra**2 * invert_no_zero(invert_no_zero(weight).sum(axis=-1))
 
 
-def mmode_transform(vis, weight, mmax=None, remove_integration_window=False):
+def mmode_transform(vis, weight, mmax=None, remove_integration_window=False, vis_dtype=np.complex128, weight_dtype=np.float64):
     """``MModeTransform.process`` on plain arrays, ``transform.py:594-641``.
 
     ``vis [nfreq, nstack, nra]`` complex64, ``weight`` same shape float32 ->
     ``(mvis [mmax+1, 2, nfreq, nstack] complex128, mweight same float64)``.
     ``mmax=None`` means "no telescope given": ``nra // 2`` (``transform.py:604-607``).
+    For a ``HybridVisStream`` (``transform.py:587``) ``vis`` is ``[pol, freq, ew, el, ra]`` and
+    ``weight`` ``[pol, freq, ew, ra]``; the output datasets are complex64 / float32
+    (``containers.py:1559-1574``): pass ``vis_dtype`` / ``weight_dtype``.
     """
     vis = np.asarray(vis)
     weight = np.asarray(weight)
@@ -105,8 +108,8 @@ def mmode_transform(vis, weight, mmax=None, remove_integration_window=False):
     if mmax is None:
         mmax = vis.shape[-1] // 2
 
-    mvis = np.zeros((mmax + 1, 2, *vis.shape[:-1]), dtype=np.complex128)
-    mweight = np.zeros(mvis.shape, dtype=np.float64)
+    mvis = np.zeros((mmax + 1, 2, *vis.shape[:-1]), dtype=vis_dtype)
+    mweight = np.zeros((mmax + 1, 2, *weight.shape[:-1]), dtype=weight_dtype)
     make_marray(vis, mvis)
     mweight[:] = weight_sum[np.newaxis, np.newaxis]
 
@@ -114,9 +117,9 @@ def mmode_transform(vis, weight, mmax=None, remove_integration_window=False):
         m = np.arange(mmax + 1)
         w = np.sinc(m / nra)
         inv_w = invert_no_zero(w)
-        sl = (slice(None),) + (np.newaxis,) * (mvis.ndim - 1)
-        mvis *= inv_w[sl]
-        mweight *= w[sl] ** 2
+        # in-place like transform.py:636,639: NumPy forms the product in the wider type and casts back
+        mvis *= inv_w[(slice(None),) + (np.newaxis,) * (mvis.ndim - 1)]
+        mweight *= w[(slice(None),) + (np.newaxis,) * (mweight.ndim - 1)] ** 2
     return mvis, mweight
 
 

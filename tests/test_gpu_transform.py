@@ -97,6 +97,30 @@ def test_mmode_task_golden(T, golden_dir):
         assert np.array_equal(ma.weight[:] == 0, ref_w == 0)
 
 
+def test_hybrid_stream_golden(T, golden_dir):
+    """HybridVisStream -> HybridVisMModes (complex64 / float32 outputs, weight without the el axis)."""
+    from draco_amd.core import containers
+    from draco_amd.core.products import TransitTelescope
+
+    g = np.load(os.path.join(golden_dir, "transform_hybrid_task.npz"))
+    for i in range(int(g["ncase"])):
+        vis, w = g[f"c{i}_vis"], g[f"c{i}_weight"]
+        mmax = int(g[f"c{i}_mmax"])
+        npol, nfreq, new, nel, nra = vis.shape
+        hs = containers.HybridVisStream(pol=npol, freq=np.arange(nfreq) + 400.0, ew=new, el=nel, ra=nra)
+        hs.vis[:] = vis
+        hs.weight[:] = w
+        task = T.MModeTransform(remove_integration_window=bool(g[f"c{i}_window"]))
+        task.setup(None if mmax < 0 else TransitTelescope(np.arange(3.0), lmax=mmax))
+        ma = task.process(hs)
+        assert isinstance(ma, containers.HybridVisMModes)
+        ref_v, ref_w = g[f"c{i}_mvis"], g[f"c{i}_mweight"]
+        assert ma.vis.shape == ref_v.shape and ma.vis.dtype == np.complex64
+        assert ma.weight.shape == ref_w.shape and ma.weight.dtype == np.float32
+        assert _rel(ma.vis[:], ref_v) < FWD_TOL
+        np.testing.assert_allclose(ma.weight[:], ref_w, rtol=2e-6)
+
+
 def test_unsupported_container_keyerror(T):
     class Other:
         pass

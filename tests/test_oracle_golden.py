@@ -75,6 +75,18 @@ def test_mmode_task(golden_dir):
         assert bool(g[f"c{i}_oddra"]) == bool(g[f"c{i}_vis"].shape[-1] % 2)
 
 
+def test_hybrid_task(golden_dir):
+    g = _load(golden_dir, "transform_hybrid_task.npz")
+    for i in range(int(g["ncase"])):
+        mmax = int(g[f"c{i}_mmax"])
+        mv, mw = otr.mmode_transform(
+            g[f"c{i}_vis"], g[f"c{i}_weight"], None if mmax < 0 else mmax, bool(g[f"c{i}_window"]), np.complex64, np.float32
+        )
+        assert mv.dtype == np.complex64 and mw.dtype == np.float32
+        np.testing.assert_allclose(mv, g[f"c{i}_mvis"], rtol=0, atol=1e-7 * np.abs(g[f"c{i}_mvis"]).max())
+        np.testing.assert_allclose(mw, g[f"c{i}_mweight"], rtol=1e-6)
+
+
 def test_inverse_task(golden_dir):
     g = _load(golden_dir, "transform_inverse_task.npz")
     for i in range(int(g["ncase"])):
