@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "dmm_internal.h"
+#include "fft_lds.h"
 
 namespace {
 
@@ -219,7 +220,10 @@ template <int NPOL>
 __global__ __launch_bounds__(kThreads) void k_ring_synth(RingParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   double2* c = reinterpret_cast<double2*>(smem);  // [NPOL][mmax+1]
-  const int ring = blockIdx.x, f = blockIdx.y;
+  // polar-cap rings only (the equatorial belt runs k_ring_synth_fft): skip over the belt
+  const int ncap = p.g.nside - 1;
+  const int ring = (int)blockIdx.x < ncap ? blockIdx.x : blockIdx.x + 2 * p.g.nside + 1;
+  const int f = blockIdx.y;
   const int nm = p.g.mmax + 1;
   const double phi0 = p.g.phi0[ring];
   const int nphi = p.g.nphi[ring];
@@ -252,6 +256,91 @@ __global__ __launch_bounds__(kThreads) void k_ring_synth(RingParams p) {
     }
 #pragma unroll
     for (int q = 0; q < NPOL; ++q) p.map[((int64_t)f * NPOL + q) * p.npix + base + j] = acc[q];
+  }
+}
+
+// Equatorial belt (rings nside .. 3 nside, nphi = 4 nside, a power of two): the ring sum is an
+// inverse DFT.  The Hermitian spectrum H_k = b_k e^{i k phi0} (k <= mmax), H_{n-k} = conj(H_k),
+// folded modulo n, makes the map real, so TWO polarisations ride one complex FFT:
+// z = H_a + i H_b  ->  IDFT(z) = map_a + i map_b.  IDFT(z) = conj(DFT(conj z)) on the shared
+// in-LDS DIF kernel (bit-reversed output, read through the reversal).
+constexpr int kFftThreads = 256;
+template <int NPOL>
+__global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p) {
+  using dmm_fft::C;
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  const int n = 4 * p.g.nside, P = n + 1;
+  int logn = 0;
+  while ((1 << logn) < n) ++logn;
+  C<double>* buf = reinterpret_cast<C<double>*>(smem);  // [NROW][P]
+  C<double>* tw = buf + NROW * P;                       // [n/2]
+  const int ring = p.g.nside - 1 + blockIdx.x, f = blockIdx.y;
+  const int nm = p.g.mmax + 1;
+  const double phi0 = p.g.phi0[ring];
+  for (int k = threadIdx.x; k < (n >> 1); k += kFftThreads) {
+    double sn, cs;
+    sincospi(-2.0 * (double)k / (double)n, &sn, &cs);
+    tw[k] = {cs, sn};
+  }
+  const double2* brow[NPOL];
+#pragma unroll
+  for (int q = 0; q < NPOL; ++q) brow[q] = p.b + (((int64_t)f * NPOL + q) * p.g.nring + ring) * nm;
+  for (int k = threadIdx.x; k < n; k += kFftThreads) {
+    double zr[NROW], zi[NROW];
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) zr[r] = zi[r] = 0.0;
+    // direct terms m == k (mod n)
+    for (int m = k; m < nm; m += n) {
+      double sn, cs;
+      sincos((double)m * phi0, &sn, &cs);
+#pragma unroll
+      for (int r = 0; r < NROW; ++r) {
+        const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
+        double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
+        double br = 0.0, bi = 0.0;
+        if (NPOL == 4) {
+          const double2 vb = brow[2 * r + 1][m];
+          br = vb.x * cs - vb.y * sn;
+          bi = vb.x * sn + vb.y * cs;
+        }
+        if (m == 0) ai = bi = 0.0;  // the m = 0 term of a real field is real
+        zr[r] += ar - bi;           // z = H_a + i H_b
+        zi[r] += ai + br;
+      }
+    }
+    // mirrored terms m == -k (mod n), m >= 1: conj(H_a) + i conj(H_b)
+    for (int m = (k == 0 ? n : n - k); m < nm; m += n) {
+      double sn, cs;
+      sincos((double)m * phi0, &sn, &cs);
+#pragma unroll
+      for (int r = 0; r < NROW; ++r) {
+        const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
+        const double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
+        double br = 0.0, bi = 0.0;
+        if (NPOL == 4) {
+          const double2 vb = brow[2 * r + 1][m];
+          br = vb.x * cs - vb.y * sn;
+          bi = vb.x * sn + vb.y * cs;
+        }
+        zr[r] += ar + bi;  // conj(a) + i conj(b) = (ar + bi) + i(br - ai)
+        zi[r] += br - ai;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) buf[r * P + k] = {zr[r], -zi[r]};  // conj(z)
+  }
+  __syncthreads();
+  dmm_fft::fft_dif<double, kFftThreads>(buf, tw, NROW, n, logn, P);
+  const int64_t base = p.g.start[ring];
+  for (int j = threadIdx.x; j < n; j += kFftThreads) {
+    const int jr = dmm_fft::bitrev(j, logn);
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) {
+      const C<double> y = buf[r * P + jr];  // IDFT(z)_j = conj(y)
+      p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * r : 0)) * p.npix + base + j] = y.x;
+      if (NPOL == 4) p.map[((int64_t)f * NPOL + 2 * r + 1) * p.npix + base + j] = -y.y;
+    }
   }
 }
 
@@ -541,8 +630,17 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   rp.map = map;
   rp.npix = 12LL * g.nside * g.nside;
   const size_t lds2 = (size_t)NPOL * (g.mmax + 1) * sizeof(double2);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_ring_synth<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-  hipLaunchKernelGGL(k_ring_synth<NPOL>, dim3(g.nring, nf), dim3(kThreads), lds2, ctx->stream, rp);
+  const int ncap2 = 2 * (g.nside - 1);  // polar-cap rings: direct sums
+  if (ncap2 > 0) {
+    DMM_HIP(hipFuncSetAttribute((const void*)k_ring_synth<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    hipLaunchKernelGGL(k_ring_synth<NPOL>, dim3(ncap2, nf), dim3(kThreads), lds2, ctx->stream, rp);
+  }
+  // equatorial belt: in-LDS FFT, two polarisations per complex transform
+  const int n = 4 * g.nside;
+  const size_t lds3 = ((size_t)(NPOL == 4 ? 2 : 1) * (n + 1) + n / 2) * sizeof(double2);
+  if (lds3 > 160 * 1024) return dmm_set_error(DMM_E_UNSUPPORTED, "alm2map: nside=%d too large for the in-LDS ring FFT", g.nside);
+  DMM_HIP(hipFuncSetAttribute((const void*)k_ring_synth_fft<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+  hipLaunchKernelGGL(k_ring_synth_fft<NPOL>, dim3(2 * g.nside + 1, nf), dim3(kFftThreads), lds3, ctx->stream, rp);
   DMM_HIP(hipGetLastError());
   return DMM_OK;
 }
