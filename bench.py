@@ -67,10 +67,16 @@ def cpu_baseline(cfg, seconds):
     from oracle import synth as osyn
     from oracle import transform as otr
 
+    # threads actually available to / used by the BLAS behind np.dot on this box
     try:
-        from threadpoolctl import threadpool_info
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
 
-        nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        threadpool_limits(limits=ncpu)
+        nthreads = min(ncpu, max([p.get("num_threads", 1) for p in threadpool_info()] + [1]))
     except Exception:
         nthreads = 1
     npairs = osyn.npairs_of(cfg["ncyl"], cfg["nfeed_cyl"])
@@ -305,6 +311,38 @@ def main():
                 }
                 del j2
                 torch.cuda.empty_cache()
+            # the rest of the map-maker around the headline path, cfg 3 sizes, HIP-event timed:
+            # inverse SHT of all frequencies (DirtyMapMaker.process's last stage) and a Wiener sample
+            from draco_amd import _lib
+            from draco_amd.analysis._solve import SolveEngine
+            from draco_amd.analysis.transform import mmode_forward
+            from draco_amd.core.products import SyntheticProvider, TransitTelescope
+            from draco_amd.device import Context, ptr
+
+            ctx = Context.get()
+            nfreq, lmax, nside = cfg["nfreq"], cfg["lmax"], cfg["nside"]
+            gen = torch.Generator(device=ctx.device).manual_seed(7)
+            alm = torch.randn((nfreq, 4, lmax + 1, lmax + 1), dtype=torch.complex128, device=ctx.device, generator=gen)
+            maps = torch.empty((nfreq, 4, 12 * nside * nside), dtype=torch.float64, device=ctx.device)
+            for _ in range(2):
+                ctx.timer_start()
+                _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), nfreq, 4, lmax, lmax, nside, ptr(maps)))
+                t_sht = ctx.timer_stop()
+            extra["alm2map_all_freq_ms"] = t_sht
+            del alm, maps
+            tel = TransitTelescope(osyn.frequencies(nfreq), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+            eng = SolveEngine(SyntheticProvider(tel, seed=5), ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=True)
+            vis1 = torch.randn((1, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
+            w1 = torch.rand((1, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
+            mv1, mw1 = mmode_forward(ctx, vis1, w1, lmax)
+            for _ in range(2):
+                ctx.sync()
+                t0 = time.perf_counter()
+                eng.solve("wiener", mv1, mw1, [0], lmax, prior_amp=1.0, prior_tilt=0.5)
+                ctx.sync()
+                t_w = time.perf_counter() - t0
+            extra["wiener_ms_per_solve"] = t_w * 1e3 / (lmax + 1)
+            extra["wiener_sample"] = f"all {lmax + 1} m of one frequency, B resident"
         except Exception as e:  # secondary numbers must never break the headline line
             extra["error"] = repr(e)
         out["extra"] = extra
