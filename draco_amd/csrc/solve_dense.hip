@@ -67,38 +67,75 @@ __device__ __forceinline__ double2 load_bc(const void* B, int c128, int64_t off)
   return make_double2((double)v.x, (double)v.y);
 }
 
-// Stage rows [row0, row0+64) x complex columns [k0, k0+KC) of an operand into LDS as doubles
-// [64][LP] (re, im interleaved).  SRC: 0 = beam tile (gram), 1 = matrix A, 2 = Linv block.
+// Staging of rows [row0, row0+64) x complex columns [k0, k0+KC) of an operand, split in two so the
+// global loads of chunk k+1 fly under the MFMAs of chunk k: fetch() -> 4 complex values per thread in
+// registers, commit() -> LDS as doubles [64][LP] (re, im interleaved).
+// SRC: 0 = beam tile (gram), 1 = matrix A, 2 = Linv block.
 template <int SRC>
-__device__ __forceinline__ void stage(double* lds, const DenseParams& p, const dmm_tile& tile, int mat, int row0,
+__device__ __forceinline__ void fetch(double2 (&v)[4], const DenseParams& p, const dmm_tile& tile, int mat, int row0,
                                       int k0, int K, bool scale_s) {
   const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
   const int row = row0 + r;
+  if (SRC == 0) {
+    const int L = p.lmax + 1 - tile.m;
+    int k = k0 + c0;
+    if (!p.full_layout && p.b_c128 && (K & 3) == 0) {
+      // fast path (packed complex128 tiles, npol*L a multiple of 4): the row is contiguous in k and the
+      // thread's 4 columns are all inside or all outside -> four 16-byte loads, one predicate
+      const bool in = row < p.N && k < K;
+      const double2* src = reinterpret_cast<const double2*>(p.B) + tile.b_off + (int64_t)row * K + k;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int k = k0 + c0 + c;
-    double2 v = make_double2(0.0, 0.0);
-    if (SRC == 0) {
-      if (row < p.N && k < K) {
-        const int L = p.lmax + 1 - tile.m;
-        const int pol = k / L, lrel = k - pol * L;
-        const int pol_stride = p.full_layout ? p.lmax + 1 : L;
-        const int64_t off = tile.b_off + (int64_t)row * p.npol * pol_stride + (int64_t)pol * pol_stride +
-                            (p.full_layout ? tile.m : 0) + lrel;
-        v = load_bc(p.B, p.b_c128, off);
-        if (scale_s && p.Sl) {
-          const double s = p.Sl[tile.m + lrel];
-          v.x *= s;
-          v.y *= s;
+      for (int c = 0; c < 4; ++c) v[c] = in ? src[c] : make_double2(0.0, 0.0);
+      if (scale_s && p.Sl && in) {
+        int lrel = k % L;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double sc = p.Sl[tile.m + lrel];
+          v[c].x *= sc;
+          v[c].y *= sc;
+          if (++lrel == L) lrel = 0;
         }
       }
-    } else if (SRC == 1) {
-      if (k < K) v = p.A[((int64_t)mat * p.Np + row) * p.Np + k];
     } else {
-      v = p.Linv[(((int64_t)mat * p.T + p.J) * TB + (row - row0)) * TB + k];
+      const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+      const int64_t rbase = tile.b_off + (int64_t)row * p.npol * pol_stride + (p.full_layout ? tile.m : 0);
+      int pol = 0;  // pol = k / L without a division (npol is tiny)
+      for (int q = 1; q < p.npol; ++q) pol += (k >= q * L);
+      int lrel = k - pol * L;
+#pragma unroll
+      for (int c = 0; c < 4; ++c, ++k) {
+        v[c] = make_double2(0.0, 0.0);
+        if (row < p.N && k < K) {
+          v[c] = load_bc(p.B, p.b_c128, rbase + (int64_t)pol * pol_stride + lrel);
+          if (scale_s && p.Sl) {
+            const double sc = p.Sl[tile.m + lrel];
+            v[c].x *= sc;
+            v[c].y *= sc;
+          }
+        }
+        if (++lrel == L) {
+          lrel = 0;
+          ++pol;
+        }
+      }
     }
-    *reinterpret_cast<double2*>(lds + r * LP + 2 * (c0 + c)) = v;
+  } else if (SRC == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c0 + c;
+      v[c] = k < K ? p.A[((int64_t)mat * p.Np + row) * p.Np + k] : make_double2(0.0, 0.0);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      v[c] = p.Linv[(((int64_t)mat * p.T + p.J) * TB + (row - row0)) * TB + k0 + c0 + c];
   }
+}
+
+__device__ __forceinline__ void commit(double* lds, const double2 (&v)[4]) {
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) *reinterpret_cast<double2*>(lds + r * LP + 2 * (c0 + c)) = v[c];
 }
 
 // One 64x64 complex output tile C(I,J) per block; 4 waves, each a 32x32 quadrant = 2x2 MFMA tiles.
@@ -135,19 +172,26 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    __syncthreads();
+  double2 xr[4], yr[4];
+  auto fetch_chunk = [&](int k0) {
     if (MODE == MODE_GRAM) {
-      stage<0>(xs, p, tile, mat, I0, k0, K, false);
-      stage<0>(ys, p, tile, mat, J0, k0, K, true);
+      fetch<0>(xr, p, tile, mat, I0, k0, K, false);
+      fetch<0>(yr, p, tile, mat, J0, k0, K, true);
     } else if (MODE == MODE_UPDATE) {
-      stage<1>(xs, p, tile, mat, I0, k0, K, false);
-      stage<1>(ys, p, tile, mat, J0, k0, K, false);
+      fetch<1>(xr, p, tile, mat, I0, k0, K, false);
+      fetch<1>(yr, p, tile, mat, J0, k0, K, false);
     } else {
-      stage<1>(xs, p, tile, mat, I0, kbase + k0, kbase + K, false);
-      stage<2>(ys, p, tile, mat, 0, k0, K, false);
+      fetch<1>(xr, p, tile, mat, I0, kbase + k0, kbase + K, false);
+      fetch<2>(yr, p, tile, mat, 0, k0, K, false);
     }
+  };
+  if (K > 0) fetch_chunk(0);
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();  // the previous chunk's MFMAs have read LDS
+    commit(xs, xr);
+    commit(ys, yr);
     __syncthreads();
+    if (k0 + KC < K) fetch_chunk(k0 + KC);  // in flight under this chunk's MFMAs
 #pragma unroll
     for (int kk = 0; kk < 2 * KC; kk += 4) {
       double a[2], b[2], b2[2];
