@@ -494,3 +494,43 @@ int dmm_mrow_is_zero(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ MaskMModeData
+// Zero m-mode noise weights ahead of map-making (reference draco/analysis/flagging.py:113-173):
+// auto-correlations, m = 0, one sign of m, m below a threshold.  weight [n_m, 2, nfreq, nstack].
+namespace {
+__global__ void k_mask_mmode(double* __restrict__ w, int n_m, int64_t nfreq, int nstack,
+                             const unsigned char* __restrict__ is_auto, int m_zero, int positive_m, int negative_m,
+                             int mask_low_m) {
+  const int64_t per_ms = nfreq * nstack, total = (int64_t)n_m * 2 * per_ms;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ms = i / per_ms;
+    const int m = (int)(ms >> 1), s = (int)(ms & 1);
+    const int p = (int)(i % nstack);
+    bool kill = false;
+    if (is_auto && is_auto[p]) kill = true;
+    if (!m_zero && m == 0) kill = true;
+    if (!positive_m && m >= 1 && s == 0) kill = true;
+    if (!negative_m && m >= 1 && s == 1) kill = true;
+    if (m < mask_low_m) kill = true;
+    if (kill) w[i] = 0.0;
+  }
+}
+}  // namespace
+
+extern "C" int dmm_mask_mmode_weight(dmm_ctx* ctx, double* mweight, int n_m, int64_t nfreq, int nstack,
+                                     const unsigned char* is_auto, int m_zero, int positive_m, int negative_m,
+                                     int mask_low_m) {
+  DMM_REQUIRE(ctx != nullptr, "dmm_mask_mmode_weight: ctx is NULL");
+  DMM_REQUIRE(n_m >= 0 && nfreq >= 0 && nstack >= 0 && mask_low_m >= 0, "dmm_mask_mmode_weight: bad sizes");
+  const int64_t total = (int64_t)n_m * 2 * nfreq * nstack;
+  if (total == 0) return DMM_OK;
+  DMM_REQUIRE(mweight != nullptr, "dmm_mask_mmode_weight: NULL argument");
+  DMM_HIP(hipSetDevice(ctx->device));
+  int64_t nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(k_mask_mmode, dim3((unsigned)nb), dim3(256), 0, ctx->stream, mweight, n_m, nfreq, nstack, is_auto,
+                     m_zero, positive_m, negative_m, mask_low_m);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}

@@ -105,6 +105,14 @@ int dmm_mifft_unpack(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int 
 int dmm_mrow_is_zero(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int m,
                      int sign, int* is_zero /*[host]*/);
 
+/* MaskMModeData.process (reference flagging.py:113-173), in place on MModes.weight
+ * [n_m, 2, nfreq, nstack] double: zero the weights of auto-correlations (is_auto[nstack] != 0;
+ * NULL = keep), of m = 0 unless m_zero, of +m / -m (m >= 1) unless positive_m / negative_m, and
+ * of every m < mask_low_m.                                                            */
+int dmm_mask_mmode_weight(dmm_ctx* ctx, double* mweight, int n_m, int64_t nfreq, int nstack,
+                          const unsigned char* is_auto /*[dev]*/, int m_zero, int positive_m,
+                          int negative_m, int mask_low_m);
+
 /* ------------------------------------------------------ map-maker solves (a5-a8)
  * A plan fixes the batch of (m, f) solves (the double loop at mapmaker.py:79-94)
  * and the shapes; it owns a device copy of the tile table.

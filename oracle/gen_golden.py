@@ -419,6 +419,32 @@ def gen_noise(out):
     np.savez_compressed(os.path.join(out, "noise.npz"), **cases)
 
 
+def gen_mask(out):
+    """MaskMModeData.process (flagging.py:113-173) on a duck-typed MModes."""
+    from draco.analysis import flagging
+
+    rng = np.random.default_rng(5005)
+    ninput = 3
+    prod = np.array([(i, j) for i in range(ninput) for j in range(i, ninput)], dtype=[("input_a", int), ("input_b", int)])
+    cases = {}
+    idx = 0
+    for auto, mzero, pos, neg, low in ((False, False, True, True, None), (True, True, True, True, None), (False, True, False, True, None), (True, False, True, False, 3), (False, False, True, True, 2)):
+        w = rng.uniform(0.5, 1.5, (6, 2, 2, len(prod)))
+        mm = FakeMModes(oddra=False, vis=np.zeros(w.shape, complex), weight=w.copy())
+        mm.prodstack = prod
+        t = flagging.MaskMModeData.__new__(flagging.MaskMModeData)
+        t.auto_correlations, t.m_zero, t.positive_m, t.negative_m, t.mask_low_m = auto, mzero, pos, neg, low
+        t.process(mm)
+        cases[f"c{idx}_w"] = w
+        cases[f"c{idx}_opts"] = np.array([auto, mzero, pos, neg, -1 if low is None else low], dtype=np.int64)
+        cases[f"c{idx}_out"] = mm.weight.arr.view(np.ndarray)
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    cases["prod_a"] = prod["input_a"]
+    cases["prod_b"] = prod["input_b"]
+    np.savez_compressed(os.path.join(out, "flagging_mask_mmode.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -433,6 +459,8 @@ def main():
         gen_hybrid(transform, GOLDEN)
     if not only or "--only-noise" in only:
         gen_noise(GOLDEN)
+    if not only or "--only-mask" in only:
+        gen_mask(GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 

@@ -164,3 +164,25 @@ def test_abi_argument_errors_on_gpu():
         _lib.check(_lib.lib.dmm_solve_plan_create(ctx.handle, tiles, 1, 3, 4, 5, 1, 6, 1, 1, C.byref(h)))
     with pytest.raises(ValueError, match="unknown option"):
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"nope", 1))
+
+
+def test_mask_mmode_data_golden(golden_dir):
+    """MaskMModeData against the reference's own outputs; in place, returns the same container."""
+    import os
+
+    from draco_amd.analysis.flagging import MaskMModeData
+    from draco_amd.core import containers
+
+    g = np.load(os.path.join(golden_dir, "flagging_mask_mmode.npz"))
+    prod = np.zeros(len(g["prod_a"]), dtype=[("input_a", int), ("input_b", int)])
+    prod["input_a"], prod["input_b"] = g["prod_a"], g["prod_b"]
+    for i in range(int(g["ncase"])):
+        w = g[f"c{i}_w"]
+        auto, mzero, pos, neg, low = (int(x) for x in g[f"c{i}_opts"])
+        mm = containers.MModes(mmax=w.shape[0] - 1, freq=np.arange(w.shape[2]) + 400.0, prod=prod, stack=len(prod), input=3)
+        mm.weight[:] = w
+        t = MaskMModeData(auto_correlations=bool(auto), m_zero=bool(mzero), positive_m=bool(pos), negative_m=bool(neg))
+        t.mask_low_m = None if low < 0 else low
+        out = t.process(mm)
+        assert out is mm
+        assert np.array_equal(mm.weight[:], g[f"c{i}_out"]), i

@@ -134,3 +134,14 @@ def test_find_keys():
     assert omm.find_keys([400.0, 401.0], [399.0]) == [None]
     with pytest.raises(ValueError):
         omm.find_keys([400.0, 401.0], [399.0], require_match=True)
+
+
+def test_mask_mmode(golden_dir):
+    from oracle import flagging as ofl
+
+    g = _load(golden_dir, "flagging_mask_mmode.npz")
+    ps = list(zip(g["prod_a"], g["prod_b"]))
+    for i in range(int(g["ncase"])):
+        auto, mzero, pos, neg, low = (int(x) for x in g[f"c{i}_opts"])
+        out = ofl.mask_mmode_weight(g[f"c{i}_w"], ps, bool(auto), bool(mzero), bool(pos), bool(neg), None if low < 0 else low)
+        np.testing.assert_array_equal(out, g[f"c{i}_out"])
