@@ -445,6 +445,125 @@ def gen_mask(out):
     np.savez_compressed(os.path.join(out, "flagging_mask_mmode.npz"), **cases)
 
 
+class _ShapeDS(_DS):
+    """Dataset stub with the MPIArray attributes DeconvolveHybridMBase.process reads."""
+
+    @property
+    def local_shape(self):
+        return self.arr.shape
+
+    @property
+    def local_offset(self):
+        return (0,) * self.arr.ndim
+
+
+class FakeHybridM(_FakeCont):
+    distributed = False
+
+    def __init__(self, vis, weight, freq, ew, el, oddra):
+        self.vis = _ShapeDS(vis)
+        self.weight = _ShapeDS(weight)
+        self.freq = np.asarray(freq, dtype=float)
+        nm, _, npol = vis.shape[:3]
+        self.index_map = {"m": np.arange(nm), "el": np.asarray(el), "ew": np.asarray(ew), "pol": np.arange(npol), "freq": self.freq}
+        self.mmax = nm - 1
+        self.oddra = bool(oddra)
+        self.attrs = {}
+
+
+class FakeRingMap(_FakeCont):
+    def __init__(self, beam=None, ra=None, axes_from=None, attrs_from=None, distributed=None, comm=None):
+        hv = axes_from
+        npol, nfreq = hv.vis.shape[2], hv.vis.shape[3]
+        nel = hv.vis.shape[5]
+        self.index_map = dict(hv.index_map)
+        self.attrs = {}
+        self._shape = (beam, npol, nfreq, ra, nel)
+        self.map = _DS(np.zeros(self._shape))
+        self.weight = _DS(np.zeros(self._shape[1:]))
+
+    def add_dataset(self, name):
+        b, npol, nfreq, ra, nel = self._shape
+        shp = {"dirty_beam_power": (b, npol, nfreq, nel), "dirty_beam": self._shape}[name]
+        setattr(self, name, _DS(np.zeros(shp)))
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+
+    debug = warning = info
+
+
+def gen_ringmap(out):
+    """TikhonovRingMapMaker / WienerRingMapMaker.process (ringmapmaker.py:538-1186) on duck-typed containers."""
+    import importlib
+
+    from draco.analysis import ringmapmaker as rmk
+
+    rmk.containers = type("NS", (), {"RingMap": FakeRingMap, "HybridVisMModes": FakeHybridM})
+    rng = np.random.default_rng(6006)
+    cases = {}
+    idx = 0
+    nm, npol, nfreq, new, nel = 9, 2, 3, 4, 5
+    freq = np.array([600.0, 650.0, 700.0])
+    ew = np.array([0.0, 22.0, 44.0, 66.0])
+    el = np.linspace(-0.8, 0.8, nel)
+
+    class _T:
+        latitude = 49.0
+
+    configs = [
+        ("tikhonov", dict(weight_ew="natural", inv_SN=1e-3), dict(exclude_cyl=[], skip=False, window="none", oddra=False)),
+        ("tikhonov", dict(weight_ew="uniform", inv_SN=1e-2), dict(exclude_cyl=[0], skip=False, window="none", oddra=True)),
+        ("tikhonov", dict(weight_ew="inverse_variance", inv_SN=1e-3), dict(exclude_cyl=[1], skip=False, window="hann", oddra=False)),
+        ("tikhonov", dict(weight_ew="natural", inv_SN=1e-3), dict(exclude_cyl=[], skip=True, window="none", oddra=False)),
+        ("wiener", dict(), dict(exclude_cyl=[], skip=False, window="none", oddra=False)),
+        ("wiener", dict(gal_amp=2.0, psrc_amp=0.1), dict(exclude_cyl=[0], skip=False, window="blackman_harris", oddra=True)),
+    ]
+    for kind, attrs, base in configs:
+        hv = crandn(rng, (nm, 2, npol, nfreq, new, nel), np.complex64)
+        bv = crandn(rng, (nm + 2, 2, npol, nfreq, new, nel), np.complex64)
+        hw = rng.uniform(0.5, 1.5, (nm, 2, npol, nfreq, new)).astype(np.float32)
+        hw[rng.uniform(size=hw.shape) < 0.1] = 0.0
+        hw[0, 1] = 0.0
+        cls = rmk.TikhonovRingMapMaker if kind == "tikhonov" else rmk.WienerRingMapMaker
+        t = cls.__new__(cls)
+        t.log = _Log()
+        t.exclude_cyl = list(base["exclude_cyl"])
+        t.exclude_intracyl = False
+        t.skip_deconvolution = base["skip"]
+        t.reference_declination = None
+        t.save_dirty_beam = True
+        t.window_type = base["window"]
+        t.window_size = 1.0
+        t.window_scaled = False
+        t.telescope = _T()
+        if kind == "tikhonov":
+            t.weight_ew = attrs["weight_ew"]
+            t.inv_SN = attrs["inv_SN"]
+        else:
+            t.gal_amp, t.gal_alpha, t.gal_beta = attrs.get("gal_amp", 1.41), -1.75, -0.75
+            t.psrc_amp, t.psrc_alpha = attrs.get("psrc_amp", 0.045), -1.0
+        rm = t.process(FakeHybridM(hv.copy(), hw.copy(), freq, ew, el, base["oddra"]), FakeHybridM(bv.copy(), np.ones(bv.shape[:-1], np.float32), freq, ew, el, base["oddra"]))
+        cases[f"c{idx}_kind"] = np.array(kind)
+        cases[f"c{idx}_hv"], cases[f"c{idx}_bv"], cases[f"c{idx}_hw"] = hv, bv, hw
+        cases[f"c{idx}_opts"] = np.array([base["skip"], base["oddra"]], dtype=np.int64)
+        cases[f"c{idx}_exclude"] = np.array(base["exclude_cyl"], dtype=np.int64)
+        cases[f"c{idx}_window"] = np.array(base["window"])
+        cases[f"c{idx}_weight_ew"] = np.array(attrs.get("weight_ew", "inverse_variance"))
+        cases[f"c{idx}_params"] = np.array([attrs.get("inv_SN", 0.0), attrs.get("gal_amp", 1.41), attrs.get("psrc_amp", 0.045)])
+        cases[f"c{idx}_map"] = rm.map.arr.view(np.ndarray)
+        cases[f"c{idx}_wgt"] = rm.weight.arr.view(np.ndarray)
+        cases[f"c{idx}_dbp"] = rm.dirty_beam_power.arr.view(np.ndarray)
+        cases[f"c{idx}_db"] = rm.dirty_beam.arr.view(np.ndarray)
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    cases["freq"], cases["ew"], cases["el"] = freq, ew, el
+    cases["latitude"] = np.float64(49.0)
+    np.savez_compressed(os.path.join(out, "ringmap_deconvolve.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -461,6 +580,8 @@ def main():
         gen_noise(GOLDEN)
     if not only or "--only-mask" in only:
         gen_mask(GOLDEN)
+    if not only or "--only-ringmap" in only:
+        gen_ringmap(GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 

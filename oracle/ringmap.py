@@ -1,0 +1,149 @@
+"""Oracle: deconvolving ring-map makers.  TEST INFRASTRUCTURE ONLY.
+
+Restates ``DeconvolveHybridMBase.process`` with the ``TikhonovRingMapMaker`` /
+``WienerRingMapMaker`` weights and regularisation (reference
+``draco/analysis/ringmapmaker.py:538-823, 842-930, 1075-1186``; window shapes from
+``draco/util/tools.py:547-601``) on plain arrays:
+
+    hv [nm, 2, npol, nfreq, new, nel] complex64   hybrid visibility m-modes
+    hw [nm, 2, npol, nfreq, new]      float32     their inverse variance
+    bv [>=nm, 2, npol, nfreq, new, nel] complex64 beam m-modes
+
+-> map [1, npol, nfreq, nra, nel], weight [npol, nfreq, nra, nel], dirty_beam_power
+[1, npol, nfreq, nel], dirty_beam [1, npol, nfreq, nra, nel], all float64.
+Pinned by ``tests/golden/ringmap_deconvolve.npz`` (outputs of the reference classes).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import scipy.constants
+
+from .transform import invert_no_zero
+
+_WINDOWS = {
+    "uniform": [1, 0, 0, 0],
+    "hann": [0.5, -0.5, 0, 0],
+    "hanning": [0.5, -0.5, 0, 0],
+    "hamming": [0.53836, -0.46164, 0, 0],
+    "blackman": [0.42, -0.5, 0.08, 0],
+    "nuttall": [0.355768, -0.487396, 0.144232, -0.012604],
+    "blackman_nuttall": [0.3635819, -0.4891775, 0.1365995, -0.0106411],
+    "blackman_harris": [0.35875, -0.48829, 0.14128, -0.01168],
+}
+
+
+def window_generalised(x, window="nuttall"):
+    """Cosine-sum windows at arbitrary locations, zero outside [0, 1] (``tools.py:583-601``)."""
+    a = np.array(_WINDOWS[window])
+    t = 2 * np.pi * np.arange(4)[:, np.newaxis] * x[np.newaxis, :]
+    w = (a[:, np.newaxis] * np.cos(t)).sum(axis=0)
+    return np.where((x >= 0) & (x <= 1), w, 0)
+
+
+def get_window(freq, m, el, ew, latitude, window_type, window_size=1.0, window_scaled=False, exclude_cyl=()):
+    """``_get_window`` (``ringmapmaker.py:842-930``) -> float32 ``[nfreq, nm, nel]``."""
+    ew = np.array([x for i, x in enumerate(ew) if i not in exclude_cyl])
+    nlocal = len(freq)
+    dec = np.arcsin(el[np.newaxis, :]) + np.radians(latitude)
+    lmbda = scipy.constants.c / (np.asarray(freq)[:, np.newaxis] * 1e6)
+    ews = np.abs(ew)[np.argsort(np.abs(ew))]
+    max_ew = ews[-1] + 0.5 * (ews[-1] - ews[-2])
+    min_ew = 0.5 * ews[ews > 0.0][0] if np.min(ews) > 0.0 else -max_ew
+    center = 0.5 * (min_ew + max_ew)
+    width = window_size * (max_ew - min_ew)
+    ew_to_m = 2.0 * np.pi * np.abs(np.cos(dec)) / lmbda
+    min_m = ew_to_m * (center - 0.5 * width)
+    max_m = ew_to_m * (center + 0.5 * width)
+    if window_scaled:
+        min_m = np.max(min_m, axis=0, keepdims=True)
+        max_m = np.min(max_m, axis=0, keepdims=True)
+    nf, nel = min_m.shape
+    window = np.zeros((nf, m.size, nel), dtype=np.float32)
+    for ff in range(nf):
+        for ee in range(nel):
+            lo, hi = min_m[ff, ee], max_m[ff, ee]
+            in_range = np.flatnonzero((m >= lo) & (m <= hi))
+            if in_range.size > 0:
+                x = (m[in_range] - lo) / (hi - lo)
+                window[ff, in_range, ee] = window_generalised(x, window=window_type)
+    if window_scaled:
+        window = np.repeat(window, nlocal, axis=0)
+    return window
+
+
+def ew_weight(kind, weight_ew, inv_var, exclude_cyl):
+    """``_get_weight`` of the two makers (``ringmapmaker.py:1096-1118, 1178-1183``); may modify ``inv_var``."""
+    if kind == "wiener":
+        w = inv_var
+        for cyl in exclude_cyl:
+            w[..., cyl, :] = 0.0
+        return w
+    if weight_ew == "inverse_variance":
+        w = inv_var
+    else:
+        n_ew = inv_var.shape[-2]
+        w = np.ones(n_ew) if weight_ew == "uniform" else n_ew - np.arange(n_ew)
+        expand = [None] * inv_var.ndim
+        expand[-2] = slice(None)
+        w = w[tuple(expand)]
+    for cyl in exclude_cyl:
+        w[..., cyl, :] = 0.0
+    return w * invert_no_zero(np.sum(w, axis=-2, keepdims=True))
+
+
+def regularisation(kind, freq, m, inv_SN=1e-6, gal_amp=1.41, gal_alpha=-1.75, gal_beta=-0.75, psrc_amp=0.045, psrc_alpha=-1.0, pivot=600.0):
+    """``_get_regularisation`` (``ringmapmaker.py:1120-1121, 1161-1176``)."""
+    if kind == "tikhonov":
+        return inv_SN
+    gal = gal_amp * (freq / pivot) ** gal_alpha * np.where(m > 0.0, m, 1.0) ** gal_beta
+    psrc = psrc_amp * (freq / pivot) ** psrc_alpha
+    spectrum = gal**2 + psrc**2
+    return invert_no_zero(spectrum[:, np.newaxis, np.newaxis])
+
+
+def deconvolve(kind, hv, hw, bv, freq, el, ew, oddra, exclude_cyl=(), skip_deconvolution=False, window=None, weight_ew="natural", iref=None, **reg):
+    """The per-frequency loop of ``DeconvolveHybridMBase.process`` (``ringmapmaker.py:683-823``).
+
+    ``window``: None (``window_type == "none"``) or float32 ``[nfreq, nm, nel]`` from :func:`get_window`.
+    """
+    nm, _, npol, nfreq, new, nel = hv.shape
+    mmax = nm - 1
+    m = np.arange(nm)
+    nra = 2 * mmax + int(oddra)
+    bv = bv[: mmax + 1]
+    rmm = np.zeros((1, npol, nfreq, nra, nel))
+    rmw = np.zeros((npol, nfreq, nra, nel))
+    rmbp = np.zeros((1, npol, nfreq, nel))
+    rmb = np.zeros((1, npol, nfreq, nra, nel))
+    if window is not None:
+        window = window[:, :, np.newaxis, :]
+    else:
+        window = np.ones(nfreq, dtype=np.float32)
+    if skip_deconvolution and iref is None:
+        iref = np.argmin(np.abs(el))
+    for lfi, f in enumerate(freq):
+        find = (slice(None),) * 3 + (lfi,)
+        hvf, bvf = hv[find], bv[find]
+        winf = window[lfi]
+        inv_var = hw[find][..., np.newaxis].copy()
+        weight = ew_weight(kind, weight_ew, inv_var, exclude_cyl) * (inv_var > 0.0)
+        sum_weight = (weight * np.abs(bvf) ** 2).sum(axis=(1, -2))
+        if not skip_deconvolution:
+            C_inv = regularisation(kind, f, m, **reg) + sum_weight
+        else:
+            C_inv = 1.0
+        map_m = winf * (bvf.conj() * weight * hvf).sum(axis=(1, -2)) * invert_no_zero(C_inv)
+        dirty_beam_m = winf * sum_weight * invert_no_zero(C_inv)
+        norm = invert_no_zero(dirty_beam_m.mean(axis=0))[:, np.newaxis, :]
+        if skip_deconvolution:
+            norm = norm[:, :, iref, np.newaxis]
+        rmm[0, :, lfi] = np.fft.irfft(map_m.transpose(1, 2, 0), axis=-1, n=nra).transpose(0, 2, 1) * norm
+        dirty_beam_ra = np.fft.irfft(dirty_beam_m.transpose(1, 2, 0), axis=-1, n=nra).transpose(0, 2, 1) * norm
+        rmbp[0, :, lfi] = np.sum(dirty_beam_ra**2, axis=1) / nra
+        rmb[0, :, lfi] = dirty_beam_ra
+        var = invert_no_zero(inv_var)
+        sigma = np.sqrt(np.sum((weight * np.abs(bvf)) ** 2 * var, axis=(1, -2)))
+        sum_var_map_m = 0.5 * np.sum((sigma * winf * norm[np.newaxis, :, 0] * invert_no_zero((mmax + 1) * C_inv)) ** 2, axis=0)[:, np.newaxis, :]
+        rmw[:, lfi] = invert_no_zero(sum_var_map_m)
+    return rmm, rmw, rmbp, rmb

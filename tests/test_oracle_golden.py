@@ -145,3 +145,31 @@ def test_mask_mmode(golden_dir):
         auto, mzero, pos, neg, low = (int(x) for x in g[f"c{i}_opts"])
         out = ofl.mask_mmode_weight(g[f"c{i}_w"], ps, bool(auto), bool(mzero), bool(pos), bool(neg), None if low < 0 else low)
         np.testing.assert_array_equal(out, g[f"c{i}_out"])
+
+
+def _ringmap_case(g, i):
+    from oracle import ringmap as orm
+
+    kind = str(g[f"c{i}_kind"])
+    skip, oddra = (bool(x) for x in g[f"c{i}_opts"])
+    excl = [int(x) for x in g[f"c{i}_exclude"]]
+    wtype = str(g[f"c{i}_window"])
+    inv_SN, gal_amp, psrc_amp = (float(x) for x in g[f"c{i}_params"])
+    hv = g[f"c{i}_hv"]
+    window = None
+    if wtype != "none":
+        window = orm.get_window(g["freq"], np.arange(hv.shape[0]), g["el"], g["ew"], float(g["latitude"]), wtype, exclude_cyl=excl)
+    reg = dict(inv_SN=inv_SN) if kind == "tikhonov" else dict(gal_amp=gal_amp, psrc_amp=psrc_amp)
+    return dict(kind=kind, hv=hv, hw=g[f"c{i}_hw"], bv=g[f"c{i}_bv"], freq=g["freq"], el=g["el"], ew=g["ew"], oddra=oddra,
+                exclude_cyl=excl, skip_deconvolution=skip, window=window, weight_ew=str(g[f"c{i}_weight_ew"]), **reg)
+
+
+def test_ringmap_deconvolve(golden_dir):
+    from oracle import ringmap as orm
+
+    g = _load(golden_dir, "ringmap_deconvolve.npz")
+    for i in range(int(g["ncase"])):
+        rmm, rmw, rmbp, rmb = orm.deconvolve(**_ringmap_case(g, i))
+        for got, name in ((rmm, "map"), (rmw, "wgt"), (rmbp, "dbp"), (rmb, "db")):
+            ref = g[f"c{i}_{name}"]
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max(), err_msg=f"case {i} {name}")
