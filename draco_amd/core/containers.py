@@ -259,6 +259,48 @@ class HybridVisMModes(MContainer, _FreqMixin, _VisMixin):
     }
 
 
+class RingMap(ContainerBase, _FreqMixin):
+    """Multi-frequency ring maps: ``map [beam, pol, freq, ra, el]``, ``weight [pol, freq, ra, el]`` float64
+    (``containers.py:1577-1653``); optional ``dirty_beam``, ``dirty_beam_power`` via :meth:`add_dataset`."""
+
+    _axes = ("beam", "pol", "freq", "ra", "el", "ew")
+    _dataset_spec = {
+        "map": {"axes": ["beam", "pol", "freq", "ra", "el"], "dtype": np.float64},
+        "weight": {"axes": ["pol", "freq", "ra", "el"], "dtype": np.float64},
+    }
+    _optional_spec = {
+        "dirty_beam": {"axes": ["beam", "pol", "freq", "ra", "el"], "dtype": np.float64},
+        "dirty_beam_power": {"axes": ["beam", "pol", "freq", "el"], "dtype": np.float64},
+    }
+
+    def __init__(self, ra=None, **kwargs):
+        if isinstance(ra, (int, np.integer)):
+            ra = np.linspace(0.0, 360.0, int(ra), endpoint=False)
+        self._dataset_spec = dict(type(self)._dataset_spec)
+        super().__init__(ra=ra, **kwargs)
+
+    def add_dataset(self, name, allocate=False):
+        self._dataset_spec[name] = self._optional_spec[name]
+        if allocate:
+            self.datasets[name] = Dataset(host=np.zeros(self.dataset_shape(name), dtype=np.float64))
+
+    @property
+    def map(self):
+        return self.datasets["map"]
+
+    @property
+    def weight(self):
+        return self.datasets["weight"]
+
+    @property
+    def dirty_beam(self):
+        return self.datasets["dirty_beam"]
+
+    @property
+    def dirty_beam_power(self):
+        return self.datasets["dirty_beam_power"]
+
+
 class Map(ContainerBase, _FreqMixin):
     """``map [freq, pol, pixel]`` float64, HEALPix RING (``containers.py:470-486``, cora ``Map`` [3P])."""
 

@@ -61,4 +61,6 @@ int dmm_set_error(int code, const char* fmt, ...);
     if (!(cond)) return dmm_set_error(DMM_E_ARG, __VA_ARGS__); \
   } while (0)
 
+int dmm_fft_tables_f64(dmm_ctx* ctx, int n, dmm_fft_tables** out);  // mfft.hip
+
 static inline bool dmm_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }

@@ -367,6 +367,9 @@ bool choose_rb(int M, size_t elem, int64_t nrow, int* RB, int* P, size_t* lds) {
 
 }  // namespace
 
+// internal: double-precision tables (twiddles; chirp + filter for non powers of two) for length n
+int dmm_fft_tables_f64(dmm_ctx* ctx, int n, dmm_fft_tables** out) { return get_tables<double2, double>(ctx->ifft, n, out); }
+
 extern "C" {
 
 int dmm_mfft_pack(dmm_ctx* ctx, const void* ts, int64_t nrow, int nra, void* out, int mmax,

@@ -164,6 +164,27 @@ int dmm_alm2map(dmm_ctx* ctx, const void* alm, int nfreq, int npol, int lmax, in
 int dmm_map2alm(dmm_ctx* ctx, const double* map, int nfreq, int npol, int lmax, int mmax,
                 int nside, int niter, void* alm);
 
+/* ------------------------------------------------ deconvolving ring-map makers
+ * The per-frequency loop of DeconvolveHybridMBase.process (reference ringmapmaker.py:744-823)
+ * with the TikhonovRingMapMaker / WienerRingMapMaker weights (:1096-1118, :1178-1183).
+ *   hv [dev] complex64 [nm, 2, npol, nfreq, new, nel]   HybridVisMModes.vis
+ *   hw [dev] float32   [nm, 2, npol, nfreq, new]        HybridVisMModes.weight (inverse variance)
+ *   bv [dev] complex64 [nm_beam >= nm, 2, npol, nfreq, new, nel]  beam m-modes (rows >= nm ignored)
+ *   weight_mode 0: w = ew_table[ew] * (hw > 0)   ("natural" / "uniform", table already normalised,
+ *                                                 excluded cylinders zero)
+ *               1: w = hw*keep / sum_ew(hw*keep)  (Tikhonov "inverse_variance"; ew_table = keep mask)
+ *               2: w = hw*keep                    (Wiener; ew_table = keep mask)
+ *   eps    [dev] double [nfreq, nm]  regularisation (ignored if skip_deconvolution)
+ *   window [dev] float32 [nfreq, nm, nel] or NULL
+ *   nra = 2*(nm-1) (+1 if oddra); outputs float64:
+ *   map [1, npol, nfreq, nra, nel], weight [npol, nfreq, nra, nel],
+ *   dirty_beam_power [1, npol, nfreq, nel], dirty_beam [1, npol, nfreq, nra, nel] or NULL.     */
+int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npol, int nfreq, int new_, int nel,
+                           int nra, int weight_mode, int skip_deconvolution, int iref, const void* hv,
+                           const float* hw, const void* bv, const double* ew_table, const double* eps,
+                           const float* window, double* map, double* weight, double* dirty_beam_power,
+                           double* dirty_beam);
+
 /* ------------------------------------------------ synthetic beam-transfer tiles
  * Fill tiles with the counter-hash generator shared with oracle/synth.py
  * (bit-identical in float64): value(seed, m, f, row, pol, l) with l<m -> 0.

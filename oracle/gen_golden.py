@@ -519,7 +519,8 @@ def gen_ringmap(out):
         ("tikhonov", dict(weight_ew="inverse_variance", inv_SN=1e-3), dict(exclude_cyl=[1], skip=False, window="hann", oddra=False)),
         ("tikhonov", dict(weight_ew="natural", inv_SN=1e-3), dict(exclude_cyl=[], skip=True, window="none", oddra=False)),
         ("wiener", dict(), dict(exclude_cyl=[], skip=False, window="none", oddra=False)),
-        ("wiener", dict(gal_amp=2.0, psrc_amp=0.1), dict(exclude_cyl=[0], skip=False, window="blackman_harris", oddra=True)),
+        ("wiener", dict(gal_amp=2.0, psrc_amp=0.1), dict(exclude_cyl=[0], skip=False, window="blackman_harris", oddra=True)),  # window is zero at every m <= 8: all-zero outputs
+        ("wiener", dict(gal_amp=2.0, psrc_amp=0.1), dict(exclude_cyl=[2], skip=False, window="blackman_harris", oddra=True)),
     ]
     for kind, attrs, base in configs:
         hv = crandn(rng, (nm, 2, npol, nfreq, new, nel), np.complex64)
