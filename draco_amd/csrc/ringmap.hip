@@ -12,8 +12,9 @@
 // (pol, freq, el):
 //   k_rm_reduce  lanes across el (coalesced 512-byte row pieces of hv / bv), the (+/-, ew)
 //                sums in registers, results transposed through LDS to rows contiguous in m;
-//   k_rm_norm    mean over m of the dirty-beam modes -> point-source normalisation;
-//   k_rm_fft     RB rows per block in LDS; the Hermitian spectra of the (complex) map modes
+//   k_rm_fft     RB rows per block in LDS; the point-source normalisation 1/mean_m(dirty_m) is formed
+//                from the row at hand (k_rm_norm supplies the reference-elevation one if the
+//                deconvolution is skipped); the Hermitian spectra of the (complex) map modes
 //                and of the (real) dirty-beam modes are packed into ONE complex sequence
 //                z = X_map + i X_dirty, so a single inverse FFT yields both real outputs;
 //                powers of two run the in-LDS radix passes, other lengths Bluestein
@@ -63,13 +64,20 @@ __global__ __launch_bounds__(kThreads) void k_rm_reduce(RmParams p) {
     const int m = m0 + mi;
     double sw = 0.0, mre = 0.0, mim = 0.0, sg = 0.0;
     if (m < p.nm && el < p.nel) {
+#pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int64_t wbase = ((((int64_t)m * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_;
         double wsum = 0.0;
         if (p.mode == 1)
           for (int e = 0; e < p.new_; ++e) wsum += (double)p.hw[wbase + e] * p.wt[e];
         const double wnorm = wsum != 0.0 ? 1.0 / wsum : 0.0;
+        const float2* hrow = p.hv + wbase * p.nel + el;
+        const float2* brow = p.bv + wbase * p.nel + el;  // same [m, s, pol, f, ew] prefix: the beam only has more m rows
+#pragma unroll 4
         for (int e = 0; e < p.new_; ++e) {
+          // loads are unconditional (no branch on the weight): the compiler batches them
+          const float2 h = hrow[(int64_t)e * p.nel];
+          const float2 b = brow[(int64_t)e * p.nel];
           double iv = (double)p.hw[wbase + e];
           double w;
           if (p.mode == 0) {
@@ -79,16 +87,13 @@ __global__ __launch_bounds__(kThreads) void k_rm_reduce(RmParams p) {
             w = p.mode == 1 ? iv * wnorm : iv;
             if (!(iv > 0.0)) w = 0.0;
           }
-          if (w == 0.0) continue;
-          const float2 h = p.hv[(wbase + e) * p.nel + el];
-          const int64_t bbase = ((((int64_t)m * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_ + e;
-          const float2 b = p.bv[bbase * p.nel + el];
+          const double var = iv > 0.0 ? 1.0 / iv : 0.0;
           const double br = b.x, bi = b.y, hr = h.x, hi = h.y;
           const double b2 = br * br + bi * bi;
-          sw += w * b2;
-          mre += w * (br * hr + bi * hi);  // conj(b) * h
-          mim += w * (br * hi - bi * hr);
-          sg += w * w * b2 / iv;
+          sw = fma(w, b2, sw);
+          mre = fma(w, br * hr + bi * hi, mre);  // conj(b) * h
+          mim = fma(w, br * hi - bi * hr, mim);
+          sg = fma(w * w * b2, var, sg);
         }
       }
     }
@@ -110,14 +115,17 @@ __global__ __launch_bounds__(kThreads) void k_rm_reduce(RmParams p) {
   }
 }
 
-__global__ void k_rm_norm(RmParams p) {  // norm[pf][el] = inz(mean_m dirty_m)
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)p.npol * p.nfreq * p.nel) return;
-  const double4* row = p.s1 + i * p.nm;
+// skip_deconvolution only: norm[pf][iref] = inz(mean_m dirty_m) at the reference elevation; one wave per (pol, freq)
+__global__ void k_rm_norm(RmParams p) {
+  const int pf = blockIdx.x;
+  const double4* row = p.s1 + ((int64_t)pf * p.nel + p.iref) * p.nm;
   double acc = 0.0;
-  for (int m = 0; m < p.nm; ++m) acc += row[m].z;
-  const double mean = acc / (double)p.nm;
-  p.norm[i] = mean != 0.0 ? 1.0 / mean : 0.0;
+  for (int m = threadIdx.x; m < p.nm; m += 64) acc += row[m].z;
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (threadIdx.x == 0) {
+    const double mean = acc / (double)p.nm;
+    p.norm[(int64_t)pf * p.nel + p.iref] = mean != 0.0 ? 1.0 / mean : 0.0;
+  }
 }
 
 struct RmFft {
@@ -190,8 +198,24 @@ __global__ __launch_bounds__(kThreads) void k_rm_fft(RmParams p, RmFft q) {
     const int64_t row = r0 + r;
     if (row >= nrow) break;  // uniform
     const int64_t pf = row / p.nel;
-    const int el = (int)(row - pf * p.nel);
-    const double nrm = p.norm[pf * p.nel + (p.skip ? p.iref : el)];
+    (void)0;
+    const double4* srow = p.s1 + row * p.nm;
+    double nrm;
+    if (p.skip) {
+      nrm = p.norm[pf * p.nel + p.iref];  // normalised at the reference declination (k_rm_norm)
+    } else {  // 1 / mean_m(dirty_m) of this row
+      double dsum = 0.0;
+      for (int m = threadIdx.x; m < p.nm; m += kThreads) dsum += srow[m].z;
+      red[threadIdx.x] = dsum;
+      __syncthreads();
+      for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+      }
+      const double mean = red[0] / (double)p.nm;
+      nrm = mean != 0.0 ? 1.0 / mean : 0.0;
+      __syncthreads();
+    }
     const double sc = nrm / (double)N;
     double pw = 0.0;
     for (int n = threadIdx.x; n < N; n += kThreads) {
@@ -204,7 +228,6 @@ __global__ __launch_bounds__(kThreads) void k_rm_fft(RmParams p, RmFft q) {
     }
     // variance sum over m (q column of s1) rides the same reduction
     double vs = 0.0;
-    const double4* srow = p.s1 + row * p.nm;
     for (int m = threadIdx.x; m < p.nm; m += kThreads) {
       const double t = srow[m].w * nrm;
       vs += t * t;
@@ -341,7 +364,7 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   p.db = dirty_beam;
 
   hipLaunchKernelGGL(k_rm_reduce, dim3((nel + 63) / 64, (nm + MT - 1) / MT, npol * nfreq), dim3(kThreads), 0, ctx->stream, p);
-  hipLaunchKernelGGL(k_rm_norm, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, ctx->stream, p);
+  if (skip_deconvolution) hipLaunchKernelGGL(k_rm_norm, dim3(npol * nfreq), dim3(64), 0, ctx->stream, p);
   DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_rm_fft, dim3((unsigned)((nrow + rb - 1) / rb)), dim3(kThreads), lds, ctx->stream, p, q);
   hipLaunchKernelGGL(k_rm_store, dim3((nra + 31) / 32, (nel + 31) / 32, npol * nfreq), dim3(kThreads), 0, ctx->stream, p);
