@@ -86,6 +86,8 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   DMM_REQUIRE(c != nullptr && name != nullptr, "dmm_ctx_set_option: NULL argument");
   if (!strcmp(name, "dirty_variant")) c->opt_dirty_variant = (int)value;
   else if (!strcmp(name, "grid_mult")) c->opt_grid_mult = (int)value;
+  else if (!strcmp(name, "project_grid_mult")) c->opt_project_grid_mult = (int)value;
+  else if (!strcmp(name, "project_variant")) c->opt_project_variant = (int)value;
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_set_option: unknown option '%s'", name);
   return DMM_OK;
 }

@@ -26,6 +26,8 @@ struct dmm_ctx {
   std::map<int64_t, void*> sht;            // SHT geometry caches keyed by (nside,lmax,mmax)
   int opt_dirty_variant = 0;               // tuning knobs, see dmm_ctx_set_option
   int opt_grid_mult = 0;
+  int opt_project_grid_mult = 0;
+  int opt_project_variant = 0;
   void* scratch = nullptr;                 // grow-only workspace (ring coefficients, Gram matrices ...)
   size_t scratch_bytes = 0;
 };

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
 
 // v[i] = sum_{pol,l} B[i, pol, l] * a[pol, l]: one wave per row, lanes across the
 // contiguous row (coalesced), shuffle reduction; a (<= 64 KB) staged in LDS per block.
-template <typename BT>
+template <typename BT, bool NT = false, int UNR = 4>
 __global__ __launch_bounds__(kThreads) void k_project(SolveParams p, const BT* __restrict__ B,
                                                       const double2* __restrict__ alm,
                                                       double2* __restrict__ vis) {
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(kThreads) void k_project(SolveParams p, const BT* _
       for (int pol = 0; pol < p.npol; ++pol) {
         const BT* seg = row + (int64_t)pol * pol_stride;
         const double2* as = a + pol * L;
-#pragma unroll 4
+#pragma unroll UNR
         for (int lrel = lane; lrel < L; lrel += 64) {
           double br, bi;
-          load_b<BT>(seg + lrel, br, bi);
+          load_b<BT, NT>(seg + lrel, br, bi);
           const double2 av = as[lrel];
           sre = fma(br, av.x, fma(-bi, av.y, sre));
           sim = fma(br, av.y, fma(bi, av.x, sim));
@@ -415,14 +415,24 @@ int dmm_project_run(dmm_plan* pl, const void* B, const void* alm_in, void* vis_o
   const size_t lds = (size_t)p.npol * (p.lmax + 1) * sizeof(double2);
   if (lds > 160 * 1024)
     return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_project_run: nsky=%d too large for the LDS stage", p.npol * (p.lmax + 1));
-  int64_t grid = (int64_t)ctx->num_cu * 8;
+  int64_t grid = (int64_t)ctx->num_cu * (ctx->opt_project_grid_mult > 0 ? ctx->opt_project_grid_mult : 16);
   if (grid > p.nwork) grid = p.nwork;
   if (pl->b_dtype == DMM_C128) {
-    auto k = k_project<double2>;
-    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B, (const double2*)alm_in, (double2*)vis_out);
+#define DMM_LAUNCH_PROJECT(KERN)                                                                              \
+  do {                                                                                                        \
+    auto k = KERN;                                                                                            \
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B,       \
+                       (const double2*)alm_in, (double2*)vis_out);                                            \
+  } while (0)
+    switch (ctx->opt_project_variant) {  // tools/project_timing.py: NT loads, 4 row pieces in flight win (6.07 vs 5.73 TB/s)
+      case 1: DMM_LAUNCH_PROJECT((k_project<double2, false, 4>)); break;
+      case 2: DMM_LAUNCH_PROJECT((k_project<double2, false, 8>)); break;
+      case 3: DMM_LAUNCH_PROJECT((k_project<double2, true, 8>)); break;
+      default: DMM_LAUNCH_PROJECT((k_project<double2, true, 4>)); break;
+    }
   } else {
-    auto k = k_project<float2>;
+    auto k = k_project<float2, true, 4>;
     DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, (const double2*)alm_in, (double2*)vis_out);
   }
