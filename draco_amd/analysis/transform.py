@@ -228,3 +228,120 @@ class MModeInverseTransform(ContainerTask):
         w0 = (mweight[0, 0] * (wfac / nra)).to(torch.float32)
         sstream.attach("vis_weight", w0.unsqueeze(-1).expand(*w0.shape, nra).contiguous())
         return sstream
+
+
+def _cmap(i, j, n):
+    if i > j:
+        i, j = j, i
+    return (n * (n + 1) // 2) - ((n - i) * (n - i + 1) // 2) + (j - i)
+
+
+def _find_inputs(input_index, inputs, require_match=False):
+    """``tools.find_inputs`` (``util/tools.py:130-169``): match on ``correlator_input`` or ``chan_id``."""
+    names = input_index.dtype.names or ()
+    field = "correlator_input" if "correlator_input" in names else ("chan_id" if "chan_id" in names else None)
+    if field is None:
+        raise ValueError("`input_index` must have either a `chan_id` or `correlator_input` field.")
+    if field not in (inputs.dtype.names or ()):
+        raise ValueError(f"`inputs` array does not have a `{field!s}` field.")
+    return tools.find_keys(input_index[field], inputs[field], require_match=require_match)
+
+
+class TelescopeStreamMixIn:
+    """Pre-computes the telescope's prod / stack / reverse-stack index maps (``transform.py:91-139``)."""
+
+    def setup(self, tel):
+        self.telescope = tel = io.get_telescope(tel)
+        n = tel.nfeed
+        self.bt_stack = np.array(
+            [(_cmap(a, b, n), 0) if a <= b else (_cmap(b, a, n), 1) for a, b in tel.uniquepairs],
+            dtype=[("prod", "<u4"), ("conjugate", "u1")],
+        )
+        triu = np.triu_indices(n)
+        self.bt_prod = np.zeros(len(triu[0]), dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        self.bt_prod["input_a"], self.bt_prod["input_b"] = triu
+        fm = np.asarray(tel.feedmask)[triu]
+        self.bt_rev = np.empty(fm.size, dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        self.bt_rev["stack"] = np.where(fm, np.asarray(tel.feedmap)[triu], tel.npairs)
+        self.bt_rev["conjugate"] = np.where(fm, np.asarray(tel.feedconj)[triu], 0)
+
+
+class CollateProducts(TelescopeStreamMixIn, ContainerTask):
+    """Extract, order and stack the correlation products for map-making (``transform.py:142-330``).
+
+    The input may hold more inputs and frequencies than the telescope; the converse raises
+    ``ValueError`` like the reference.  Inputs that are ALREADY redundancy-stacked are not supported
+    yet (the reference re-derives their representative products, ``transform.py:206-221``).
+
+    Attributes
+    ----------
+    weight : {"natural", "uniform", "inverse_variance"}
+        How to weight the redundant baselines when stacking.
+    """
+
+    weight = "natural"
+    _config_names = ("weight",)
+
+    def process(self, ss):
+        tel = self.telescope
+        ss_input = np.asarray(ss.index_map["input"])
+        input_ind = _find_inputs(tel.input_index, ss_input, require_match=False)
+        rev_input_ind = _find_inputs(ss_input, tel.input_index, require_match=True)
+        freq_ind = tools.find_keys(list(ss.index_map["freq"]["centre"]), list(tel.frequencies), require_match=True)
+        bt_freq = ss.index_map["freq"][freq_ind]
+        if getattr(ss, "is_stacked", False):
+            raise NotImplementedError("CollateProducts on an already stacked stream is not built yet")
+        ss_prod = np.asarray(ss.index_map["prod"])
+        if self.weight not in ("natural", "uniform", "inverse_variance"):
+            raise ValueError(f"unknown weight {self.weight!r}")
+
+        sp = type(ss)(freq=bt_freq, ra=np.asarray(ss.index_map["ra"]), input=tel.input_index, prod=self.bt_prod, stack=self.bt_stack,
+                      reverse_map_stack=self.bt_rev, attrs_from=ss, comm=ss.comm, allocate=False)
+        ctx = Context.get()
+        ssv = _dev_dataset(ss.vis, ctx, np.complex64)
+        ssw = _dev_dataset(ss.weight, ctx, np.float32)
+        nf_in, nprod_in, nt = ssv.shape
+
+        # invert the reference's product loop (transform.py:277-320) into output-major lists
+        lists = [[] for _ in range(tel.npairs)]
+        for ss_pi, (ii, ij) in enumerate(zip(ss_prod["input_a"], ss_prod["input_b"])):
+            bi, bj = input_ind[ii], input_ind[ij]
+            if bi is None or bj is None:
+                continue
+            sp_pi = int(tel.feedmap[bi, bj])
+            if sp_pi < 0:
+                continue
+            lists[sp_pi].append((ss_pi, bool(tel.feedconj[bi, bj])))  # file products are not conjugated (unstacked)
+        ptr_ = np.zeros(tel.npairs + 1, dtype=np.int32)
+        ptr_[1:] = np.cumsum([len(x) for x in lists])
+        src = np.array([p for x in lists for p, _ in x], dtype=np.int32)
+        cj = np.array([c for x in lists for _, c in x], dtype=np.uint8)
+
+        flags = None
+        if "input_flags" in ss.datasets:
+            flags = np.asarray(ss.input_flags[:], dtype=np.float32)
+        red_d = None
+        if self.weight != "inverse_variance":
+            fl = flags if flags is not None and np.any(flags) else np.ones((len(ss_input), nt), np.float32)
+            red = fl[ss_prod["input_a"].astype(int)] * fl[ss_prod["input_b"].astype(int)]  # one product per "stack" entry
+            if self.weight == "uniform":
+                red = (red > 0).astype(np.float32)
+            red_d = ctx.to_device(np.ascontiguousarray(red, dtype=np.float32))
+        out_v = ctx.empty((len(freq_ind), tel.npairs, nt), np.complex64)
+        out_w = ctx.empty((len(freq_ind), tel.npairs, nt), np.float32)
+        d = lambda a: ctx.to_device(a) if a.size else ctx.to_device(np.zeros(1, a.dtype))  # noqa: E731
+        # keep the index tensors referenced until the launch is enqueued (a temporary would be recycled at once)
+        find_d, ptr_d, src_d, cj_d = d(np.asarray(freq_ind, dtype=np.int32)), d(ptr_), d(src), d(cj)
+        _lib.check(
+            _lib.lib.dmm_collate_products(
+                ctx.handle, ptr(ssv), ptr(ssw), int(nf_in), int(nprod_in), int(nt), len(freq_ind), ptr(find_d),
+                int(tel.npairs), ptr(ptr_d), ptr(src_d), ptr(cj_d), ptr(red_d), ptr(out_v), ptr(out_w),
+            )
+        )
+        ctx.sync()  # the small index tensors go out of scope below
+        sp.attach("vis", out_v)
+        sp.attach("vis_weight", out_w)
+        if flags is not None:
+            sp.add_dataset("input_flags", allocate=True)
+            sp.input_flags[:] = flags[rev_input_ind, :]
+        return sp

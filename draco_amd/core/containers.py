@@ -185,6 +185,22 @@ class SiderealStream(ContainerBase, _FreqMixin, _VisMixin):
         "vis": {"axes": ["freq", "stack", "ra"], "dtype": np.complex64},
         "vis_weight": {"axes": ["freq", "stack", "ra"], "dtype": np.float32},
     }
+    _optional_spec = {"input_flags": {"axes": ["input", "ra"], "dtype": np.float32}}  # containers.py:525-530
+
+    def add_dataset(self, name, allocate=True):
+        self._dataset_spec = dict(self._dataset_spec)
+        self._dataset_spec[name] = self._optional_spec[name]
+        if allocate:
+            self.datasets[name] = Dataset(host=np.zeros(self.dataset_shape(name), dtype=self._optional_spec[name]["dtype"]))
+
+    @property
+    def input_flags(self):
+        return self.datasets["input_flags"]
+
+    @property
+    def is_stacked(self):
+        st = self.index_map.get("stack")
+        return st is not None and st.dtype.names is not None and "prod" in st.dtype.names and len(st) != len(self.index_map.get("prod", st))
 
     def __init__(self, ra=None, stack=None, prod=None, input=None, reverse_map_stack=None, **kwargs):
         if isinstance(ra, (int, np.integer)):

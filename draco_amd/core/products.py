@@ -74,7 +74,7 @@ class TransitTelescope:
         self.num_pol_sky = int(num_pol_sky)
         self.ncyl, self.nfeed_cyl, self.npol_feed = int(ncyl), int(nfeed_cyl), int(npol_feed)
         self.nfeed = self.ncyl * self.nfeed_cyl * self.npol_feed
-        self.input_index = np.arange(self.nfeed)
+        self.input_index = np.array([(i, i) for i in range(self.nfeed)], dtype=[("chan_id", "<u2"), ("correlator_input", "<u2")])
         self._build_pairs()
         if npairs is not None and int(npairs) != self.npairs:
             # free-form pair count (tests): treat every pair as unique, no stacking information
@@ -112,6 +112,15 @@ class TransitTelescope:
             for pidx, conj in groups[k]:
                 rev[pidx] = (s, conj)
         self.reverse_map_stack = rev
+        # pair -> unique baseline maps in driftscan's shape [3P]: feedmap[i, j] = stack index (-1: not
+        # measured), feedconj[i, j] = the pair is the conjugate of the stack's representative
+        self.feedmap = np.full((n, n), -1, dtype=np.int64)
+        self.feedconj = np.zeros((n, n), dtype=bool)
+        for pidx, (i, j) in enumerate(prod):
+            s_, c_ = int(rev[pidx]["stack"]), bool(rev[pidx]["conjugate"])
+            self.feedmap[i, j], self.feedconj[i, j] = s_, c_
+            self.feedmap[j, i], self.feedconj[j, i] = s_, (not c_) if i != j else c_
+        self.feedmask = self.feedmap >= 0
         self.nbase = self.npairs
         self.redundancy = np.array([len(groups[k]) for k in keys], dtype=np.float64)
         up = self.index_map_prod[self.index_map_stack["prod"]]

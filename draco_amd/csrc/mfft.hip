@@ -537,3 +537,57 @@ extern "C" int dmm_mask_mmode_weight(dmm_ctx* ctx, double* mweight, int n_m, int
   DMM_HIP(hipGetLastError());
   return DMM_OK;
 }
+
+// ------------------------------------------------------------------ CollateProducts
+// Weighted stacking of correlation products into the telescope's unique baselines
+// (reference draco/analysis/transform.py:277-320).  The reference scatters product by product
+// into the output; here the host inverts the map once (CSR: output baseline -> contributing
+// input products) so every output sample is one thread's deterministic gather, no atomics.
+namespace {
+__global__ void k_collate(const float2* __restrict__ ssv, const float* __restrict__ ssw, int nprod_in, int nt,
+                          int nf_out, const int* __restrict__ freq_ind, int nstack_out,
+                          const int* __restrict__ csr_ptr, const int* __restrict__ csr_src,
+                          const unsigned char* __restrict__ csr_conj, const float* __restrict__ red,
+                          float2* __restrict__ out_vis, float* __restrict__ out_w) {
+  const int64_t total = (int64_t)nf_out * nstack_out * nt;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % nt);
+    const int sp = (int)((i / nt) % nstack_out);
+    const int fo = (int)(i / ((int64_t)nt * nstack_out));
+    const int64_t fbase = (int64_t)freq_ind[fo] * nprod_in;
+    double vr = 0.0, vi = 0.0, var = 0.0, cnt = 0.0;
+    for (int e = csr_ptr[sp]; e < csr_ptr[sp + 1]; ++e) {
+      const int pi = csr_src[e];
+      const int64_t o = (fbase + pi) * nt + t;
+      const double w = (double)ssw[o];
+      const double wss = red ? (w > 0.0 ? (double)red[(int64_t)pi * nt + t] : 0.0) : w;  // transform.py:297-301
+      const float2 v = ssv[o];
+      vr += wss * (double)v.x;
+      vi += wss * (csr_conj[e] ? -(double)v.y : (double)v.y);
+      var += w != 0.0 ? wss * wss / w : 0.0;
+      cnt += wss;
+    }
+    const double ic = cnt != 0.0 ? 1.0 / cnt : 0.0;
+    out_vis[i] = make_float2((float)(vr * ic), (float)(vi * ic));
+    out_w[i] = (float)(var != 0.0 ? cnt * cnt / var : 0.0);
+  }
+}
+}  // namespace
+
+extern "C" int dmm_collate_products(dmm_ctx* ctx, const void* ssv, const float* ssw, int nf_in, int nprod_in, int nt,
+                                    int nf_out, const int* freq_ind, int nstack_out, const int* csr_ptr,
+                                    const int* csr_src, const unsigned char* csr_conj, const float* red,
+                                    void* out_vis, float* out_w) {
+  DMM_REQUIRE(ctx != nullptr, "dmm_collate_products: ctx is NULL");
+  DMM_REQUIRE(nf_in >= 0 && nprod_in >= 0 && nt >= 0 && nf_out >= 0 && nstack_out >= 0, "dmm_collate_products: bad sizes");
+  const int64_t total = (int64_t)nf_out * nstack_out * nt;
+  if (total == 0) return DMM_OK;
+  DMM_REQUIRE(ssv && ssw && freq_ind && csr_ptr && out_vis && out_w, "dmm_collate_products: NULL argument");
+  DMM_HIP(hipSetDevice(ctx->device));
+  int64_t nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(k_collate, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float2*)ssv, ssw, nprod_in, nt, nf_out,
+                     freq_ind, nstack_out, csr_ptr, csr_src, csr_conj, red, (float2*)out_vis, out_w);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}

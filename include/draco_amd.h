@@ -113,6 +113,20 @@ int dmm_mask_mmode_weight(dmm_ctx* ctx, double* mweight, int n_m, int64_t nfreq,
                           const unsigned char* is_auto /*[dev]*/, int m_zero, int positive_m,
                           int negative_m, int mask_low_m);
 
+/* CollateProducts.process, the stacking loop (reference transform.py:277-320): every output
+ * (freq, unique baseline, time) sample is the weighted mean of its contributing input products
+ *   vis = sum wss * (conj?) v / sum wss,  weight = (sum wss)^2 / sum(wss^2 / w)
+ *   wss = w                      if red == NULL  ("inverse_variance")
+ *       = (w > 0) * red[prod, t]  otherwise       ("natural": redundancy; "uniform": 0/1)
+ * ssv [dev] complex64 [nf_in, nprod_in, nt], ssw [dev] float32 same; freq_ind [dev] int [nf_out]
+ * (input frequency of each output frequency); CSR over output baselines: csr_ptr [nstack_out+1],
+ * csr_src / csr_conj [nnz] (input product, conjugate it?); outputs complex64 / float32
+ * [nf_out, nstack_out, nt].                                                             */
+int dmm_collate_products(dmm_ctx* ctx, const void* ssv, const float* ssw, int nf_in, int nprod_in, int nt,
+                         int nf_out, const int* freq_ind, int nstack_out, const int* csr_ptr,
+                         const int* csr_src, const unsigned char* csr_conj, const float* red,
+                         void* out_vis, float* out_w);
+
 /* ------------------------------------------------------ map-maker solves (a5-a8)
  * A plan fixes the batch of (m, f) solves (the double loop at mapmaker.py:79-94)
  * and the shapes; it owns a device copy of the tile table.

@@ -565,6 +565,132 @@ def gen_ringmap(out):
     np.savez_compressed(os.path.join(out, "ringmap_deconvolve.npz"), **cases)
 
 
+class _LA(np.ndarray):
+    @property
+    def local_array(self):
+        return self.view(np.ndarray)
+
+    @property
+    def local_bounds(self):
+        return slice(0, self.shape[-1])
+
+
+class _LDS:
+    def __init__(self, arr):
+        self.arr = arr.view(_LA)
+
+    def __getitem__(self, k):
+        r = self.arr[k]
+        return r.view(_LA) if isinstance(r, np.ndarray) else r
+
+    def __setitem__(self, k, v):
+        self.arr[k] = v
+
+    @property
+    def shape(self):
+        return self.arr.shape
+
+
+class FakeCollateStream(_FakeCont):
+    """SiderealStream duck type for CollateProducts (vis/weight/input_flags, prod/stack maps)."""
+
+    def __init__(self, freq=None, input=None, prod=None, stack=None, reverse_map_stack=None, copy_from=None, distributed=None, comm=None, vis=None, weight=None, input_flags=None):
+        nra = copy_from.vis.shape[-1] if copy_from is not None else vis.shape[-1]
+        self.index_map = {"freq": freq, "input": input, "prod": prod}
+        self.input, self.prod = input, prod
+        self.freq = freq["centre"]
+        self.is_stacked = stack is not None and copy_from is None and len(stack) != len(prod)
+        self.stack = stack
+        self.reverse_map = {"stack": reverse_map_stack}
+        nstack = len(stack) if stack is not None else len(prod)
+        if vis is None:
+            vis = np.zeros((len(freq), nstack, nra), np.complex64)
+            weight = np.zeros((len(freq), nstack, nra), np.float32)
+            input_flags = np.zeros((len(input), nra), np.float32)
+        self.vis, self.weight, self.input_flags = _LDS(vis), _LDS(weight), _LDS(input_flags)
+        self.attrs = {}
+
+
+class _CollateTel:
+    """Telescope attributes CollateProducts reads; the pairing is a regular 1-cylinder grid built here."""
+
+    def __init__(self, nfeed, freqs):
+        self.nfeed = nfeed
+        self.frequencies = np.asarray(freqs, dtype=float)
+        self.input_index = np.array([(100 + i,) for i in range(nfeed)], dtype=[("chan_id", "<u2")])
+        # unique baselines = separations d = j - i >= 0 (all feeds alike); (i, j) with i > j is the conjugate
+        self.uniquepairs = np.array([(0, d) for d in range(nfeed)])
+        self.npairs = nfeed
+        self.feedmap = np.zeros((nfeed, nfeed), dtype=int)
+        self.feedconj = np.zeros((nfeed, nfeed), dtype=bool)
+        self.feedmask = np.ones((nfeed, nfeed), dtype=bool)
+        for i in range(nfeed):
+            for j in range(nfeed):
+                self.feedmap[i, j] = abs(j - i)
+                self.feedconj[i, j] = i > j
+
+
+def gen_collate(transform, out):
+    """CollateProducts.process (transform.py:168-330) on duck-typed streams (unstacked full-triangle input)."""
+    import importlib
+
+    ft = importlib.import_module("draco.util._fast_tools")
+
+    def _calc_redundancy(input_flags, pm, stack_index, nstack, redundancy):
+        for ii in range(pm.shape[0]):
+            ist = stack_index[ii]
+            if 0 <= ist < nstack:
+                redundancy[ist] += input_flags[pm[ii, 0]] * input_flags[pm[ii, 1]]
+
+    transform.tools._calc_redundancy = _calc_redundancy
+    transform.copy_datasets_filter = lambda *a, **k: None
+    transform.io.get_telescope = lambda t: t
+    rng = np.random.default_rng(7007)
+    cases = {}
+    idx = 0
+    nfeed_tel, nra = 4, 6
+    tel_freq = [400.0, 410.0]
+    for weight, extra_feed, perm_freq in (("inverse_variance", False, False), ("natural", False, False), ("uniform", True, True), ("inverse_variance", True, True)):
+        tel = _CollateTel(nfeed_tel, tel_freq)
+        # the file may hold one more input than the telescope and an extra / permuted frequency
+        file_ids = [100 + i for i in range(nfeed_tel)] + ([999] if extra_feed else [])
+        if extra_feed:
+            file_ids = [file_ids[i] for i in (2, 0, 4, 1, 3)]
+        ninp = len(file_ids)
+        inputs = np.array([(c,) for c in file_ids], dtype=[("chan_id", "<u2")])
+        ffreq = [410.0, 405.0, 400.0] if perm_freq else list(tel_freq)
+        fm = np.zeros(len(ffreq), dtype=[("centre", float), ("width", float)])
+        fm["centre"], fm["width"] = ffreq, 10.0
+        prod = np.array([(i, j) for i in range(ninp) for j in range(i, ninp)], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        rev = np.zeros(len(prod), dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        rev["stack"] = np.arange(len(prod))
+        vis = crandn(rng, (len(ffreq), len(prod), nra), np.complex64)
+        w = rng.uniform(0.5, 1.5, vis.shape).astype(np.float32)
+        w[rng.uniform(size=w.shape) < 0.15] = 0.0
+        flags = (rng.uniform(size=(ninp, nra)) > 0.2).astype(np.float32)
+        ss = FakeCollateStream(freq=fm, input=inputs, prod=prod, stack=None, reverse_map_stack=rev, vis=vis.copy(), weight=w.copy(), input_flags=flags.copy())
+        t = transform.CollateProducts.__new__(transform.CollateProducts)
+        t.log = _Log()
+        t.weight = weight
+        transform.TelescopeStreamMixIn.setup(t, tel)
+        sp = t.process(ss)
+        cases[f"c{idx}_weight"] = np.array(weight)
+        cases[f"c{idx}_file_ids"] = np.array(file_ids)
+        cases[f"c{idx}_ffreq"] = np.array(ffreq)
+        cases[f"c{idx}_vis"], cases[f"c{idx}_w"], cases[f"c{idx}_flags"] = vis, w, flags
+        cases[f"c{idx}_out_vis"] = sp.vis.arr.view(np.ndarray)
+        cases[f"c{idx}_out_w"] = sp.weight.arr.view(np.ndarray)
+        cases[f"c{idx}_out_flags"] = sp.input_flags.arr.view(np.ndarray)
+        cases[f"c{idx}_out_stack_prod"] = sp.stack["prod"]
+        cases[f"c{idx}_out_stack_conj"] = sp.stack["conjugate"]
+        cases[f"c{idx}_out_rev_stack"] = sp.reverse_map["stack"]["stack"]
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    cases["nfeed_tel"] = np.int64(nfeed_tel)
+    cases["tel_freq"] = np.array(tel_freq)
+    np.savez_compressed(os.path.join(out, "transform_collate.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -583,6 +709,8 @@ def main():
         gen_mask(GOLDEN)
     if not only or "--only-ringmap" in only:
         gen_ringmap(GOLDEN)
+    if not only or "--only-collate" in only:
+        gen_collate(transform, GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 

@@ -186,3 +186,82 @@ def test_mask_mmode_data_golden(golden_dir):
         out = t.process(mm)
         assert out is mm
         assert np.array_equal(mm.weight[:], g[f"c{i}_out"]), i
+
+
+def test_collate_products_golden(golden_dir):
+    """CollateProducts against the reference's own outputs (unstacked full-triangle inputs, extra feed,
+    permuted/extra frequencies, all three weight schemes)."""
+    import os
+
+    from draco_amd.analysis.transform import CollateProducts
+    from draco_amd.core import containers
+
+    g = np.load(os.path.join(golden_dir, "transform_collate.npz"))
+    nfeed = int(g["nfeed_tel"])
+
+    class Tel:  # the same 1-cylinder pairing the golden generator used
+        pass
+
+    tel = Tel()
+    tel.nfeed, tel.npairs = nfeed, nfeed
+    tel.lmax = tel.mmax = 1
+    tel.frequencies = g["tel_freq"]
+    tel.input_index = np.array([(100 + i,) for i in range(nfeed)], dtype=[("chan_id", "<u2")])
+    tel.uniquepairs = np.array([(0, d) for d in range(nfeed)])
+    idx = np.arange(nfeed)
+    tel.feedmap = np.abs(idx[None, :] - idx[:, None])
+    tel.feedconj = idx[:, None] > idx[None, :]
+    tel.feedmask = np.ones((nfeed, nfeed), bool)
+    for i in range(int(g["ncase"])):
+        ids = g[f"c{i}_file_ids"]
+        ninp = len(ids)
+        inputs = np.array([(c,) for c in ids], dtype=[("chan_id", "<u2")])
+        prod = np.array([(a, b) for a in range(ninp) for b in range(a, ninp)], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        fm = np.zeros(len(g[f"c{i}_ffreq"]), dtype=[("centre", float), ("width", float)])
+        fm["centre"], fm["width"] = g[f"c{i}_ffreq"], 10.0
+        vis = g[f"c{i}_vis"]
+        ss = containers.SiderealStream(freq=fm, ra=vis.shape[-1], input=inputs, prod=prod, stack=len(prod))
+        ss.vis[:] = vis
+        ss.weight[:] = g[f"c{i}_w"]
+        ss.add_dataset("input_flags")
+        ss.input_flags[:] = g[f"c{i}_flags"]
+        t = CollateProducts(weight=str(g[f"c{i}_weight"]))
+        t.setup(tel)
+        sp = t.process(ss)
+        assert isinstance(sp, containers.SiderealStream)
+        np.testing.assert_allclose(sp.vis[:], g[f"c{i}_out_vis"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(sp.weight[:], g[f"c{i}_out_w"], rtol=2e-6)
+        assert np.array_equal(sp.input_flags[:], g[f"c{i}_out_flags"])
+        assert np.array_equal(sp.index_map["stack"]["prod"], g[f"c{i}_out_stack_prod"])
+        assert np.array_equal(sp.reverse_map["stack"]["stack"], g[f"c{i}_out_rev_stack"])
+        assert np.array_equal(sp.index_map["freq"]["centre"], g["tel_freq"])
+    # the telescope needs every one of its frequencies in the file
+    tel.frequencies = np.array([400.0, 123.0])
+    t.setup(tel)
+    with pytest.raises(ValueError, match="Could not find all of the keys"):
+        t.process(ss)
+
+
+def test_collate_with_package_telescope_feeds_mapmaker():
+    """Full-triangle stream of the package's own telescope -> CollateProducts -> stacked stream of npairs baselines."""
+    from draco_amd.analysis.transform import CollateProducts
+    from draco_amd.core import containers
+    from draco_amd.core.products import TransitTelescope
+
+    tel = TransitTelescope(np.array([400.0, 410.0]), lmax=4, ncyl=2, nfeed_cyl=2)
+    rng = np.random.default_rng(1)
+    nprod = len(tel.index_map_prod)
+    true = rng.standard_normal((2, tel.npairs, 5)) + 1j * rng.standard_normal((2, tel.npairs, 5))
+    # every product carries its stack's value (conjugated where the map says so): stacking must give it back
+    rev = tel.reverse_map_stack
+    vis = np.where(rev["conjugate"][None, :, None].astype(bool), true[:, rev["stack"]].conj(), true[:, rev["stack"]]).astype(np.complex64)
+    ss = containers.SiderealStream(freq=tel.frequencies, ra=5, input=tel.input_index, prod=tel.index_map_prod, stack=nprod)
+    ss.vis[:] = vis
+    ss.weight[:] = 1.0
+    t = CollateProducts(weight="natural")
+    t.setup(tel)
+    sp = t.process(ss)
+    assert sp.vis.shape == (2, tel.npairs, 5)
+    assert _rel(sp.vis[:], true.astype(np.complex64)) < 1e-6
+    # weight = (sum w)^2 / sum(w^2 / 1) = redundancy for unit weights
+    np.testing.assert_allclose(sp.weight[:][0, :, 0], tel.redundancy, rtol=1e-6)

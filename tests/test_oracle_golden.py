@@ -173,3 +173,25 @@ def test_ringmap_deconvolve(golden_dir):
         for got, name in ((rmm, "map"), (rmw, "wgt"), (rmbp, "dbp"), (rmb, "db")):
             ref = g[f"c{i}_{name}"]
             np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max(), err_msg=f"case {i} {name}")
+
+
+def _collate_tel(nfeed):
+    feedmap = np.abs(np.arange(nfeed)[None, :] - np.arange(nfeed)[:, None])
+    feedconj = np.arange(nfeed)[:, None] > np.arange(nfeed)[None, :]
+    return feedmap, feedconj
+
+
+def test_collate_products(golden_dir):
+    from oracle import collate as oc
+
+    g = _load(golden_dir, "transform_collate.npz")
+    nfeed = int(g["nfeed_tel"])
+    feedmap, feedconj = _collate_tel(nfeed)
+    for i in range(int(g["ncase"])):
+        ids = g[f"c{i}_file_ids"]
+        ninp = len(ids)
+        prod = np.array([(a, b) for a in range(ninp) for b in range(a, ninp)], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        v, w, fl = oc.collate(g[f"c{i}_vis"], g[f"c{i}_w"], g[f"c{i}_flags"], ids, g[f"c{i}_ffreq"], prod, 100 + np.arange(nfeed), g["tel_freq"], feedmap, feedconj, str(g[f"c{i}_weight"]))
+        np.testing.assert_allclose(v, g[f"c{i}_out_vis"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(w, g[f"c{i}_out_w"], rtol=1e-6)
+        np.testing.assert_array_equal(fl, g[f"c{i}_out_flags"])
