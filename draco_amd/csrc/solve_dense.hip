@@ -460,6 +460,7 @@ struct BjParams {
   int nb;           // number of 32-blocks
   int target;       // k_bj_apply: 0 = A columns, 1 = V columns, 2 = A rows
   int inner_sweeps; // cap on the in-LDS Jacobi sweeps per visit (W stays exactly unitary either way)
+  int* any_rot;     // device word: set when any pair of the sweep still needed a rotation
 };
 
 __global__ __launch_bounds__(kThreads) void k_bj_init(BjParams bp) {  // V = I, scale = max diag
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
   __shared__ double rc[M / 2];
   __shared__ double2 rs[M / 2];
   __shared__ int pa[M / 2], pb[M / 2];
-  __shared__ int any_rot, need;
+  __shared__ int any_rot, need, work;
   const DenseParams& p = bp.d;
   const int pr = blockIdx.x, mat = blockIdx.y, n = p.Np;
   int P, Q;
@@ -508,24 +509,31 @@ __global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
   // re-inject O(eps * sqrt(n)) noise, a tighter test would never settle); the eigenvalue cut of the
   // ML filter sits at 1e-6 of the scale, eight digits above this
   const double tol2 = 1e-28 * scale * scale;
-  if (threadIdx.x == 0) need = 0;
+  if (threadIdx.x == 0) need = work = 0;
   __syncthreads();
-  int my_need = 0;
+  int my_need = 0, my_work = 0;
   for (int idx = threadIdx.x; idx < M * M; idx += kThreads) {
     const int i = idx / M, j = idx % M;
     const int gi = i < JB ? P0 + i : Q0 + i - JB, gj = j < JB ? P0 + j : Q0 + j - JB;
     const double2 v = A[(int64_t)gi * n + gj];
     s[i][j] = v;
     w[i][j] = make_double2(i == j ? 1.0 : 0.0, 0.0);
-    if (i != j && v.x * v.x + v.y * v.y > tol2) my_need = 1;
+    const double a2 = v.x * v.x + v.y * v.y;
+    if (i != j && a2 > tol2) my_need = 1;
+    // the sweep loop on the host stops once no pair holds an off-diagonal above 1e-11 of the scale
+    // (eigenvalues then carry errors ~ delta^2 / gap); elements between 1e-14 and 1e-11 are still
+    // rotated here but are at the level the MFMA block updates re-inject, so they never all vanish
+    if (i != j && a2 > tol2 * 1e6) my_work = 1;
   }
   if (my_need) need = 1;
+  if (my_work) work = 1;
   __syncthreads();
   int* flag = bp.flag + (int64_t)mat * (bp.nb / 2) + pr;
   if (!need) {  // already diagonal to working precision: nothing to rotate
     if (threadIdx.x == 0) *flag = 0;
     return;
   }
+  if (threadIdx.x == 0 && work) *bp.any_rot = 1;  // benign race: every writer stores 1
   for (int sweep = 0; sweep < bp.inner_sweeps; ++sweep) {
     if (threadIdx.x == 0) any_rot = 0;
     __syncthreads();
@@ -765,7 +773,7 @@ Layout layout_of(const dmm_plan* pl, bool ml) {
   const size_t a = (size_t)L.Np * L.Np * sizeof(double2);
   const size_t aux = ml ? a : (size_t)L.T * TB * TB * sizeof(double2);
   L.per_mat = a + aux + (size_t)L.N * sizeof(double2);
-  L.per_mat_extra = ml ? (size_t)(L.Np / 64) * TB * TB * sizeof(double2) + (size_t)(L.Np / 64) * sizeof(int) + 16 : 0;
+  L.per_mat_extra = ml ? (size_t)(L.Np / 64) * TB * TB * sizeof(double2) + (size_t)(L.Np / 64) * sizeof(int) + 32 : 0;
   L.header = ((size_t)(pl->lmax + 1) * sizeof(double) + 255) / 256 * 256;
   return L;
 }
@@ -877,9 +885,9 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   jp.V = jp.d.Linv;
   jp.acond = acond;
   jp.rcond = rcond;
-  jp.max_sweeps = 14;
+  jp.max_sweeps = ctx->opt_ml_outer_sweeps > 0 ? ctx->opt_ml_outer_sweeps : 60;
   BjParams bp;
-  bp.inner_sweeps = 2;
+  bp.inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;  // tools/ml_tune.py: one inner sweep per visit is fastest at equal accuracy
   bp.V = jp.V;
   bp.nb = L.Np / JB;
   const int npr = bp.nb / 2;
@@ -889,6 +897,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   bp.Wh = (double2*)extra;
   bp.flag = (int*)(bp.Wh + (size_t)cap * npr * TB * TB);
   bp.scale = (double*)(bp.flag + (((size_t)cap * npr + 1) & ~(size_t)1));
+  bp.any_rot = (int*)(bp.scale + cap);
   const size_t sub_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
   const size_t fil_lds = (size_t)2 * L.Np * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_bj_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
@@ -901,7 +910,8 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(L.T * (L.T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
     hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
     hipLaunchKernelGGL(k_bj_init, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, bp);
-    for (int sweep = 0; sweep < jp.max_sweeps; ++sweep)
+    for (int sweep = 0; sweep < jp.max_sweeps; ++sweep) {
+      DMM_HIP(hipMemsetAsync(bp.any_rot, 0, sizeof(int), ctx->stream));
       for (int round = 0; round < bp.nb - 1; ++round) {
         bp.round = round;
         hipLaunchKernelGGL(k_bj_sub, dim3(npr, nmat), dim3(kThreads), sub_lds, ctx->stream, bp);
@@ -912,6 +922,14 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         bp.target = 1;
         hipLaunchKernelGGL(k_bj_apply, dim3(L.T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
       }
+      // converged when a whole sweep found every pair diagonal to working precision
+      int any = 1;
+      DMM_HIP(hipMemcpyAsync(&any, bp.any_rot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      DMM_HIP(hipStreamSynchronize(ctx->stream));
+      if (!any) break;
+      if (sweep == jp.max_sweeps - 1)
+        return dmm_set_error(DMM_E_STATE, "dmm_ml_run: Jacobi did not converge in %d sweeps", jp.max_sweeps);
+    }
     hipLaunchKernelGGL(k_ml_filter, dim3(nmat), dim3(kThreads), fil_lds, ctx->stream, jp);
     DMM_HIP(hipGetLastError());
     int rc = dmm_dirty_w_launch(pl, B, jp.d.wbuf, nullptr, t0, nmat, alm);
