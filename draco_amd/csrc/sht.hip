@@ -398,13 +398,41 @@ struct LegAnalParams {
   int accumulate;     // 1: alm += result (Jacobi refinement)
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// Sum NV per-lane values over the 64 lanes of a wave with a halving butterfly: at each of
+// the first log2(NV) exchanges a lane hands half of its values to its partner and keeps the
+// other half, so NV-1 + (6 - log2 NV) shuffles replace 6*NV.  On return the lanes with
+// (lane & (64/NV - 1)) == 0 hold the total of value number lane / (64/NV).
+template <int NV>
+__device__ __forceinline__ double wave_reduce_scatter(double (&v)[NV], int lane) {
+  static_assert(NV == 8 || NV == 2, "NV");
+  double z;
+  if (NV == 8) {
+    double w[4], u[2];
+    const bool up5 = lane & 32, up4 = lane & 16, up3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (up5 ? v[4 + i] : v[i]) + __shfl_xor(up5 ? v[i] : v[4 + i], 32, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) u[i] = (up4 ? w[2 + i] : w[i]) + __shfl_xor(up4 ? w[i] : w[2 + i], 16, 64);
+    z = (up3 ? u[1] : u[0]) + __shfl_xor(up3 ? u[0] : u[1], 8, 64);
+    z += __shfl_xor(z, 4, 64);
+    z += __shfl_xor(z, 2, 64);
+    z += __shfl_xor(z, 1, 64);
+  } else {
+    const bool up5 = lane & 32;
+    z = (up5 ? v[1] : v[0]) + __shfl_xor(up5 ? v[0] : v[1], 32, 64);
+    for (int off = 16; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+  }
+  return z;
 }
 
-// block = (m, f); threads own ring pairs; for every l the products are reduced over the
-// block's rings: in-wave butterflies, then one LDS slot per wave, summed by the writer.
+// block = (m, f); each thread owns TWO ring pairs (one polar, one equatorial: r and
+// r + kThreads) whose recurrences advance together, so their products are summed in
+// registers before any exchange.  Per l the NV reals are reduced over the wave by the
+// halving butterfly above; the per-wave totals of kBatch consecutive l are parked in a
+// double-buffered LDS slab and folded into the block totals once per batch (one barrier per
+// kBatch l-steps).  Summation order is fixed: results are bit-reproducible.
+constexpr int kAnalBatch = 8;
+
 template <int NPOL>
 __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -412,9 +440,11 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
   const int lmax = p.g.lmax, nl = lmax - m + 1;
   constexpr int NW = kThreads / 64;
   constexpr int NV = NPOL == 4 ? 8 : 2;                 // reduced reals per l
+  constexpr int L = kAnalBatch;
+  constexpr int kGroup = 64 / NV;                       // lanes per reduced value
   Coef* coef = reinterpret_cast<Coef*>(smem);           // [nl]
   double* out = reinterpret_cast<double*>(coef + nl);   // [nl][NV] block totals
-  double* part = out + (size_t)nl * NV;                 // [NW][NV] per-wave partials of the current l
+  double* part = out + (size_t)nl * NV;                 // [2][NW][L][NV] per-wave totals of one batch
   fill_coef(coef, m, lmax);
   for (int i = threadIdx.x; i < nl * NV; i += kThreads) out[i] = 0.0;
   __syncthreads();
@@ -423,80 +453,102 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
   const double lfac_m = p.g.lfac[m];
   const int64_t mstride = p.g.mmax + 1;
 
-  for (int r0 = 0; r0 < npair; r0 += kThreads) {  // uniform trip count: barriers inside
-    const int r = r0 + threadIdx.x;
-    const bool live = r < npair;
-    const int rr = live ? r : 0;
-    const double x = p.g.z[rr], sth = p.g.sth[rr];
-    const int rs = nring - 1 - rr;
-    const bool skip = !live || ring_skips_m(m, lmax, sth);
-    // sym / anti combinations of the north and south ring coefficients
+  struct Ring {
+    double x, inv_s2, xs2, lam, lam_prev;
+    int nsc;       // pending 2^-800 blocks; < 0: ring takes no part (skipped or out of range)
     double2 gs[NPOL], ga[NPOL];
+  };
+  int buf = 0;
+  for (int r0 = 0; r0 < npair; r0 += 2 * kThreads) {  // uniform trip count: barriers inside
+    Ring R[2];
 #pragma unroll
-    for (int q = 0; q < NPOL; ++q) {
-      double2 n = {0, 0}, s = {0, 0};
-      if (live) {
-        n = p.b[(((int64_t)f * NPOL + q) * nring + rr) * mstride + m];
-        if (rs != rr) s = p.b[(((int64_t)f * NPOL + q) * nring + rs) * mstride + m];
+    for (int t = 0; t < 2; ++t) {
+      const int r = r0 + t * kThreads + threadIdx.x;
+      const bool live = r < npair;
+      const int rr = live ? r : 0;
+      const double x = p.g.z[rr], sth = p.g.sth[rr];
+      const int rs = nring - 1 - rr;
+      R[t].x = x;
+      R[t].inv_s2 = 1.0 / (sth * sth);
+      R[t].xs2 = x * R[t].inv_s2;
+      R[t].lam = R[t].lam_prev = 0.0;
+      R[t].nsc = -1;
+      if (live && !ring_skips_m(m, lmax, sth)) lam_start(lfac_m, m, sth, R[t].lam, R[t].nsc);
+      // sym / anti combinations of the north and south ring coefficients
+#pragma unroll
+      for (int q = 0; q < NPOL; ++q) {
+        double2 n = {0, 0}, s = {0, 0};
+        if (live) {
+          n = p.b[(((int64_t)f * NPOL + q) * nring + rr) * mstride + m];
+          if (rs != rr) s = p.b[(((int64_t)f * NPOL + q) * nring + rs) * mstride + m];
+        }
+        R[t].gs[q] = make_double2(n.x + s.x, n.y + s.y);
+        R[t].ga[q] = make_double2(n.x - s.x, n.y - s.y);
       }
-      gs[q] = make_double2(n.x + s.x, n.y + s.y);
-      ga[q] = make_double2(n.x - s.x, n.y - s.y);
     }
-    const double inv_s2 = 1.0 / (sth * sth), xs2 = x * inv_s2;
-    double lam = 0.0, lam_prev = 0.0;
-    int nsc = 0;
-    if (!skip) lam_start(lfac_m, m, sth, lam, nsc);
-    for (int k = 0; k < nl; ++k) {
-      const Coef q = coef[k];
-      if (k > 0 && !skip) {
-        const double nxt = x * lam * q.ra - lam_prev * q.rb;
-        lam_prev = lam;
-        lam = nxt;
-        if (nsc > 0 && fabs(lam) > kBig) {
-          lam *= kSmallStep;
-          lam_prev *= kSmallStep;
-          --nsc;
+    for (int k0 = 0; k0 < nl; k0 += L) {
+#pragma unroll
+      for (int kk = 0; kk < L; ++kk) {
+        const int k = k0 + kk;
+        if (k >= nl) break;
+        const Coef q = coef[k];
+        double v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = 0.0;
+        bool act = false;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          Ring& g = R[t];
+          if (k > 0 && g.nsc >= 0) {
+            const double nxt = g.x * g.lam * q.ra - g.lam_prev * q.rb;
+            g.lam_prev = g.lam;
+            g.lam = nxt;
+            if (g.nsc > 0 && fabs(g.lam) > kBig) {
+              g.lam *= kSmallStep;
+              g.lam_prev *= kSmallStep;
+              --g.nsc;
+            }
+          }
+          if (g.nsc == 0) {
+            act = true;
+            const bool even = !(kk & 1);  // k0 is a multiple of the (even) batch: static per unrolled step
+            const double2 gT = even ? g.gs[0] : g.ga[0];
+            v[0] = fma(gT.x, g.lam, v[0]);
+            v[1] = fma(gT.y, g.lam, v[1]);
+            if (NPOL == 4) {
+              const double2 gV = even ? g.gs[3] : g.ga[3];
+              v[6] = fma(gV.x, g.lam, v[6]);
+              v[7] = fma(gV.y, g.lam, v[7]);
+              const double F1 = fma(q.cd * g.xs2, g.lam_prev, -fma(q.c1, g.inv_s2, q.c2) * g.lam);
+              const double F2 = fma(q.c4 * g.inv_s2, g.lam_prev, -q.c3 * g.xs2 * g.lam);
+              // F1 pairs with the lambda-parity combination, F2 with the opposite one
+              const double2 Q1 = even ? g.gs[1] : g.ga[1], Q2 = even ? g.ga[1] : g.gs[1];
+              const double2 U1 = even ? g.gs[2] : g.ga[2], U2 = even ? g.ga[2] : g.gs[2];
+              // E = -(F1 gQ + i F2 gU),  B = -(F1 gU - i F2 gQ)
+              v[2] -= F1 * Q1.x - F2 * U2.y;
+              v[3] -= F1 * Q1.y + F2 * U2.x;
+              v[4] -= F1 * U1.x + F2 * Q2.y;
+              v[5] -= F1 * U1.y - F2 * Q2.x;
+            }
+          }
         }
-      }
-      double v[NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) v[i] = 0.0;
-      if (!skip && nsc == 0) {
-        const bool even = !(k & 1);
-        const double2 gT = even ? gs[0] : ga[0];
-        v[0] = gT.x * lam;
-        v[1] = gT.y * lam;
-        if (NPOL == 4) {
-          const double2 gV = even ? gs[3] : ga[3];
-          v[6] = gV.x * lam;
-          v[7] = gV.y * lam;
-          const double F1 = fma(q.cd * xs2, lam_prev, -fma(q.c1, inv_s2, q.c2) * lam);
-          const double F2 = fma(q.c4 * inv_s2, lam_prev, -q.c3 * xs2 * lam);
-          // F1 pairs with the lambda-parity combination, F2 with the opposite one
-          const double2 Q1 = even ? gs[1] : ga[1], Q2 = even ? ga[1] : gs[1];
-          const double2 U1 = even ? gs[2] : ga[2], U2 = even ? ga[2] : gs[2];
-          // E = -(F1 gQ + i F2 gU),  B = -(F1 gU - i F2 gQ)
-          v[2] = -(F1 * Q1.x - F2 * U2.y);
-          v[3] = -(F1 * Q1.y + F2 * U2.x);
-          v[4] = -(F1 * U1.x + F2 * Q2.y);
-          v[5] = -(F1 * U1.y - F2 * Q2.x);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) part[wave * NV + i] = v[i];
+        double z = 0.0;
+        if (__any(act)) z = wave_reduce_scatter<NV>(v, lane);  // wave-uniform branch
+        if ((lane & (kGroup - 1)) == 0) part[((buf * NW + wave) * L + kk) * NV + lane / kGroup] = z;
       }
       __syncthreads();
-      if (threadIdx.x < NV) {
-        double s = 0.0;
+      if (threadIdx.x < L * NV) {
+        const int kk = threadIdx.x / NV, i = threadIdx.x - kk * NV;
+        if (k0 + kk < nl) {
+          double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s += part[w * NV + threadIdx.x];
-        out[k * NV + threadIdx.x] += s;
+          for (int w = 0; w < NW; ++w) s += part[((buf * NW + w) * L + kk) * NV + i];
+          out[(k0 + kk) * NV + i] += s;
+        }
       }
-      __syncthreads();
+      buf ^= 1;  // the next batch fills the other slab: no second barrier
     }
+    __syncthreads();
   }
   // write a_lm (l >= m) and zeros for l < m
   for (int idx = threadIdx.x; idx < NPOL * (lmax + 1); idx += kThreads) {
@@ -667,7 +719,7 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   lp.alm = alm;
   lp.accumulate = accumulate;
   constexpr int NV = NPOL == 4 ? 8 : 2;
-  const size_t lds2 = (size_t)(g.lmax + 1) * (sizeof(Coef) + NV * sizeof(double)) + (kThreads / 64) * NV * sizeof(double);
+  const size_t lds2 = (size_t)(g.lmax + 1) * (sizeof(Coef) + NV * sizeof(double)) + (size_t)2 * (kThreads / 64) * kAnalBatch * NV * sizeof(double);
   DMM_HIP(hipFuncSetAttribute((const void*)k_leg_anal<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
   hipLaunchKernelGGL(k_leg_anal<NPOL>, dim3(g.mmax + 1, nf), dim3(kThreads), lds2, ctx->stream, lp);
   DMM_HIP(hipGetLastError());
