@@ -122,8 +122,13 @@ class SolveEngine:
                 s.close()
 
     # ---- the four batched operations
-    def solve(self, kind, mvis_d, mweight_d, freq_ind, mmax, **params):
-        """``alm [nfreq, npol, mmax+1, lmax+1]`` complex128 on the device."""
+    def solve(self, kind, mvis_d, mweight_d, freq_ind, mmax, on_freqs_done=None, **params):
+        """``alm [nfreq, npol, mmax+1, lmax+1]`` complex128 on the device.
+
+        ``on_freqs_done(alm, f0, f1)`` is called after each slab's launch with the range of
+        (data) frequencies whose every m has now been issued, so a caller can start the next
+        stage for them on another stream while the following slab is filled and solved.
+        """
         tel = self.provider.telescope
         n_m_data, _, nfreq, npairs = mvis_d.shape
         if npairs != tel.npairs:
@@ -132,6 +137,7 @@ class SolveEngine:
         alm = torch.empty((nfreq, tel.num_pol_sky, n_m, tel.lmax + 1), dtype=torch.complex128, device=self.ctx.device)
         self.last_b_bytes = 0
         lib = _lib.lib
+        issued, f_done = 0, 0
         for slab in self.slabs(freq_ind, mmax, nfreq, n_m):
             self.last_b_bytes += slab.b_bytes
             if kind == "dirty":
@@ -152,6 +158,10 @@ class SolveEngine:
                 )
             else:
                 raise ValueError(kind)
+            issued += slab.ntile  # slabs are consecutive ranges of the f-major, m-minor tile list
+            if on_freqs_done is not None and issued // n_m > f_done:
+                on_freqs_done(alm, f_done, issued // n_m)
+                f_done = issued // n_m
         return alm
 
     def project(self, alm_d, freq_ind, mmax):

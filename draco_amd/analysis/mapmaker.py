@@ -66,7 +66,7 @@ class BaseMapMaker(ContainerTask):
     def _solve_params(self):
         return {}
 
-    def make_alm(self, mmodes):
+    def make_alm(self, mmodes, on_freqs_done=None):
         """All (m, f) solves: device ``alm [nfreq, npol, mmax+1, lmax+1]`` (``mapmaker.py:50-94``)."""
         bt = self.beamtransfer
         mmax = min(bt.telescope.mmax, len(mmodes.index_map["m"]) - 1)
@@ -79,7 +79,7 @@ class BaseMapMaker(ContainerTask):
         ctx = eng.ctx
         mvis = _dev_dataset(mmodes.vis, ctx, np.complex128)
         mweight = _dev_dataset(mmodes.weight, ctx, np.float64)
-        return eng.solve(self._kind, mvis, mweight, freq_ind, mmax, **self._solve_params())
+        return eng.solve(self._kind, mvis, mweight, freq_ind, mmax, on_freqs_done=on_freqs_done, **self._solve_params())
 
     def alm_square(self, alm_d):
         """Device alm -> the reference's square ``[nfreq, 4, lmax+1, lmax+1]`` ndarray (``mapmaker.py:102-109``)."""
@@ -94,17 +94,35 @@ class BaseMapMaker(ContainerTask):
         bt = self.beamtransfer
         lmax = bt.telescope.lmax
         user_hook = type(self)._solve_m not in _BUILTIN_SOLVERS
-        if user_hook:
-            alm_d = self._host_loop(mmodes)
-        else:
-            alm_d = self.make_alm(mmodes)
         ctx = Context.get()
-        nfreq, npol, n_m, nl = alm_d.shape
-        if npol == 1:  # the reference's alm always has 4 pol slots and broadcasts into them (:71,:94)
-            alm_d = alm_d.expand(nfreq, 4, n_m, nl).contiguous()
-        npix = 12 * int(self.nside) ** 2
-        maps = ctx.empty((nfreq, 4, npix), np.float64)
-        _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm_d), nfreq, 4, lmax, n_m - 1, int(self.nside), ptr(maps)))
+        nside = int(self.nside)
+        npix = 12 * nside**2
+        if user_hook or bt.telescope.num_pol_sky != 4:
+            alm_d = self._host_loop(mmodes) if user_hook else self.make_alm(mmodes)
+            nfreq, npol, n_m, nl = alm_d.shape
+            if npol == 1:  # the reference's alm always has 4 pol slots and broadcasts into them (:71,:94)
+                alm_d = alm_d.expand(nfreq, 4, n_m, nl).contiguous()
+            maps = ctx.empty((nfreq, 4, npix), np.float64)
+            _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm_d), nfreq, 4, lmax, n_m - 1, nside, ptr(maps)))
+        else:
+            # the inverse SHT (:112) of the frequencies a slab has finished runs on a side stream
+            # beside the next slab's fill + solves: it is compute-bound, they are HBM/PCIe-bound
+            side = Context.side(ctx.device_index)
+            main = torch.cuda.current_stream(ctx.device)
+            out = {}
+
+            def sht_of(alm, f0, f1):
+                nfreq, _, n_m, _ = alm.shape  # the local frequencies
+                if "maps" not in out:
+                    out["maps"] = ctx.empty((nfreq, 4, npix), np.float64)
+                side.wait_for(main)
+                _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(out["maps"][f0:f1])))
+
+            alm_d = self.make_alm(mmodes, on_freqs_done=sht_of)
+            side.join(main)
+            maps = out.get("maps")
+            if maps is None:  # no frequencies on this rank
+                maps = ctx.empty((alm_d.shape[0], 4, npix), np.float64)
         m = containers.Map(nside=self.nside, axes_from=mmodes, comm=mmodes.comm, allocate=False)
         m.attach("map", maps)
         return m
@@ -151,7 +169,7 @@ class _OneTile:
     """Adapter so that a single-tile slab (only m, not 0..m) can be fed through SolveEngine.solve."""
 
     def __init__(self, slab):
-        self.plan, self.pool, self.b_bytes = slab.plan, slab.pool, slab.b_bytes
+        self.plan, self.pool, self.b_bytes, self.ntile = slab.plan, slab.pool, slab.b_bytes, slab.ntile
 
 
 class DirtyMapMaker(BaseMapMaker):

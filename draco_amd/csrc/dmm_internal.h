@@ -29,6 +29,7 @@ struct dmm_ctx {
   int opt_project_grid_mult = 0;
   int opt_project_variant = 0;
   int opt_ml_inner_sweeps = 0, opt_ml_outer_sweeps = 0;
+  int opt_sht_variant = 0;
   void* scratch = nullptr;                 // grow-only workspace (ring coefficients, Gram matrices ...)
   size_t scratch_bytes = 0;
 };

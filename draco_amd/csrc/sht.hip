@@ -39,8 +39,17 @@ struct ShtGeom {          // device tables for one (nside, lmax, mmax)
   int* nphi;              // [nring]
   int64_t* start;         // [nring]
   double* lfac;           // [mmax+1] log2 |lambda_mm| prefactor (without sin^m)
+  double* coef;           // [sum_m (lmax-m+1)][8] per-(m,l) recurrence / spin-2 factors (struct Coef rows)
+  double2* bfilt;         // Bluestein filter spectra of the cap rings, back to back (see k_build_bfilt)
+  int64_t* bf_off;        // [blue_rmax+1] offset of cap ring number ir's spectrum in bfilt
+  int blue_rmax;          // cap ring numbers 1..blue_rmax have a spectrum (FFT length <= kMaxBlue)
   void* block;            // the single allocation behind all of the above
 };
+
+// rows of the coefficient table before those of m: sum_{m'<m} (lmax - m' + 1)
+__host__ __device__ __forceinline__ int64_t coef_row0(int m, int lmax) {
+  return (int64_t)m * (lmax + 1) - (int64_t)m * (m - 1) / 2;
+}
 
 struct LegParams {
   ShtGeom g;
@@ -60,8 +69,29 @@ struct Coef {  // wave-uniform per-l factors of one m
   double c4, pad;
 };
 
-__device__ __forceinline__ void fill_coef(Coef* coef, int m, int lmax) {
-  for (int l = m + threadIdx.x; l <= lmax; l += kThreads) {
+// Wave-uniform operands (coefficient rows, a_lm columns) are read through the constant
+// address space: the loads become s_load into SGPRs and cost no LDS or vector-memory issue.
+typedef const __attribute__((address_space(4))) double* kptr;
+
+__device__ __forceinline__ Coef load_coef(kptr c) {  // c -> one 8-double row
+  Coef q;
+  q.ra = c[0];
+  q.rb = c[1];
+  q.c1 = c[2];
+  q.c2 = c[3];
+  q.cd = c[4];
+  q.c3 = c[5];
+  q.c4 = c[6];
+  q.pad = 0.0;
+  return q;
+}
+
+__device__ __forceinline__ double2 load_c(kptr a) { return make_double2(a[0], a[1]); }
+
+__global__ void k_fill_coef(Coef* table, int lmax) {  // block = m
+  const int m = blockIdx.x;
+  Coef* coef = table + coef_row0(m, lmax);
+  for (int l = m + threadIdx.x; l <= lmax; l += blockDim.x) {
     Coef q;
     const double dl = (double)l, dm = (double)m;
     const double A = sqrt((dl * dl - dm * dm) / (4.0 * dl * dl - 1.0));
@@ -80,6 +110,7 @@ __device__ __forceinline__ void fill_coef(Coef* coef, int m, int lmax) {
     coef[l - m] = q;
   }
 }
+static_assert(sizeof(Coef) == 64, "Coef row");
 
 // start of the recurrence for ring (x, sth): lam_mm = v * 2^(-800*nsc)
 __device__ __forceinline__ void lam_start(double lfac_m, int m, double sth, double& v, int& nsc) {
@@ -96,117 +127,143 @@ __device__ __forceinline__ bool ring_skips_m(int m, int lmax, double sth) {
 }
 
 // ---------------------------------------------------------------- synthesis, stage 1
-template <int NPOL>
-__global__ __launch_bounds__(kThreads) void k_leg_synth(LegParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
+template <int NPOL, int NR, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_leg_synth(LegParams p) {
   const int m = blockIdx.x, f = blockIdx.y;
   const int lmax = p.g.lmax, nl = lmax - m + 1;
-  Coef* coef = reinterpret_cast<Coef*>(smem);                  // [nl]
-  double2* a = reinterpret_cast<double2*>(coef + nl);          // [NPOL][nl]
-  fill_coef(coef, m, lmax);
-  for (int idx = threadIdx.x; idx < NPOL * nl; idx += kThreads) {
-    const int pol = idx / nl, k = idx - pol * nl;
-    a[idx] = p.alm[(((int64_t)f * NPOL + pol) * p.n_m + m) * (lmax + 1) + m + k];
-  }
-  __syncthreads();
+  const kptr coef = (kptr)p.g.coef + 8 * coef_row0(m, lmax);   // [nl][8]
+  kptr a[NPOL];                                                // a_lm columns, l = m..lmax
+#pragma unroll
+  for (int q = 0; q < NPOL; ++q)
+    a[q] = (kptr)(p.alm + (((int64_t)f * NPOL + q) * p.n_m + m) * (lmax + 1) + m);
 
   const int nring = p.g.nring, npair = (nring + 1) / 2;  // north rings incl. equator
   const double lfac_m = p.g.lfac[m];
-  for (int r = threadIdx.x; r < npair; r += kThreads) {
-    const double x = p.g.z[r], sth = p.g.sth[r];
-    const int rs = nring - 1 - r;  // southern mirror (== r on the equator)
-    // accumulators: [sym, anti] for I, V (and Q, U)
-    double2 Ts = {0, 0}, Ta = {0, 0}, Vs = {0, 0}, Va = {0, 0};
-    double2 Qs = {0, 0}, Qa = {0, 0}, Us = {0, 0}, Ua = {0, 0};
-    if (!ring_skips_m(m, lmax, sth)) {
-      const double inv_s2 = 1.0 / (sth * sth), xs2 = x * inv_s2;
-      double lam, lam_prev = 0.0;
-      int nsc;
-      lam_start(lfac_m, m, sth, lam, nsc);
-      // one l-step; the accumulator pairing is static per parity (no selects in the loop):
-      // lambda-parity terms go to (T, V, Q1, U1), opposite-parity (F2) terms to (Q2, U2)
-      auto step = [&](const Coef& q, const double2& aT, const double2& aE, const double2& aB, const double2& aV,
-                      bool first, double2& T, double2& V, double2& Q1, double2& Q2, double2& U1, double2& U2) {
-        if (!first) {
-          const double nxt = x * lam * q.ra - lam_prev * q.rb;
-          lam_prev = lam;
-          lam = nxt;
-          if (nsc > 0 && fabs(lam) > kBig) {
-            lam *= kSmallStep;
-            lam_prev *= kSmallStep;
-            --nsc;
-          }
-        }
-        if (nsc == 0) {
-          T.x = fma(aT.x, lam, T.x);
-          T.y = fma(aT.y, lam, T.y);
-          if (NPOL == 4) {
-            V.x = fma(aV.x, lam, V.x);
-            V.y = fma(aV.y, lam, V.y);
-            // l < 2: c1..c4 are zero, F1 = F2 = 0
-            const double F1 = fma(q.cd * xs2, lam_prev, -fma(q.c1, inv_s2, q.c2) * lam);
-            const double F2 = fma(q.c4 * inv_s2, lam_prev, -q.c3 * xs2 * lam);
-            Q1.x = fma(-aE.x, F1, Q1.x);   // Q: -(E F1 + i B F2)
-            Q1.y = fma(-aE.y, F1, Q1.y);
-            Q2.x = fma(aB.y, F2, Q2.x);    // -i*B*F2 = (B.y, -B.x) * F2
-            Q2.y = fma(-aB.x, F2, Q2.y);
-            U1.x = fma(-aB.x, F1, U1.x);   // U: -(B F1 - i E F2)
-            U1.y = fma(-aB.y, F1, U1.y);
-            U2.x = fma(-aE.y, F2, U2.x);   // +i*E*F2 = (-E.y, E.x) * F2
-            U2.y = fma(aE.x, F2, U2.y);
-          }
-        }
-      };
-      const double2 zero2 = {0.0, 0.0};
-      int k = 0;
-      for (; k + 1 < nl; k += 2) {
-        // all LDS operands of both steps first: one wait covers two steps
-        const Coef q0 = coef[k], q1 = coef[k + 1];
-        const double2 t0 = a[k], t1 = a[k + 1];
-        double2 e0 = zero2, b0 = zero2, v0 = zero2, e1 = zero2, b1 = zero2, v1 = zero2;
-        if (NPOL == 4) {
-          e0 = a[nl + k];
-          e1 = a[nl + k + 1];
-          b0 = a[2 * nl + k];
-          b1 = a[2 * nl + k + 1];
-          v0 = a[3 * nl + k];
-          v1 = a[3 * nl + k + 1];
-        }
-        step(q0, t0, e0, b0, v0, k == 0, Ts, Vs, Qs, Qa, Us, Ua);
-        step(q1, t1, e1, b1, v1, false, Ta, Va, Qa, Qs, Ua, Us);
-      }
-      if (k < nl) {
-        const Coef q0 = coef[k];
-        const double2 t0 = a[k];
-        double2 e0 = zero2, b0 = zero2, v0 = zero2;
-        if (NPOL == 4) {
-          e0 = a[nl + k];
-          b0 = a[2 * nl + k];
-          v0 = a[3 * nl + k];
-        }
-        step(q0, t0, e0, b0, v0, k == 0, Ts, Vs, Qs, Qa, Us, Ua);
-      }
+  const int64_t mstride = p.g.mmax + 1;
+  // accumulators: [sym, anti] for I, V (and Q, U); lambda-parity terms go to (T, V, Q1, U1),
+  // opposite-parity (F2) terms to (Q2, U2): the pairing is static per parity (no selects)
+  struct Ring {
+    double x, inv_s2, xs2, lam, lam_prev;
+    int nsc;  // pending 2^-800 blocks; < 0: ring takes no part
+    double2 Ts, Ta, Vs, Va, Qs, Qa, Us, Ua;
+  };
+  // each thread advances NR ring pairs (r, r + kThreads, ...: polar and equatorial mixed) together:
+  // independent recurrences interleave and every LDS operand serves both
+  for (int r0 = 0; r0 < npair; r0 += NR * kThreads) {
+    Ring R[NR];
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const int r = r0 + t * kThreads + threadIdx.x;
+      const bool live = r < npair;
+      const int rr = live ? r : 0;
+      const double x = p.g.z[rr], sth = p.g.sth[rr];
+      R[t].x = x;
+      R[t].inv_s2 = 1.0 / (sth * sth);
+      R[t].xs2 = x * R[t].inv_s2;
+      R[t].lam = R[t].lam_prev = 0.0;
+      R[t].nsc = -1;
+      if (live && !ring_skips_m(m, lmax, sth)) lam_start(lfac_m, m, sth, R[t].lam, R[t].nsc);
+      const double2 z2 = {0.0, 0.0};
+      R[t].Ts = R[t].Ta = R[t].Vs = R[t].Va = R[t].Qs = R[t].Qa = R[t].Us = R[t].Ua = z2;
     }
-    const int64_t mstride = p.g.mmax + 1;
-    auto put = [&](int pol, int ring, double2 s, double2 an, double sgn) {
-      p.b[(((int64_t)f * NPOL + pol) * nring + ring) * mstride + m] = make_double2(s.x + sgn * an.x, s.y + sgn * an.y);
+    auto step = [&](Ring& g, const Coef& q, const double2& aT, const double2& aE, const double2& aB, const double2& aV,
+                    bool first, bool even) {
+      if (g.nsc < 0) return;
+      if (!first) {
+        const double nxt = g.x * g.lam * q.ra - g.lam_prev * q.rb;
+        g.lam_prev = g.lam;
+        g.lam = nxt;
+        if (g.nsc > 0 && fabs(g.lam) > kBig) {
+          g.lam *= kSmallStep;
+          g.lam_prev *= kSmallStep;
+          --g.nsc;
+        }
+      }
+      if (g.nsc == 0) {
+        double2& T = even ? g.Ts : g.Ta;
+        double2& V = even ? g.Vs : g.Va;
+        double2& Q1 = even ? g.Qs : g.Qa;
+        double2& Q2 = even ? g.Qa : g.Qs;
+        double2& U1 = even ? g.Us : g.Ua;
+        double2& U2 = even ? g.Ua : g.Us;
+        T.x = fma(aT.x, g.lam, T.x);
+        T.y = fma(aT.y, g.lam, T.y);
+        if (NPOL == 4) {
+          V.x = fma(aV.x, g.lam, V.x);
+          V.y = fma(aV.y, g.lam, V.y);
+          // l < 2: c1..c4 are zero, F1 = F2 = 0
+          const double F1 = fma(q.cd * g.xs2, g.lam_prev, -fma(q.c1, g.inv_s2, q.c2) * g.lam);
+          const double F2 = fma(q.c4 * g.inv_s2, g.lam_prev, -q.c3 * g.xs2 * g.lam);
+          Q1.x = fma(-aE.x, F1, Q1.x);   // Q: -(E F1 + i B F2)
+          Q1.y = fma(-aE.y, F1, Q1.y);
+          Q2.x = fma(aB.y, F2, Q2.x);    // -i*B*F2 = (B.y, -B.x) * F2
+          Q2.y = fma(-aB.x, F2, Q2.y);
+          U1.x = fma(-aB.x, F1, U1.x);   // U: -(B F1 - i E F2)
+          U1.y = fma(-aB.y, F1, U1.y);
+          U2.x = fma(-aE.y, F2, U2.x);   // +i*E*F2 = (-E.y, E.x) * F2
+          U2.y = fma(aE.x, F2, U2.y);
+        }
+      }
     };
-    put(0, r, Ts, Ta, 1.0);
-    if (rs != r) put(0, rs, Ts, Ta, -1.0);
-    if (NPOL == 4) {
-      put(1, r, Qs, Qa, 1.0);
-      put(2, r, Us, Ua, 1.0);
-      put(3, r, Vs, Va, 1.0);
-      if (rs != r) {
-        put(1, rs, Qs, Qa, -1.0);
-        put(2, rs, Us, Ua, -1.0);
-        put(3, rs, Vs, Va, -1.0);
+    // Scalar operands of one l: software-pipelined by hand.  SMEM returns out of order, so every
+    // wait drains the queue: the loads of step k+1 are issued BEFORE the arithmetic of step k
+    // and first needed after it (indices clamp to the last row: always in bounds, no branches).
+    struct Ops {
+      Coef q;
+      double2 aT, aE, aB, aV;
+    };
+    auto fetch = [&](int k) {
+      const int kc = k < nl ? k : nl - 1;
+      // drain the PREVIOUS fetch here, before this one is issued (lgkmcnt(0); vmcnt/expcnt untouched):
+      // otherwise the compiler's wait lands at the first use of the older operands, after these loads
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      Ops o;
+      o.q = load_coef(coef + 8 * kc);
+      o.aT = load_c(a[0] + 2 * kc);
+      o.aE = o.aB = o.aV = make_double2(0.0, 0.0);
+      if (NPOL == 4) {
+        o.aE = load_c(a[NPOL > 1 ? 1 : 0] + 2 * kc);
+        o.aB = load_c(a[NPOL > 1 ? 2 : 0] + 2 * kc);
+        o.aV = load_c(a[NPOL > 1 ? 3 : 0] + 2 * kc);
+      }
+      return o;
+    };
+    Ops cur = fetch(0);
+    for (int k = 0; k < nl; k += 2) {
+      Ops nxt = fetch(k + 1);
+#pragma unroll
+      for (int t = 0; t < NR; ++t) step(R[t], cur.q, cur.aT, cur.aE, cur.aB, cur.aV, k == 0, true);
+      if (k + 1 >= nl) break;
+      cur = fetch(k + 2);
+#pragma unroll
+      for (int t = 0; t < NR; ++t) step(R[t], nxt.q, nxt.aT, nxt.aE, nxt.aB, nxt.aV, false, false);
+    }
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const int r = r0 + t * kThreads + threadIdx.x;
+      if (r >= npair) continue;
+      const int rs = nring - 1 - r;  // southern mirror (== r on the equator)
+      const Ring& g = R[t];
+      auto put = [&](int pol, int ring, double2 s, double2 an, double sgn) {
+        p.b[(((int64_t)f * NPOL + pol) * nring + ring) * mstride + m] = make_double2(s.x + sgn * an.x, s.y + sgn * an.y);
+      };
+      put(0, r, g.Ts, g.Ta, 1.0);
+      if (rs != r) put(0, rs, g.Ts, g.Ta, -1.0);
+      if (NPOL == 4) {
+        put(1, r, g.Qs, g.Qa, 1.0);
+        put(2, r, g.Us, g.Ua, 1.0);
+        put(3, r, g.Vs, g.Va, 1.0);
+        if (rs != r) {
+          put(1, rs, g.Qs, g.Qa, -1.0);
+          put(2, rs, g.Us, g.Ua, -1.0);
+          put(3, rs, g.Vs, g.Va, -1.0);
+        }
       }
     }
   }
 }
 
-// ---------------------------------------------------------------- synthesis, stage 2
+// ---------------------------------------------------------------- ring stages (2 and 1')
 struct RingParams {
   ShtGeom g;
   int nf, npol;
@@ -215,14 +272,36 @@ struct RingParams {
   int64_t npix;
 };
 
-// block = (ring, f): map(j) = Re sum_m fac_m b_m e^{i m (phi0 + 2 pi j / nphi)} for all pols
+// A launch covers one CLASS of rings that share an FFT length:
+//   belt:  rings nside .. 3 nside (nphi = 4 nside, a power of two): plain FFT, M = nphi
+//   cap:   ring numbers ir in [r_lo, r_hi] of BOTH caps (nphi = 4 ir): Bluestein with M = the
+//          class's power of two >= 2 nphi - 1 (at least kMinBlue, so the tiny rings share a class)
+struct RingClass {
+  int belt;        // 1: equatorial belt
+  int r_lo, r_hi;  // cap ring numbers (1-based), inclusive
+  int M, logM;
+};
+constexpr int kMinBlue = 256, kMaxBlue = 4096;
+
+__host__ __device__ __forceinline__ int blue_len(int ir) {  // Bluestein FFT length of cap ring number ir
+  int M = kMinBlue;
+  while (M < 8 * ir - 1) M <<= 1;
+  return M;
+}
+
+__device__ __forceinline__ int class_ring(const RingClass& rc, const ShtGeom& g, int i) {
+  if (rc.belt) return g.nside - 1 + i;
+  const int ir = rc.r_lo + (i >> 1);
+  return (i & 1) ? g.nring - ir : ir - 1;  // south : north
+}
+
+// direct evaluation, block = (ring of the class, f): map(j) = Re sum_m fac_m b_m e^{i m phi_j}.
+// Fallback for rings whose FFT does not fit the LDS (nside > 512) and the check of the FFT path.
 template <int NPOL>
-__global__ __launch_bounds__(kThreads) void k_ring_synth(RingParams p) {
+__global__ __launch_bounds__(kThreads) void k_ring_synth(RingParams p, RingClass rc) {
   extern __shared__ __align__(16) unsigned char smem[];
   double2* c = reinterpret_cast<double2*>(smem);  // [NPOL][mmax+1]
-  // polar-cap rings only (the equatorial belt runs k_ring_synth_fft): skip over the belt
-  const int ncap = p.g.nside - 1;
-  const int ring = (int)blockIdx.x < ncap ? blockIdx.x : blockIdx.x + 2 * p.g.nside + 1;
+  const int ring = class_ring(rc, p.g, blockIdx.x);
   const int f = blockIdx.y;
   const int nm = p.g.mmax + 1;
   const double phi0 = p.g.phi0[ring];
@@ -259,85 +338,140 @@ __global__ __launch_bounds__(kThreads) void k_ring_synth(RingParams p) {
   }
 }
 
-// Equatorial belt (rings nside .. 3 nside, nphi = 4 nside, a power of two): the ring sum is an
-// inverse DFT.  The Hermitian spectrum H_k = b_k e^{i k phi0} (k <= mmax), H_{n-k} = conj(H_k),
-// folded modulo n, makes the map real, so TWO polarisations ride one complex FFT:
-// z = H_a + i H_b  ->  IDFT(z) = map_a + i map_b.  IDFT(z) = conj(DFT(conj z)) on the shared
-// in-LDS DIF kernel (bit-reversed output, read through the reversal).
+// ---- FFT ring stages.  A ring of N = nphi pixels is a length-N DFT: a plain in-LDS FFT when N
+// is a power of two (the belt), Bluestein's chirp-z otherwise (the caps):
+//   X_j = c_j * sum_k (x_k c_k) conj(c)_{j-k},  c_k = exp(-i pi k^2 / N)
+// i.e. multiply by the chirp, FFT_M, multiply by the precomputed spectrum of the wrapped conjugate
+// chirp (ShtGeom::bfilt, stored in the DIF kernel's bit-reversed order and scaled by 1/M),
+// inverse FFT_M, multiply by the chirp.  TWO real fields ride one complex transform.
 constexpr int kFftThreads = 256;
-template <int NPOL>
-__global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p) {
+
+struct RingLds {
+  dmm_fft::C<double>* buf;    // [NROW][M + 1]
+  dmm_fft::C<double>* tw;     // [M / 2]   exp(-2 pi i k / M)
+  dmm_fft::C<double>* chirp;  // [N]       (Bluestein only)
+};
+
+template <int NROW, bool BLUE>
+__device__ __forceinline__ RingLds ring_lds(unsigned char* smem, int N, int M) {
+  RingLds l;
+  l.buf = reinterpret_cast<dmm_fft::C<double>*>(smem);
+  l.tw = l.buf + NROW * (M + 1);
+  l.chirp = l.tw + (M >> 1);
+  for (int k = threadIdx.x; k < (M >> 1); k += kFftThreads) {
+    double sn, cs;
+    sincospi(-2.0 * (double)k / (double)M, &sn, &cs);
+    l.tw[k] = {cs, sn};
+  }
+  if (BLUE) {
+    for (int k = threadIdx.x; k < N; k += kFftThreads) {
+      const int k2 = (int)(((int64_t)k * k) % (2 * (int64_t)N));  // exact phase reduction
+      double sn, cs;
+      sincospi(-(double)k2 / (double)N, &sn, &cs);
+      l.chirp[k] = {cs, sn};
+    }
+  }
+  return l;
+}
+
+// forward DFT_N of the NROW rows in l.buf (natural order, already multiplied by the chirp and
+// zero-padded to M when BLUE).  Afterwards X_k is ring_dft_at(l, r, k).
+template <int NROW, bool BLUE>
+__device__ __forceinline__ void ring_dft(const RingLds& l, const double2* bfilt, int M, int logM) {
+  const int P = M + 1;
+  dmm_fft::fft_dif<double, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
+  if (BLUE) {
+    for (int idx = threadIdx.x; idx < NROW * M; idx += kFftThreads) {
+      const int r = idx / M, k = idx - r * M;
+      const double2 fk = bfilt[k];
+      l.buf[r * P + k] = dmm_fft::cmul<double>(l.buf[r * P + k], {fk.x, fk.y});
+    }
+    __syncthreads();
+    dmm_fft::fft_dit<double, true, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
+  }
+}
+
+template <bool BLUE>
+__device__ __forceinline__ dmm_fft::C<double> ring_dft_at(const RingLds& l, int r, int k, int M, int logM) {
+  if (BLUE) return dmm_fft::cmul<double>(l.buf[r * (M + 1) + k], l.chirp[k]);
+  return l.buf[r * (M + 1) + dmm_fft::bitrev(k, logM)];
+}
+
+// Synthesis: the Hermitian spectrum H_k = b_k e^{i k phi0} (k <= mmax), H_{N-k} = conj(H_k),
+// folded modulo N, makes the map real, so two polarisations ride one transform:
+// z = H_a + i H_b  ->  IDFT(z) = map_a + i map_b, and IDFT(z) = conj(DFT(conj z)).
+template <int NPOL, bool BLUE>
+__global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, RingClass rc) {
   using dmm_fft::C;
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int NROW = NPOL == 4 ? 2 : 1;
-  const int n = 4 * p.g.nside, P = n + 1;
-  int logn = 0;
-  while ((1 << logn) < n) ++logn;
-  C<double>* buf = reinterpret_cast<C<double>*>(smem);  // [NROW][P]
-  C<double>* tw = buf + NROW * P;                       // [n/2]
-  const int ring = p.g.nside - 1 + blockIdx.x, f = blockIdx.y;
+  const int ring = class_ring(rc, p.g, blockIdx.x), f = blockIdx.y;
+  const int n = p.g.nphi[ring], M = rc.M, P = M + 1;
+  const RingLds l = ring_lds<NROW, BLUE>(smem, n, M);
+  if (BLUE) __syncthreads();  // the chirp is used by the load below
   const int nm = p.g.mmax + 1;
   const double phi0 = p.g.phi0[ring];
-  for (int k = threadIdx.x; k < (n >> 1); k += kFftThreads) {
-    double sn, cs;
-    sincospi(-2.0 * (double)k / (double)n, &sn, &cs);
-    tw[k] = {cs, sn};
-  }
   const double2* brow[NPOL];
 #pragma unroll
   for (int q = 0; q < NPOL; ++q) brow[q] = p.b + (((int64_t)f * NPOL + q) * p.g.nring + ring) * nm;
-  for (int k = threadIdx.x; k < n; k += kFftThreads) {
+  for (int k = threadIdx.x; k < M; k += kFftThreads) {
     double zr[NROW], zi[NROW];
 #pragma unroll
     for (int r = 0; r < NROW; ++r) zr[r] = zi[r] = 0.0;
-    // direct terms m == k (mod n)
-    for (int m = k; m < nm; m += n) {
-      double sn, cs;
-      sincos((double)m * phi0, &sn, &cs);
+    if (k < n) {
+      // direct terms m == k (mod n)
+      for (int m = k; m < nm; m += n) {
+        double sn, cs;
+        sincos((double)m * phi0, &sn, &cs);
 #pragma unroll
-      for (int r = 0; r < NROW; ++r) {
-        const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
-        double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
-        double br = 0.0, bi = 0.0;
-        if (NPOL == 4) {
-          const double2 vb = brow[2 * r + 1][m];
-          br = vb.x * cs - vb.y * sn;
-          bi = vb.x * sn + vb.y * cs;
+        for (int r = 0; r < NROW; ++r) {
+          const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
+          double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
+          double br = 0.0, bi = 0.0;
+          if (NPOL == 4) {
+            const double2 vb = brow[NPOL == 4 ? 2 * r + 1 : 0][m];
+            br = vb.x * cs - vb.y * sn;
+            bi = vb.x * sn + vb.y * cs;
+          }
+          if (m == 0) ai = bi = 0.0;  // the m = 0 term of a real field is real
+          zr[r] += ar - bi;           // z = H_a + i H_b
+          zi[r] += ai + br;
         }
-        if (m == 0) ai = bi = 0.0;  // the m = 0 term of a real field is real
-        zr[r] += ar - bi;           // z = H_a + i H_b
-        zi[r] += ai + br;
+      }
+      // mirrored terms m == -k (mod n), m >= 1: conj(H_a) + i conj(H_b)
+      for (int m = (k == 0 ? n : n - k); m < nm; m += n) {
+        double sn, cs;
+        sincos((double)m * phi0, &sn, &cs);
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
+          const double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
+          double br = 0.0, bi = 0.0;
+          if (NPOL == 4) {
+            const double2 vb = brow[NPOL == 4 ? 2 * r + 1 : 0][m];
+            br = vb.x * cs - vb.y * sn;
+            bi = vb.x * sn + vb.y * cs;
+          }
+          zr[r] += ar + bi;  // conj(a) + i conj(b) = (ar + bi) + i(br - ai)
+          zi[r] += br - ai;
+        }
       }
     }
-    // mirrored terms m == -k (mod n), m >= 1: conj(H_a) + i conj(H_b)
-    for (int m = (k == 0 ? n : n - k); m < nm; m += n) {
-      double sn, cs;
-      sincos((double)m * phi0, &sn, &cs);
-#pragma unroll
-      for (int r = 0; r < NROW; ++r) {
-        const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
-        const double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
-        double br = 0.0, bi = 0.0;
-        if (NPOL == 4) {
-          const double2 vb = brow[2 * r + 1][m];
-          br = vb.x * cs - vb.y * sn;
-          bi = vb.x * sn + vb.y * cs;
-        }
-        zr[r] += ar + bi;  // conj(a) + i conj(b) = (ar + bi) + i(br - ai)
-        zi[r] += br - ai;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < NROW; ++r) buf[r * P + k] = {zr[r], -zi[r]};  // conj(z)
-  }
-  __syncthreads();
-  dmm_fft::fft_dif<double, kFftThreads>(buf, tw, NROW, n, logn, P);
-  const int64_t base = p.g.start[ring];
-  for (int j = threadIdx.x; j < n; j += kFftThreads) {
-    const int jr = dmm_fft::bitrev(j, logn);
 #pragma unroll
     for (int r = 0; r < NROW; ++r) {
-      const C<double> y = buf[r * P + jr];  // IDFT(z)_j = conj(y)
+      C<double> v = {zr[r], -zi[r]};  // conj(z)
+      if (BLUE && k < n) v = dmm_fft::cmul<double>(v, l.chirp[k]);
+      l.buf[r * P + k] = v;
+    }
+  }
+  __syncthreads();
+  const double2* bfilt = BLUE ? p.g.bfilt + p.g.bf_off[rc.belt ? 0 : rc.r_lo + ((int)blockIdx.x >> 1)] : nullptr;
+  ring_dft<NROW, BLUE>(l, bfilt, M, rc.logM);
+  const int64_t base = p.g.start[ring];
+  for (int j = threadIdx.x; j < n; j += kFftThreads) {
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) {
+      const C<double> y = ring_dft_at<BLUE>(l, r, j, M, rc.logM);  // IDFT(z)_j = conj(y)
       p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * r : 0)) * p.npix + base + j] = y.x;
       if (NPOL == 4) p.map[((int64_t)f * NPOL + 2 * r + 1) * p.npix + base + j] = -y.y;
     }
@@ -345,12 +479,13 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p) {
 }
 
 // ---------------------------------------------------------------- analysis, stage 1'
-// block = (ring, f): g_m = w * sum_j map_j e^{-i m phi_j}; thread <-> m, pixels broadcast from LDS
+// direct evaluation, block = (ring of the class, f): g_m = w * sum_j map_j e^{-i m phi_j};
+// thread <-> m, pixels broadcast from LDS.  Fallback / check, as k_ring_synth.
 template <int NPOL>
-__global__ __launch_bounds__(kThreads) void k_ring_anal(RingParams p) {
+__global__ __launch_bounds__(kThreads) void k_ring_anal(RingParams p, RingClass rc) {
   extern __shared__ __align__(16) unsigned char smem[];
   double* px = reinterpret_cast<double*>(smem);  // [NPOL][nphi]
-  const int ring = blockIdx.x, f = blockIdx.y;
+  const int ring = class_ring(rc, p.g, blockIdx.x), f = blockIdx.y;
   const int nm = p.g.mmax + 1;
   const double phi0 = p.g.phi0[ring];
   const int nphi = p.g.nphi[ring];
@@ -387,6 +522,87 @@ __global__ __launch_bounds__(kThreads) void k_ring_anal(RingParams p) {
       p.b[(((int64_t)f * NPOL + q) * p.g.nring + ring) * nm + m] =
           make_double2(w * (are[q] * c0 - aim[q] * s0), w * (are[q] * s0 + aim[q] * c0));
   }
+}
+
+// FFT version: x = map_a + i map_b, X = DFT_N(x); the two real fields separate through
+// A_k = (X_k + conj X_{N-k}) / 2, B_k = (X_k - conj X_{N-k}) / (2i); g_m = w e^{-i m phi0} A_{m mod N}.
+template <int NPOL, bool BLUE>
+__global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, RingClass rc) {
+  using dmm_fft::C;
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  const int ring = class_ring(rc, p.g, blockIdx.x), f = blockIdx.y;
+  const int n = p.g.nphi[ring], M = rc.M, P = M + 1;
+  const RingLds l = ring_lds<NROW, BLUE>(smem, n, M);
+  if (BLUE) __syncthreads();
+  const int64_t base = p.g.start[ring];
+  for (int k = threadIdx.x; k < M; k += kFftThreads) {
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) {
+      C<double> v = {0.0, 0.0};
+      if (k < n) {
+        v.x = p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * r : 0)) * p.npix + base + k];
+        if (NPOL == 4) v.y = p.map[((int64_t)f * NPOL + 2 * r + 1) * p.npix + base + k];
+        if (BLUE) v = dmm_fft::cmul<double>(v, l.chirp[k]);
+      }
+      l.buf[r * P + k] = v;
+    }
+  }
+  __syncthreads();
+  const double2* bfilt = BLUE ? p.g.bfilt + p.g.bf_off[rc.belt ? 0 : rc.r_lo + ((int)blockIdx.x >> 1)] : nullptr;
+  ring_dft<NROW, BLUE>(l, bfilt, M, rc.logM);
+  const int nm = p.g.mmax + 1;
+  const double phi0 = p.g.phi0[ring];
+  const double w = 4.0 * M_PI / (double)p.npix;
+  for (int m = threadIdx.x; m < nm; m += kFftThreads) {
+    const int k = m % n, k2 = (n - k) % n;
+    double s0, c0;
+    sincos(-(double)m * phi0, &s0, &c0);
+#pragma unroll
+    for (int r = 0; r < NROW; ++r) {
+      const C<double> X = ring_dft_at<BLUE>(l, r, k, M, rc.logM), Y = ring_dft_at<BLUE>(l, r, k2, M, rc.logM);
+      const double ar = 0.5 * (X.x + Y.x), ai = 0.5 * (X.y - Y.y);
+      p.b[(((int64_t)f * NPOL + (NPOL == 4 ? 2 * r : 0)) * p.g.nring + ring) * nm + m] =
+          make_double2(w * (ar * c0 - ai * s0), w * (ar * s0 + ai * c0));
+      if (NPOL == 4) {
+        const double br = 0.5 * (X.y + Y.y), bi = -0.5 * (X.x - Y.x);
+        p.b[(((int64_t)f * NPOL + 2 * r + 1) * p.g.nring + ring) * nm + m] =
+            make_double2(w * (br * c0 - bi * s0), w * (br * s0 + bi * c0));
+      }
+    }
+  }
+}
+
+// geometry build: spectrum of the wrapped conjugate chirp of cap ring number ir = blockIdx.x + 1
+__global__ __launch_bounds__(kFftThreads) void k_build_bfilt(double2* table, const int64_t* bf_off) {
+  using dmm_fft::C;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int ir = blockIdx.x + 1, N = 4 * ir, M = blue_len(ir), P = M + 1;
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+  C<double>* buf = reinterpret_cast<C<double>*>(smem);
+  C<double>* tw = buf + P;
+  for (int k = threadIdx.x; k < (M >> 1); k += kFftThreads) {
+    double sn, cs;
+    sincospi(-2.0 * (double)k / (double)M, &sn, &cs);
+    tw[k] = {cs, sn};
+  }
+  for (int j = threadIdx.x; j < M; j += kFftThreads) {
+    const int nn = j < N ? j : (j > M - N ? M - j : -1);
+    C<double> v = {0.0, 0.0};
+    if (nn >= 0) {
+      const int k2 = (int)(((int64_t)nn * nn) % (2 * (int64_t)N));
+      double sn, cs;
+      sincospi((double)k2 / (double)N, &sn, &cs);  // conj(c_n) = exp(+i pi n^2 / N)
+      v = {cs, sn};
+    }
+    buf[j] = v;
+  }
+  __syncthreads();
+  dmm_fft::fft_dif<double, kFftThreads>(buf, tw, 1, M, logM, P);
+  const double inv = 1.0 / (double)M;
+  double2* out = table + bf_off[ir];
+  for (int k = threadIdx.x; k < M; k += kFftThreads) out[k] = make_double2(buf[k].x * inv, buf[k].y * inv);
 }
 
 // ---------------------------------------------------------------- analysis, stage 2'
@@ -442,10 +658,9 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
   constexpr int NV = NPOL == 4 ? 8 : 2;                 // reduced reals per l
   constexpr int L = kAnalBatch;
   constexpr int kGroup = 64 / NV;                       // lanes per reduced value
-  Coef* coef = reinterpret_cast<Coef*>(smem);           // [nl]
-  double* out = reinterpret_cast<double*>(coef + nl);   // [nl][NV] block totals
+  const kptr coef = (kptr)p.g.coef + 8 * coef_row0(m, lmax);   // [nl][8], wave-uniform scalar loads
+  double* out = reinterpret_cast<double*>(smem);        // [nl][NV] block totals
   double* part = out + (size_t)nl * NV;                 // [2][NW][L][NV] per-wave totals of one batch
-  fill_coef(coef, m, lmax);
   for (int i = threadIdx.x; i < nl * NV; i += kThreads) out[i] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -486,12 +701,15 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
         R[t].ga[q] = make_double2(n.x - s.x, n.y - s.y);
       }
     }
+    Coef qn = load_coef(coef);
     for (int k0 = 0; k0 < nl; k0 += L) {
 #pragma unroll
       for (int kk = 0; kk < L; ++kk) {
         const int k = k0 + kk;
         if (k >= nl) break;
-        const Coef q = coef[k];
+        const Coef q = qn;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // drain the previous fetch before issuing the next (see k_leg_synth)
+        qn = load_coef(coef + 8 * (k + 1 < nl ? k + 1 : nl - 1));
         double v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = 0.0;
@@ -516,19 +734,19 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
             v[0] = fma(gT.x, g.lam, v[0]);
             v[1] = fma(gT.y, g.lam, v[1]);
             if (NPOL == 4) {
-              const double2 gV = even ? g.gs[3] : g.ga[3];
-              v[6] = fma(gV.x, g.lam, v[6]);
-              v[7] = fma(gV.y, g.lam, v[7]);
+              const double2 gV = even ? g.gs[NPOL - 1] : g.ga[NPOL - 1];
+              v[NV - 2] = fma(gV.x, g.lam, v[NV - 2]);
+              v[NV - 1] = fma(gV.y, g.lam, v[NV - 1]);
               const double F1 = fma(q.cd * g.xs2, g.lam_prev, -fma(q.c1, g.inv_s2, q.c2) * g.lam);
               const double F2 = fma(q.c4 * g.inv_s2, g.lam_prev, -q.c3 * g.xs2 * g.lam);
               // F1 pairs with the lambda-parity combination, F2 with the opposite one
-              const double2 Q1 = even ? g.gs[1] : g.ga[1], Q2 = even ? g.ga[1] : g.gs[1];
-              const double2 U1 = even ? g.gs[2] : g.ga[2], U2 = even ? g.ga[2] : g.gs[2];
+              const double2 Q1 = even ? g.gs[NPOL > 1 ? 1 : 0] : g.ga[NPOL > 1 ? 1 : 0], Q2 = even ? g.ga[NPOL > 1 ? 1 : 0] : g.gs[NPOL > 1 ? 1 : 0];
+              const double2 U1 = even ? g.gs[NPOL > 2 ? 2 : 0] : g.ga[NPOL > 2 ? 2 : 0], U2 = even ? g.ga[NPOL > 2 ? 2 : 0] : g.gs[NPOL > 2 ? 2 : 0];
               // E = -(F1 gQ + i F2 gU),  B = -(F1 gU - i F2 gQ)
-              v[2] -= F1 * Q1.x - F2 * U2.y;
-              v[3] -= F1 * Q1.y + F2 * U2.x;
-              v[4] -= F1 * U1.x + F2 * Q2.y;
-              v[5] -= F1 * U1.y - F2 * Q2.x;
+              v[NV > 2 ? 2 : 0] -= F1 * Q1.x - F2 * U2.y;
+              v[NV > 2 ? 3 : 0] -= F1 * Q1.y + F2 * U2.x;
+              v[NV > 2 ? 4 : 0] -= F1 * U1.x + F2 * Q2.y;
+              v[NV > 2 ? 5 : 0] -= F1 * U1.y - F2 * Q2.x;
             }
           }
         }
@@ -582,6 +800,20 @@ int get_geom(dmm_ctx* ctx, int nside, int lmax, int mmax, ShtGeom* out) {
   const int nring = 4 * nside - 1;
   const size_t nd = (size_t)3 * nring + (mmax + 1);
   const size_t bytes = nd * sizeof(double) + (size_t)nring * sizeof(int64_t) + (size_t)nring * sizeof(int);
+  const size_t coef_ofs = (bytes + 63) / 64 * 64;
+  const size_t coef_rows = (size_t)coef_row0(mmax + 1, lmax);
+  // Bluestein spectra of the cap rings
+  int blue_rmax = 0;
+  std::vector<int64_t> bf_off(1, 0);
+  int64_t bf_total = 0;
+  for (int ir = 1; ir < nside && blue_len(ir) <= kMaxBlue; ++ir) {
+    bf_off.push_back(bf_total);
+    bf_total += blue_len(ir);
+    blue_rmax = ir;
+  }
+  const size_t bfo_ofs = coef_ofs + coef_rows * sizeof(Coef);
+  const size_t bf_ofs = (bfo_ofs + bf_off.size() * sizeof(int64_t) + 63) / 64 * 64;
+  const size_t total = bf_ofs + (size_t)bf_total * sizeof(double2);
   if (it == ctx->sht.end()) {
     std::vector<unsigned char> h(bytes);
     double* z = reinterpret_cast<double*>(h.data());
@@ -620,8 +852,24 @@ int get_geom(dmm_ctx* ctx, int nside, int lmax, int mmax, ShtGeom* out) {
       lfac[m] = 0.5 * (log2(2.0 * m + 1.0) - log2(4.0 * M_PI) + prod);
     }
     void* d = nullptr;
-    DMM_HIP(hipMalloc(&d, bytes));
+    DMM_HIP(hipMalloc(&d, total));
+    unsigned char* db = static_cast<unsigned char*>(d);
     hipError_t e = hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db + bfo_ofs, bf_off.data(), bf_off.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_fill_coef, dim3(mmax + 1), dim3(256), 0, ctx->stream, reinterpret_cast<Coef*>(db + coef_ofs), lmax);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && blue_rmax > 0) {
+      const int Mmax = blue_len(blue_rmax);
+      const size_t lds = ((size_t)Mmax + 1 + Mmax / 2) * sizeof(double2);
+      e = hipFuncSetAttribute((const void*)k_build_bfilt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_build_bfilt, dim3(blue_rmax), dim3(kFftThreads), lds, ctx->stream,
+                           reinterpret_cast<double2*>(db + bf_ofs), reinterpret_cast<const int64_t*>(db + bfo_ofs));
+        e = hipGetLastError();
+      }
+    }
     if (e != hipSuccess) {
       (void)hipFree(d);
       return dmm_set_error((int)e, "sht geometry upload: %s", hipGetErrorString(e));
@@ -640,6 +888,11 @@ int get_geom(dmm_ctx* ctx, int nside, int lmax, int mmax, ShtGeom* out) {
   g.lfac = g.phi0 + nring;
   g.start = reinterpret_cast<int64_t*>(g.lfac + (mmax + 1));
   g.nphi = reinterpret_cast<int*>(g.start + nring);
+  unsigned char* gb = static_cast<unsigned char*>(g.block);
+  g.coef = reinterpret_cast<double*>(gb + coef_ofs);
+  g.bf_off = reinterpret_cast<int64_t*>(gb + bfo_ofs);
+  g.bfilt = reinterpret_cast<double2*>(gb + bf_ofs);
+  g.blue_rmax = blue_rmax;
   *out = g;
   return DMM_OK;
 }
@@ -661,6 +914,63 @@ size_t chunk_freqs(int nfreq, int npol, int nring, int mmax) {
   return nf;
 }
 
+// the ring classes of a geometry (see RingClass) with the launch shape of each
+struct ClassLaunch {
+  RingClass rc;
+  int nblock;       // rings in the class
+  int nphi_max;     // pixels of its largest ring
+  bool blue;        // Bluestein (caps) or plain FFT (belt)
+};
+
+std::vector<ClassLaunch> ring_classes(const ShtGeom& g) {
+  std::vector<ClassLaunch> out;
+  ClassLaunch b;
+  b.rc.belt = 1;
+  b.rc.r_lo = b.rc.r_hi = 0;
+  b.rc.M = 4 * g.nside;
+  b.rc.logM = 0;
+  while ((1 << b.rc.logM) < b.rc.M) ++b.rc.logM;
+  b.nblock = 2 * g.nside + 1;
+  b.nphi_max = 4 * g.nside;
+  b.blue = false;
+  out.push_back(b);
+  for (int ir = 1; ir < g.nside;) {
+    const int M = blue_len(ir);
+    int hi = ir;
+    while (hi + 1 < g.nside && blue_len(hi + 1) == M) ++hi;
+    ClassLaunch c;
+    c.rc.belt = 0;
+    c.rc.r_lo = ir;
+    c.rc.r_hi = hi;
+    c.rc.M = M;
+    c.rc.logM = 0;
+    while ((1 << c.rc.logM) < M) ++c.rc.logM;
+    c.nblock = 2 * (hi - ir + 1);
+    c.nphi_max = 4 * hi;
+    c.blue = true;
+    out.push_back(c);
+    ir = hi + 1;
+  }
+  return out;
+}
+
+// LDS bytes of the FFT ring kernels for a class; 0 if the class must take the direct kernel
+size_t ring_fft_lds(const ShtGeom& g, const ClassLaunch& c, int nrow, int force_direct) {
+  if (force_direct) return 0;
+  if (c.blue && c.rc.r_hi > g.blue_rmax) return 0;
+  const size_t lds = ((size_t)nrow * (c.rc.M + 1) + c.rc.M / 2 + (c.blue ? c.nphi_max : 0)) * sizeof(double2);
+  return lds <= 160 * 1024 ? lds : 0;
+}
+
+template <typename K>
+int launch_ring(K kern, dim3 grid, int threads, size_t lds, hipStream_t st, const RingParams& rp, const RingClass& rc) {
+  if (lds > 160 * 1024) return dmm_set_error(DMM_E_UNSUPPORTED, "SHT ring stage needs %zu bytes of LDS (nside too large)", lds);
+  DMM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, rp, rc);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
 template <int NPOL>
 int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int nf, double2* b, double* map) {
   LegParams lp;
@@ -670,9 +980,12 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   lp.n_m = n_m;
   lp.alm = alm;
   lp.b = b;
-  const size_t lds1 = (size_t)(g.lmax + 1) * (sizeof(Coef) + NPOL * sizeof(double2));
-  DMM_HIP(hipFuncSetAttribute((const void*)k_leg_synth<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-  hipLaunchKernelGGL(k_leg_synth<NPOL>, dim3(g.mmax + 1, nf), dim3(kThreads), lds1, ctx->stream, lp);
+  switch (ctx->opt_sht_variant & 3) {
+    case 1: hipLaunchKernelGGL((k_leg_synth<NPOL, 1, 1>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;
+    case 2: hipLaunchKernelGGL((k_leg_synth<NPOL, 2, 1>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;
+    case 3: hipLaunchKernelGGL((k_leg_synth<NPOL, 1, 6>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;
+    default: hipLaunchKernelGGL((k_leg_synth<NPOL, 2, 4>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;
+  }
   DMM_HIP(hipGetLastError());
   RingParams rp;
   rp.g = g;
@@ -681,19 +994,19 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   rp.b = b;
   rp.map = map;
   rp.npix = 12LL * g.nside * g.nside;
-  const size_t lds2 = (size_t)NPOL * (g.mmax + 1) * sizeof(double2);
-  const int ncap2 = 2 * (g.nside - 1);  // polar-cap rings: direct sums
-  if (ncap2 > 0) {
-    DMM_HIP(hipFuncSetAttribute((const void*)k_ring_synth<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(k_ring_synth<NPOL>, dim3(ncap2, nf), dim3(kThreads), lds2, ctx->stream, rp);
+  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  const int force_direct = ctx->opt_sht_variant & 4;
+  for (const ClassLaunch& c : ring_classes(g)) {
+    const size_t lds = ring_fft_lds(g, c, NROW, force_direct);
+    int rc;
+    if (lds == 0)
+      rc = launch_ring(k_ring_synth<NPOL>, dim3(c.nblock, nf), kThreads, (size_t)NPOL * (g.mmax + 1) * sizeof(double2), ctx->stream, rp, c.rc);
+    else if (c.blue)
+      rc = launch_ring(k_ring_synth_fft<NPOL, true>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
+    else
+      rc = launch_ring(k_ring_synth_fft<NPOL, false>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
+    if (rc) return rc;
   }
-  // equatorial belt: in-LDS FFT, two polarisations per complex transform
-  const int n = 4 * g.nside;
-  const size_t lds3 = ((size_t)(NPOL == 4 ? 2 : 1) * (n + 1) + n / 2) * sizeof(double2);
-  if (lds3 > 160 * 1024) return dmm_set_error(DMM_E_UNSUPPORTED, "alm2map: nside=%d too large for the in-LDS ring FFT", g.nside);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_ring_synth_fft<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-  hipLaunchKernelGGL(k_ring_synth_fft<NPOL>, dim3(2 * g.nside + 1, nf), dim3(kFftThreads), lds3, ctx->stream, rp);
-  DMM_HIP(hipGetLastError());
   return DMM_OK;
 }
 
@@ -706,10 +1019,19 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   rp.b = b;
   rp.map = const_cast<double*>(map);
   rp.npix = 12LL * g.nside * g.nside;
-  const size_t lds1 = (size_t)NPOL * 4 * g.nside * sizeof(double);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_ring_anal<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-  hipLaunchKernelGGL(k_ring_anal<NPOL>, dim3(g.nring, nf), dim3(kThreads), lds1, ctx->stream, rp);
-  DMM_HIP(hipGetLastError());
+  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  const int force_direct = ctx->opt_sht_variant & 4;
+  for (const ClassLaunch& c : ring_classes(g)) {
+    const size_t lds = ring_fft_lds(g, c, NROW, force_direct);
+    int rc;
+    if (lds == 0)
+      rc = launch_ring(k_ring_anal<NPOL>, dim3(c.nblock, nf), kThreads, (size_t)NPOL * c.nphi_max * sizeof(double), ctx->stream, rp, c.rc);
+    else if (c.blue)
+      rc = launch_ring(k_ring_anal_fft<NPOL, true>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
+    else
+      rc = launch_ring(k_ring_anal_fft<NPOL, false>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
+    if (rc) return rc;
+  }
   LegAnalParams lp;
   lp.g = g;
   lp.nf = nf;
@@ -719,7 +1041,7 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   lp.alm = alm;
   lp.accumulate = accumulate;
   constexpr int NV = NPOL == 4 ? 8 : 2;
-  const size_t lds2 = (size_t)(g.lmax + 1) * (sizeof(Coef) + NV * sizeof(double)) + (size_t)2 * (kThreads / 64) * kAnalBatch * NV * sizeof(double);
+  const size_t lds2 = (size_t)(g.lmax + 1) * NV * sizeof(double) + (size_t)2 * (kThreads / 64) * kAnalBatch * NV * sizeof(double);
   DMM_HIP(hipFuncSetAttribute((const void*)k_leg_anal<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
   hipLaunchKernelGGL(k_leg_anal<NPOL>, dim3(g.mmax + 1, nf), dim3(kThreads), lds2, ctx->stream, lp);
   DMM_HIP(hipGetLastError());

@@ -26,8 +26,9 @@ class Context:
     """Owns a ``dmm_ctx`` bound to ``cuda:<device>`` and torch's current stream on it."""
 
     _cache: dict[int, "Context"] = {}
+    _side_cache: dict[int, "Context"] = {}
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, stream: "torch.cuda.Stream | None" = None):
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "draco_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback."
@@ -37,6 +38,7 @@ class Context:
         h = C.c_void_p()
         _lib.check(_lib.lib.dmm_ctx_create(self.device_index, C.byref(h)))
         self.handle = h
+        self.stream = stream  # None: follow torch's current stream; else pinned to this one
         self.bind_stream()
 
     @classmethod
@@ -49,9 +51,39 @@ class Context:
         ctx.bind_stream()
         return ctx
 
+    @classmethod
+    def side(cls, device: int | None = None) -> "Context":
+        """A second ``dmm_ctx`` of the same GPU pinned to its own stream (own scratch, own tables).
+
+        For stages that can run beside the main stream's work, e.g. the compute-bound alm2map of
+        finished frequencies under the HBM-bound solves of the next slab.  Order the two with
+        events: ``side.wait_for(main_stream)`` before launching, ``side.join(main_stream)`` after.
+        """
+        if device is None:
+            device = torch.cuda.current_device()
+        if device not in cls._side_cache:
+            dev = torch.device("cuda", device)
+            try:  # lowest priority the device offers: side work yields to the main stream's kernels
+                least = int(torch.cuda.Stream.priority_range()[0])
+                st = torch.cuda.Stream(device=dev, priority=least)
+            except Exception:
+                st = torch.cuda.Stream(device=dev)
+            cls._side_cache[device] = cls(device, st)
+        return cls._side_cache[device]
+
+    def wait_for(self, other: "torch.cuda.Stream"):
+        """Work launched on this (pinned) context after the call starts after ``other``'s work so far."""
+        ev = torch.cuda.Event()
+        ev.record(other)
+        self.stream.wait_event(ev)
+
+    def join(self, other: "torch.cuda.Stream"):
+        """``other``'s later work waits for everything launched on this (pinned) context so far."""
+        other.wait_stream(self.stream)
+
     def bind_stream(self):
         """Launch on torch's current stream of this device (so torch allocations/copies order with kernels)."""
-        s = torch.cuda.current_stream(self.device).cuda_stream
+        s = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
         _lib.check(_lib.lib.dmm_ctx_set_stream(self.handle, C.c_void_p(s)))
 
     def sync(self):

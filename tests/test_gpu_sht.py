@@ -112,6 +112,31 @@ def test_sht_roundtrip_larger():
     assert np.abs(back - alm).max() < 1e-6 * np.abs(alm).max()
 
 
+@pytest.mark.parametrize("nside,lmax,npol", [(8, 23, 4), (64, 128, 4), (128, 200, 1), (256, 300, 4)])
+def test_ring_fft_vs_direct_sums(nside, lmax, npol):
+    """The FFT / Bluestein ring stages against the direct per-ring sums (sht_variant bit 2).
+
+    Covers every Bluestein class (M = 256 ... 2048 at nside 256), rings shorter than mmax
+    (folding modulo nphi) and both transforms; both evaluate the same sums, so 1e-12.
+    """
+    from draco_amd import _lib
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    rng = np.random.default_rng(nside)
+    alm = _rand_alm(rng, 2, npol, lmax)
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"sht_variant", 4))
+        m_direct = _alm2map_gpu(alm, nside)
+        a_direct = _map2alm_gpu(m_direct, lmax, lmax, 0)
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"sht_variant", 0))
+    m_fft = _alm2map_gpu(alm, nside)
+    a_fft = _map2alm_gpu(m_direct, lmax, lmax, 0)
+    assert np.abs(m_fft - m_direct).max() < 1e-12 * np.abs(m_direct).max()
+    assert np.abs(a_fft - a_direct).max() < 1e-12 * np.abs(a_direct).max()
+
+
 def _tel(nfreq, lmax, ncyl=1, nfeed_cyl=3):
     from draco_amd.core.products import TransitTelescope
 
