@@ -91,7 +91,16 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_inner_sweeps")) c->opt_ml_inner_sweeps = (int)value;
   else if (!strcmp(name, "ml_outer_sweeps")) c->opt_ml_outer_sweeps = (int)value;
   else if (!strcmp(name, "sht_variant")) c->opt_sht_variant = (int)value;
+  else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_set_option: unknown option '%s'", name);
+  return DMM_OK;
+}
+
+int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
+  DMM_REQUIRE(c != nullptr && name != nullptr && value != nullptr, "dmm_ctx_get_counter: NULL argument");
+  if (!strcmp(name, "ml_tiles_direct")) *value = c->ml_tiles_direct;
+  else if (!strcmp(name, "ml_tiles_eigen")) *value = c->ml_tiles_eigen;
+  else return dmm_set_error(DMM_E_ARG, "dmm_ctx_get_counter: unknown counter '%s'", name);
   return DMM_OK;
 }
 

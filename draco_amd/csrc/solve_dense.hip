@@ -13,6 +13,18 @@
 //            with the columns kept where sqrt(L) > rcond*sqrt(L_max) and sqrt(L) > acond.
 // Rows with Ni = 0 decouple (unit diagonal / zero eigenvalue): no NaN, like the reference.
 //
+// ML, full-rank shortcut.  pinv_svd keeps sigma > rcond*sigma_max and sigma > acond; when NO
+// singular value of D B is cut the pseudo-inverse is an ordinary inverse:
+//   ntel <= nsky_m (telescope side):  a = B^H D (D B B^H D)^-1 D v
+//   nsky_m < ntel  (sky side):        a = (B^H Ni B)^-1 B^H Ni v     (the smaller Gram matrix)
+// and "nothing is cut" is CERTIFIED without an eigen-decomposition: with theta >= lambda_max
+// (theta = max row sum of |G|) and tau = max(rcond^2 theta, acond^2), the Cholesky factorisation
+// of G - tau I succeeds  <=>  lambda_min(G) > tau >= the reference's cut.  Tiles that pass are
+// solved by a second Cholesky (of G itself); tiles that fail -- some mode really is, or may be,
+// cut -- take the Jacobi eigen-decomposition of the same (smaller-side) Gram matrix.  Exactly
+// zero rows (masked baselines, structurally empty sky columns) are zero modes the reference
+// drops: they are pinned to a unit-scale diagonal and contribute nothing either way.
+//
 // Kernel structure (all batched over the matrices of a sub-batch):
 //   k_nt<GRAM>    G(I,J)  = [delta] + d_i d_j sum_k B[i,k] S_k conj(B[j,k])   64x64 tiles, f64 MFMA
 //   k_nt<UPDATE>  A(I,J) -= sum_{k<64J} L[i,k] conj(L[j,k])                   (left-looking Cholesky)
@@ -25,6 +37,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "dmm_internal.h"
@@ -38,7 +51,7 @@ constexpr int TB = 64;        // tile edge (rows and columns of an output tile)
 constexpr int KC = 16;        // complex columns per staged chunk
 constexpr int LP = 2 * KC + 2;  // LDS row pitch in doubles: == 2 (mod 32) -> conflict-free ds_read_b64
 
-enum { MODE_GRAM = 0, MODE_UPDATE = 1, MODE_PANEL = 2 };
+enum { MODE_GRAM = 0, MODE_UPDATE = 1, MODE_PANEL = 2, MODE_GRAMX = 3 };
 
 struct DenseParams {
   // batch
@@ -59,6 +72,15 @@ struct DenseParams {
   double2* Linv;           // [nmat][T][64][64]
   double2* wbuf;           // [nmat][N]
   int J;                   // current column block (update / panel / diag)
+  // ML extras
+  int sky;                 // 1: the matrices are sky-side (order npol*(lmax+1-m)), rhs/solution live in alm
+  const double2* X;        // [nmat][Np][ldx] rows of (D B)^H for the sky-side Gram (MODE_GRAMX)
+  int ldx;                 // row pitch of X (>= 2*npairs)
+  double2* alm;            // [nfreq][npol][n_m][lmax+1] (sky side: rhs in, solution out)
+  int n_m;
+  int* fail;               // [nmat] set when a Cholesky pivot is not positive (nullptr: not tracked)
+  const int* msel;         // Jacobi kernels: matrix index of the k-th selected matrix (nullptr: identity)
+  double* theta;           // [nmat] upper bound of the largest eigenvalue
 };
 
 __device__ __forceinline__ double2 load_bc(const void* B, int c128, int64_t off) {
@@ -125,10 +147,16 @@ __device__ __forceinline__ void fetch(double2 (&v)[4], const DenseParams& p, con
       const int k = k0 + c0 + c;
       v[c] = k < K ? p.A[((int64_t)mat * p.Np + row) * p.Np + k] : make_double2(0.0, 0.0);
     }
-  } else {
+  } else if (SRC == 2) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       v[c] = p.Linv[(((int64_t)mat * p.T + p.J) * TB + (row - row0)) * TB + k0 + c0 + c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = k0 + c0 + c;
+      v[c] = (row < p.N && k < K) ? p.X[((int64_t)mat * p.Np + row) * p.ldx + k] : make_double2(0.0, 0.0);
+    }
   }
 }
 
@@ -146,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
   const int mat = blockIdx.y;
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   int bi, bj;
-  if (MODE == MODE_GRAM) {
+  if (MODE == MODE_GRAM || MODE == MODE_GRAMX) {
     const int tt = blockIdx.x;
     bi = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= tt) ++bi;
@@ -160,7 +188,10 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
     bj = p.J;
   }
   const int I0 = bi * TB, J0 = bj * TB;
-  const int K = MODE == MODE_GRAM ? p.npol * (p.lmax + 1 - tile.m) : (MODE == MODE_UPDATE ? p.J * TB : TB);
+  const int K = MODE == MODE_GRAM    ? p.npol * (p.lmax + 1 - tile.m)
+                : MODE == MODE_GRAMX ? 2 * p.npairs
+                : MODE == MODE_UPDATE ? p.J * TB
+                                      : TB;
   const int kbase = MODE == MODE_PANEL ? J0 : 0;  // panel: X = A(I, J-block columns)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -177,6 +208,9 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
     if (MODE == MODE_GRAM) {
       fetch<0>(xr, p, tile, mat, I0, k0, K, false);
       fetch<0>(yr, p, tile, mat, J0, k0, K, true);
+    } else if (MODE == MODE_GRAMX) {
+      fetch<3>(xr, p, tile, mat, I0, k0, K, false);
+      fetch<3>(yr, p, tile, mat, J0, k0, K, false);
     } else if (MODE == MODE_UPDATE) {
       fetch<1>(xr, p, tile, mat, I0, k0, K, false);
       fetch<1>(yr, p, tile, mat, J0, k0, K, false);
@@ -240,6 +274,9 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
             if (p.add_identity) re += 1.0;  // padded rows (d = 0): unit diagonal for Cholesky, zero eigenvalue for ML
           }
           *dst = make_double2(re, im);
+        } else if (MODE == MODE_GRAMX) {
+          if (i == j) im = 0.0;
+          *dst = make_double2(re, im);
         } else if (MODE == MODE_UPDATE) {
           const double2 old = *dst;
           *dst = make_double2(old.x - re, old.y - im);
@@ -263,7 +300,9 @@ __global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
   }
   __syncthreads();
   for (int k = 0; k < TB; ++k) {
-    const double d = sqrt(a[k][k].x);
+    const double akk = a[k][k].x;
+    if (p.fail && threadIdx.x == 0 && !(akk > 0.0)) p.fail[mat] = 1;  // not positive definite (NaN included)
+    const double d = sqrt(akk);
     const double inv = 1.0 / d;
     __syncthreads();
     if (threadIdx.x == 0) a[k][k] = make_double2(d, 0.0);
@@ -318,14 +357,20 @@ __global__ __launch_bounds__(kThreads) void k_chol_solve(DenseParams p) {
   const int mat = blockIdx.x;
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   const double2* A = p.A + (int64_t)mat * p.Np * p.Np;
+  const int Lsky = p.lmax + 1 - tile.m;
   for (int i = threadIdx.x; i < p.Np; i += kThreads) {
     double2 b = make_double2(0.0, 0.0);
     if (i < p.N) {
-      const int s = i >= p.npairs, pp = i - s * p.npairs;
-      const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
-      const double d = sqrt(p.mweight[o]);
-      const double2 v = p.mvis[o];
-      b = make_double2(d * v.x, d * v.y);
+      if (p.sky) {  // rhs = B^H Ni v, left in alm by the dirty pass
+        const int pol = i / Lsky, lrel = i - pol * Lsky;
+        b = p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel];
+      } else {
+        const int s = i >= p.npairs, pp = i - s * p.npairs;
+        const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
+        const double d = sqrt(p.mweight[o]);
+        const double2 v = p.mvis[o];
+        b = make_double2(d * v.x, d * v.y);
+      }
     }
     y[i] = b;
   }
@@ -395,10 +440,89 @@ __global__ __launch_bounds__(kThreads) void k_chol_solve(DenseParams p) {
     }
     __syncthreads();
   }
+  if (p.fail && p.fail[mat]) return;  // not certified: the eigen path owns this tile's output
   for (int i = threadIdx.x; i < p.N; i += kThreads) {
-    const int s = i >= p.npairs, pp = i - s * p.npairs;
-    const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
-    p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * y[i].x, d * y[i].y);
+    if (p.sky) {
+      const int pol = i / Lsky, lrel = i - pol * Lsky;
+      p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel] = y[i];
+    } else {
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+      p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * y[i].x, d * y[i].y);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- ML: certificate of "nothing cut"
+// X[mat][k][i] = d_i conj(B[i][k]): the rows of (D B)^H, so that the NT tile product gives B^H Ni B
+__global__ __launch_bounds__(kThreads) void k_xpose(DenseParams p, double2* X) {
+  __shared__ double2 t[32][33];
+  const int mat = blockIdx.z;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  const int L = p.lmax + 1 - tile.m, K = p.npol * L, ntel = 2 * p.npairs;
+  const int k0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, k = k0 + tx;
+    double2 v = make_double2(0.0, 0.0);
+    if (i < ntel && k < K) {
+      const int pol = k / L, lrel = k - pol * L;
+      const int64_t off = tile.b_off + ((int64_t)i * p.npol + pol) * pol_stride + (p.full_layout ? tile.m : 0) + lrel;
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+      const double2 b = load_bc(p.B, p.b_c128, off);
+      v = make_double2(d * b.x, -d * b.y);
+    }
+    t[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, i = i0 + tx;
+    if (k < K && i < ntel) X[((int64_t)mat * p.Np + k) * p.ldx + i] = t[tx][r];
+  }
+}
+
+// theta[mat] = max_i sum_j |A_ij| >= lambda_max (A Hermitian, full storage); one block per matrix
+__global__ __launch_bounds__(kThreads) void k_rowsum(DenseParams p) {
+  __shared__ double red[kThreads / 64];
+  const int mat = blockIdx.x, n = p.Np;
+  const double2* A = p.A + (int64_t)mat * n * n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double best = 0.0;
+  for (int i = wave; i < p.N; i += kThreads / 64) {
+    double sum = 0.0;
+    for (int j = lane; j < p.N; j += 64) {
+      const double2 v = A[(int64_t)i * n + j];
+      sum += sqrt(v.x * v.x + v.y * v.y);
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    best = fmax(best, sum);
+  }
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) m = fmax(m, red[w]);
+    p.theta[mat] = m;
+  }
+}
+
+// C = A - shift*I with the zero modes pinned: rows that are exactly zero (and the padding) get the
+// diagonal theta.  shift = max(rcond2 * theta, acond2) when `shifted`, else 0.
+__global__ __launch_bounds__(kThreads) void k_shift_copy(DenseParams p, double2* C, int shifted, double rcond2, double acond2) {
+  const int mat = blockIdx.y, n = p.Np;
+  const double2* A = p.A + (int64_t)mat * n * n;
+  double2* dst = C + (int64_t)mat * n * n;
+  const double th = p.theta[mat];
+  const double pin = th > 0.0 ? th : 1.0;
+  const double shift = shifted ? fmax(rcond2 * th, acond2) : 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    double2 v = A[idx];
+    if (i == j) v = (i >= p.N || v.x == 0.0) ? make_double2(pin, 0.0) : make_double2(v.x - shift, 0.0);
+    dst[idx] = v;
   }
 }
 
@@ -465,7 +589,7 @@ struct BjParams {
 
 __global__ __launch_bounds__(kThreads) void k_bj_init(BjParams bp) {  // V = I, scale = max diag
   const DenseParams& p = bp.d;
-  const int mat = blockIdx.y, n = p.Np;
+  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y, n = p.Np;
   double2* V = bp.V + (int64_t)mat * n * n;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -499,7 +623,7 @@ __global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
   __shared__ int pa[M / 2], pb[M / 2];
   __shared__ int any_rot, need, work;
   const DenseParams& p = bp.d;
-  const int pr = blockIdx.x, mat = blockIdx.y, n = p.Np;
+  const int pr = blockIdx.x, mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y, n = p.Np;
   int P, Q;
   rr_pair(bp.round, pr, bp.nb, P, Q);
   const int P0 = P * JB, Q0 = Q * JB;
@@ -612,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void k_bj_apply(BjParams bp) {
   __shared__ __align__(16) double xs[TB * LP];
   __shared__ __align__(16) double ys[TB * LP];
   const DenseParams& p = bp.d;
-  const int tileidx = blockIdx.x, pr = blockIdx.y, mat = blockIdx.z, n = p.Np;
+  const int tileidx = blockIdx.x, pr = blockIdx.y, mat = p.msel ? p.msel[blockIdx.z] : blockIdx.z, n = p.Np;
   if (!bp.flag[(int64_t)mat * (bp.nb / 2) + pr]) return;
   int P, Q;
   rr_pair(bp.round, pr, bp.nb, P, Q);
@@ -697,18 +821,24 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
   double2* b = reinterpret_cast<double2*>(smem);  // [n]  D v
   double2* c = b + n;                             // [n]  coefficients
   __shared__ double lam_max;
-  const int mat = blockIdx.x;
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   const double2* A = p.A + (int64_t)mat * n * n;
   const double2* V = jp.V + (int64_t)mat * n * n;
+  const int Lsky = p.lmax + 1 - tile.m;
   for (int i = threadIdx.x; i < n; i += kThreads) {
     double2 v = make_double2(0.0, 0.0);
     if (i < p.N) {
-      const int s = i >= p.npairs, pp = i - s * p.npairs;
-      const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
-      const double d = sqrt(p.mweight[o]);
-      const double2 x = p.mvis[o];
-      v = make_double2(d * x.x, d * x.y);
+      if (p.sky) {
+        const int pol = i / Lsky, lrel = i - pol * Lsky;
+        v = p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel];
+      } else {
+        const int s = i >= p.npairs, pp = i - s * p.npairs;
+        const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
+        const double d = sqrt(p.mweight[o]);
+        const double2 x = p.mvis[o];
+        v = make_double2(d * x.x, d * x.y);
+      }
     }
     b[i] = v;
   }
@@ -744,9 +874,14 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
       acc.x += u.x * x.x - u.y * x.y;
       acc.y += u.x * x.y + u.y * x.x;
     }
-    const int s = i >= p.npairs, pp = i - s * p.npairs;
-    const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
-    p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * acc.x, d * acc.y);
+    if (p.sky) {
+      const int pol = i / Lsky, lrel = i - pol * Lsky;
+      p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel] = acc;
+    } else {
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+      p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * acc.x, d * acc.y);
+    }
   }
 }
 
@@ -773,7 +908,7 @@ Layout layout_of(const dmm_plan* pl, bool ml) {
   const size_t a = (size_t)L.Np * L.Np * sizeof(double2);
   const size_t aux = ml ? a : (size_t)L.T * TB * TB * sizeof(double2);
   L.per_mat = a + aux + (size_t)L.N * sizeof(double2);
-  L.per_mat_extra = ml ? (size_t)(L.Np / 64) * TB * TB * sizeof(double2) + (size_t)(L.Np / 64) * sizeof(int) + 32 : 0;
+  L.per_mat_extra = ml ? (size_t)(L.Np / 64) * TB * TB * sizeof(double2) + (size_t)(L.Np / 64) * sizeof(int) + 32 + 64 : 0;  // + theta, tile, work, fail, msel
   L.header = ((size_t)(pl->lmax + 1) * sizeof(double) + 255) / 256 * 256;
   return L;
 }
@@ -816,6 +951,14 @@ DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, cons
   q += (size_t)nmat_cap * (L.per_mat - (size_t)L.Np * L.Np * sizeof(double2) - (size_t)L.N * sizeof(double2));
   p.wbuf = (double2*)q;
   p.J = 0;
+  p.sky = 0;
+  p.X = nullptr;
+  p.ldx = 0;
+  p.alm = nullptr;
+  p.n_m = pl->n_m;
+  p.fail = nullptr;
+  p.msel = nullptr;
+  p.theta = nullptr;
   return p;
 }
 
@@ -824,6 +967,8 @@ DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, cons
 // implemented in solve_dirty.hip: a = S o B^H w over tiles [tile0, tile0+nmat)
 int dmm_dirty_w_launch(dmm_plan* pl, const void* B, const double2* wbuf, const double* Sl, int64_t tile0, int nmat,
                        void* alm);
+int dmm_dirty_w_launch_list(dmm_plan* pl, const void* B, const double2* wbuf, const double* Sl, const dmm_tile* tiles_d,
+                            const int32_t* work_d, int nmat, int64_t nwork, void* alm);
 
 extern "C" {
 
@@ -876,65 +1021,193 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   if (pl->ntile == 0) return DMM_OK;
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
-  const Layout L = layout_of(pl, true);
+  const Layout L = layout_of(pl, true);  // telescope-side order: the largest any batch uses
   const int64_t wsb = dmm_ml_workspace_bytes(pl);
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
-  JacobiParams jp;
-  jp.d = make_params(pl, L, B, mvis, mweight, ws, cap);
-  jp.V = jp.d.Linv;
-  jp.acond = acond;
-  jp.rcond = rcond;
-  jp.max_sweeps = ctx->opt_ml_outer_sweeps > 0 ? ctx->opt_ml_outer_sweeps : 60;
-  BjParams bp;
-  bp.inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;  // tools/ml_tune.py: one inner sweep per visit is fastest at equal accuracy
-  bp.V = jp.V;
-  bp.nb = L.Np / JB;
-  const int npr = bp.nb / 2;
-  // pair buffers live behind the per-matrix regions (sized in layout_of)
-  unsigned char* extra = (unsigned char*)(jp.d.wbuf + (size_t)cap * L.N);
+  const DenseParams base = make_params(pl, L, B, mvis, mweight, ws, cap);
+  double2* const Abuf = base.A;      // [cap] Gram matrices (kept intact for the eigen fallback)
+  double2* const Vbuf = base.Linv;   // [cap] X, then the Cholesky copies, then the eigenvectors
+  // small per-batch arrays live behind the per-matrix regions (sized in layout_of)
+  unsigned char* extra = (unsigned char*)(base.wbuf + (size_t)cap * L.N);
   extra = (unsigned char*)(((uintptr_t)extra + 255) & ~(uintptr_t)255);
-  bp.Wh = (double2*)extra;
-  bp.flag = (int*)(bp.Wh + (size_t)cap * npr * TB * TB);
-  bp.scale = (double*)(bp.flag + (((size_t)cap * npr + 1) & ~(size_t)1));
-  bp.any_rot = (int*)(bp.scale + cap);
-  const size_t sub_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
-  const size_t fil_lds = (size_t)2 * L.Np * sizeof(double2);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_bj_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
-  DMM_HIP(hipFuncSetAttribute((const void*)k_ml_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fil_lds));
-  for (int64_t t0 = 0; t0 < pl->ntile; t0 += cap) {
-    const int nmat = (int)std::min<int64_t>(cap, pl->ntile - t0);
-    jp.d.tile0 = t0;
-    jp.d.nmat = nmat;
-    bp.d = jp.d;
-    hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(L.T * (L.T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
-    hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, jp.d);
-    hipLaunchKernelGGL(k_bj_init, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, bp);
-    for (int sweep = 0; sweep < jp.max_sweeps; ++sweep) {
-      DMM_HIP(hipMemsetAsync(bp.any_rot, 0, sizeof(int), ctx->stream));
-      for (int round = 0; round < bp.nb - 1; ++round) {
-        bp.round = round;
-        hipLaunchKernelGGL(k_bj_sub, dim3(npr, nmat), dim3(kThreads), sub_lds, ctx->stream, bp);
-        bp.target = 0;
-        hipLaunchKernelGGL(k_bj_apply, dim3(L.T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
-        bp.target = 2;
-        hipLaunchKernelGGL(k_bj_apply, dim3(L.T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
-        bp.target = 1;
-        hipLaunchKernelGGL(k_bj_apply, dim3(L.T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
-      }
-      // converged when a whole sweep found every pair diagonal to working precision
-      int any = 1;
-      DMM_HIP(hipMemcpyAsync(&any, bp.any_rot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      DMM_HIP(hipStreamSynchronize(ctx->stream));
-      if (!any) break;
-      if (sweep == jp.max_sweeps - 1)
-        return dmm_set_error(DMM_E_STATE, "dmm_ml_run: Jacobi did not converge in %d sweeps", jp.max_sweeps);
-    }
-    hipLaunchKernelGGL(k_ml_filter, dim3(nmat), dim3(kThreads), fil_lds, ctx->stream, jp);
-    DMM_HIP(hipGetLastError());
-    int rc = dmm_dirty_w_launch(pl, B, jp.d.wbuf, nullptr, t0, nmat, alm);
+  double2* const Whbuf = (double2*)extra;  // pair rotations (Jacobi) / inverted diagonal blocks (Cholesky)
+  unsigned char* q = (unsigned char*)(Whbuf + (size_t)cap * (L.Np / 64) * TB * TB);
+  int* const flag_d = (int*)q;
+  q += (((size_t)cap * (L.Np / 64) + 1) & ~(size_t)1) * sizeof(int);
+  double* const scale_d = (double*)q;
+  q += (size_t)cap * sizeof(double);
+  double* const theta_d = (double*)q;
+  q += (size_t)cap * sizeof(double);
+  dmm_tile* const tiles_d = (dmm_tile*)q;
+  q += (size_t)cap * sizeof(dmm_tile);
+  int32_t* const work_d = (int32_t*)q;
+  q += (((size_t)cap + 2) & ~(size_t)1) * sizeof(int32_t);
+  int* const fail_d = (int*)q;
+  q += (((size_t)cap + 1) & ~(size_t)1) * sizeof(int);
+  int* const msel_d = (int*)q;
+  q += (((size_t)cap + 1) & ~(size_t)1) * sizeof(int);
+  int* const any_rot_d = (int*)q;
+
+  const int ntel = 2 * pl->npairs;
+  const bool shortcut = ctx->opt_ml_shortcut != 2;  // 2: always take the eigen path (tests, timing)
+  const int max_sweeps = ctx->opt_ml_outer_sweeps > 0 ? ctx->opt_ml_outer_sweeps : 60;
+  const int inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;  // tools/ml_tune.py
+
+  // the smaller Gram matrix of each tile: telescope side (any m) or sky side (tiles of one m share an order)
+  std::vector<int64_t> tel_list;
+  std::map<int, std::vector<int64_t>> sky_lists;
+  for (int64_t t = 0; t < pl->ntile; ++t) {
+    const int m = pl->tiles_h[t].m;
+    const int nsky = pl->npol * (pl->lmax + 1 - m);
+    if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);  // 3: telescope side only
+    else sky_lists[m].push_back(t);
+  }
+  if (!sky_lists.empty()) {  // B^H Ni v of every tile: the right-hand side of the sky-side systems
+    int rc = dmm_dirty_run(pl, B, mvis, mweight, alm);
     if (rc) return rc;
   }
+  const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);
+  const size_t diag_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
+  const size_t sub_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
+  const size_t fil_lds = (size_t)2 * L.Np * sizeof(double2);
+  DMM_HIP(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
+  DMM_HIP(hipFuncSetAttribute((const void*)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+  DMM_HIP(hipFuncSetAttribute((const void*)k_bj_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
+  DMM_HIP(hipFuncSetAttribute((const void*)k_ml_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fil_lds));
+
+  std::vector<dmm_tile> tiles_c;
+  std::vector<int32_t> work_c;
+  std::vector<int> fail_h, msel_h;
+  auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int m) -> int {
+    DenseParams p = base;
+    p.tiles = tiles_d;
+    p.tile0 = 0;
+    p.nmat = nmat;
+    p.sky = sky ? 1 : 0;
+    p.N = sky ? pl->npol * (pl->lmax + 1 - m) : ntel;
+    p.Np = (p.N + TB - 1) / TB * TB;
+    p.T = p.Np / TB;
+    p.alm = (double2*)alm;
+    p.theta = theta_d;
+    // the batch's tiles (and, telescope side, the column-block prefix of the back-projection)
+    tiles_c.resize(nmat);
+    work_c.assign(nmat + 1, 0);
+    for (int i = 0; i < nmat; ++i) {
+      tiles_c[i] = pl->tiles_h[list[i0 + i]];
+      const int ncol = pl->npol * (pl->lmax + 1 - tiles_c[i].m);
+      work_c[i + 1] = work_c[i] + (ncol + pl->cols_per_block - 1) / pl->cols_per_block;
+    }
+    DMM_HIP(hipMemcpyAsync(tiles_d, tiles_c.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, ctx->stream));
+    DMM_HIP(hipMemcpyAsync(work_d, work_c.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    DMM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors are reused by the next batch
+    const int T = p.T;
+    if (sky) {
+      p.ldx = ntel;
+      p.X = Vbuf;
+      hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf);
+      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+    } else {
+      hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+    }
+    hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
+    DMM_HIP(hipGetLastError());
+    fail_h.assign(nmat, 1);
+    if (shortcut) {
+      hipLaunchKernelGGL(k_rowsum, dim3(nmat), dim3(kThreads), 0, ctx->stream, p);
+      DMM_HIP(hipMemsetAsync(fail_d, 0, nmat * sizeof(int), ctx->stream));
+      DenseParams pc = p;  // factorisations run on a copy: A stays intact for the eigen path
+      pc.A = Vbuf;
+      pc.Linv = Whbuf;
+      pc.fail = fail_d;
+      auto cholesky = [&]() {
+        for (int J = 0; J < T; ++J) {
+          pc.J = J;
+          if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(T - J, nmat), dim3(kThreads), 0, ctx->stream, pc);
+          hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, ctx->stream, pc);
+          if (J < T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(T - J - 1, nmat), dim3(kThreads), 0, ctx->stream, pc);
+        }
+      };
+      // certificate: G - tau I positive definite  <=>  no mode is cut
+      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf, 1, rcond * rcond, acond * acond);
+      cholesky();
+      // solve with G itself (certified tiles only write their result)
+      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf, 0, 0.0, 0.0);
+      cholesky();
+      hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, pc);
+      DMM_HIP(hipGetLastError());
+      DMM_HIP(hipMemcpyAsync(fail_h.data(), fail_d, nmat * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      DMM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    msel_h.clear();
+    for (int i = 0; i < nmat; ++i)
+      if (fail_h[i]) msel_h.push_back(i);
+    ctx->ml_tiles_direct += nmat - (int64_t)msel_h.size();
+    ctx->ml_tiles_eigen += (int64_t)msel_h.size();
+    if (!msel_h.empty()) {  // eigen-decomposition of the same Gram matrices, reference's cut applied
+      const int nsel = (int)msel_h.size();
+      DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      DMM_HIP(hipStreamSynchronize(ctx->stream));
+      JacobiParams jp;
+      jp.d = p;
+      jp.d.msel = msel_d;
+      jp.V = Vbuf;
+      jp.acond = acond;
+      jp.rcond = rcond;
+      jp.max_sweeps = max_sweeps;
+      BjParams bp;
+      bp.d = jp.d;
+      bp.V = Vbuf;
+      bp.Wh = Whbuf;
+      bp.flag = flag_d;
+      bp.scale = scale_d;
+      bp.any_rot = any_rot_d;
+      bp.inner_sweeps = inner_sweeps;
+      bp.nb = p.Np / JB;
+      bp.round = 0;
+      bp.target = 0;
+      const int npr = bp.nb / 2;
+      hipLaunchKernelGGL(k_bj_init, dim3(64, nsel), dim3(kThreads), 0, ctx->stream, bp);
+      for (int sweep = 0; sweep < max_sweeps && bp.nb > 1; ++sweep) {
+        DMM_HIP(hipMemsetAsync(any_rot_d, 0, sizeof(int), ctx->stream));
+        for (int round = 0; round < bp.nb - 1; ++round) {
+          bp.round = round;
+          hipLaunchKernelGGL(k_bj_sub, dim3(npr, nsel), dim3(kThreads), sub_lds, ctx->stream, bp);
+          bp.target = 0;
+          hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nsel), dim3(kThreads), 0, ctx->stream, bp);
+          bp.target = 2;
+          hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nsel), dim3(kThreads), 0, ctx->stream, bp);
+          bp.target = 1;
+          hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nsel), dim3(kThreads), 0, ctx->stream, bp);
+        }
+        // converged when a whole sweep found every pair diagonal to working precision
+        int any = 1;
+        DMM_HIP(hipMemcpyAsync(&any, any_rot_d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DMM_HIP(hipStreamSynchronize(ctx->stream));
+        if (!any) break;
+        if (sweep == max_sweeps - 1)
+          return dmm_set_error(DMM_E_STATE, "dmm_ml_run: Jacobi did not converge in %d sweeps", max_sweeps);
+      }
+      hipLaunchKernelGGL(k_ml_filter, dim3(nsel), dim3(kThreads), fil_lds, ctx->stream, jp);
+      DMM_HIP(hipGetLastError());
+    }
+    if (!sky) {
+      int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_d, work_d, nmat, work_c[nmat], alm);
+      if (rc) return rc;
+      DMM_HIP(hipStreamSynchronize(ctx->stream));  // tiles_d / work_d are rewritten by the next batch
+    }
+    return DMM_OK;
+  };
+
+  for (size_t i0 = 0; i0 < tel_list.size(); i0 += cap) {
+    int rc = run_batch(tel_list, i0, (int)std::min<size_t>(cap, tel_list.size() - i0), false, 0);
+    if (rc) return rc;
+  }
+  for (auto& kv : sky_lists)
+    for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
+      int rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first);
+      if (rc) return rc;
+    }
   return DMM_OK;
 }
 

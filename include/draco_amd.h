@@ -65,8 +65,13 @@ int dmm_ctx_destroy(dmm_ctx* ctx);
 /* run on the caller's HIP stream (hipStream_t passed as void*; NULL = default stream) */
 int dmm_ctx_set_stream(dmm_ctx* ctx, void* hip_stream);
 int dmm_ctx_sync(dmm_ctx* ctx);
-/* tuning knobs (performance only, never results): "dirty_variant" (0 = default), "grid_mult" */
+/* tuning knobs (performance only, never results): "dirty_variant" (0 = default), "grid_mult",
+ * "project_variant", "project_grid_mult", "ml_inner_sweeps", "ml_outer_sweeps", "sht_variant",
+ * "ml_shortcut" (0 = on; 2 = always eigen-decompose; 3 = telescope-side systems only) */
 int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
+/* diagnostics counters, cumulative per context: "ml_tiles_direct" (tiles whose pseudo-inverse was
+ * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed) */
+int dmm_ctx_get_counter(dmm_ctx* ctx, const char* name, int64_t* value);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
 int dmm_timer_start(dmm_ctx* ctx);
 int dmm_timer_stop(dmm_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */

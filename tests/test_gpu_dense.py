@@ -91,6 +91,75 @@ def test_alm_vs_oracle(kind, tol, nfreq, lmax, ncyl, nfeed, b_dtype):
     assert _rel(alm, ref) < tol
 
 
+def _counter(ctx, name):
+    import ctypes as C
+
+    from draco_amd import _lib
+
+    v = C.c_int64()
+    _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+    return int(v.value)
+
+
+def test_ml_certified_shortcut_vs_eigen_path():
+    """ML: the certified full-rank shortcut (Cholesky on the smaller Gram matrix, telescope or sky side)
+    against the eigen-decomposition path on the same tiles, and both against the oracle.
+
+    ntel = 86, nsky_m = 4 (61 - m): m <= 39 solve on the telescope side, m >= 40 on the sky side;
+    10 % of the weights are zero (pinned rows) and two (m, f) have a rank-deficient B (equal rows,
+    equal columns, a zero column) so that their certificates must fail and the eigen path run.
+    """
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import ArrayProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    nfreq, lmax = 2, 60
+    tel = _tel(nfreq, lmax, 2, 4)
+    assert 2 * tel.npairs == 86
+    seed = 4242
+
+    def beam(m, f):
+        b = osyn.beam_tile(seed, m, f, tel.npairs, 4, lmax).copy()
+        if f == 1 and m in (3, 50):  # deficient on either side: nsky_3 = 232 > 86 (telescope), nsky_50 = 44 (sky)
+            b[0, 1] = b[0, 0]
+            b[1, 5] = b[1, 2]
+            b[:, :, 2, m + 1] = 0.0
+            b[:, :, :, m + 2] = b[:, :, :, m + 3]
+        return b
+
+    bt = ArrayProvider(tel, beam)
+    rng = np.random.default_rng(9)
+    mv = rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs)) + 1j * rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs))
+    mw = rng.uniform(0.5, 1.5, mv.shape) * 30.0
+    mw[rng.uniform(size=mw.shape) < 0.1] = 0.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    ref = omm.solve_alm("ml", beam, mv, mw, lmax, tel.mmax, list(range(nfreq)))
+    out = {}
+    stats = {}
+    try:
+        for mode in (0, 2, 3):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", mode))
+            d0, e0 = _counter(ctx, b"ml_tiles_direct"), _counter(ctx, b"ml_tiles_eigen")
+            task = MaximumLikelihoodMapMaker()
+            task.setup(bt)
+            out[mode] = task.alm_square(task.make_alm(mm))
+            stats[mode] = (_counter(ctx, b"ml_tiles_direct") - d0, _counter(ctx, b"ml_tiles_eigen") - e0)
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+    ntile = nfreq * (lmax + 1)
+    assert stats[2] == (0, ntile)
+    assert stats[0][0] + stats[0][1] == ntile and stats[0][1] >= 2  # the two deficient tiles at least
+    assert stats[0][0] > ntile // 2, stats  # and most tiles take the shortcut
+    for mode in (0, 2, 3):
+        assert _rel(out[mode], ref) < 1e-8, (mode, stats[mode])
+    assert _rel(out[0], out[2]) < 1e-9
+
+
 def test_wiener_cfg2_sized_tile_properties():
     """cfg-2 sized tile (374 x 1028): Wiener solution satisfies its normal equations (size-independent check)."""
     import torch

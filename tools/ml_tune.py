@@ -1,5 +1,8 @@
 #!/usr/bin/env python
-"""ML (blocked Jacobi) sweep-cap tuning: time and accuracy vs the oracle SVD on sampled tiles."""
+"""ML timing and accuracy vs the oracle SVD on sampled tiles: all m of one frequency.
+
+    python tools/ml_tune.py [config]      modes: certified shortcut (default), eigen path always, telescope side only
+"""
 import json
 import os
 import sys
@@ -23,29 +26,43 @@ def main():
     from oracle import synth as osyn
 
     cfgn = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    nf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    modes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 3, 2]
     cfg = osyn.CONFIGS[cfgn]
     ctx = Context.get()
     lmax = cfg["lmax"]
-    tel = TransitTelescope(osyn.frequencies(1), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+    tel = TransitTelescope(osyn.frequencies(nf), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
     eng = SolveEngine(SyntheticProvider(tel, seed=5), ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=True)
     gen = torch.Generator(device=ctx.device).manual_seed(7)
-    vis = torch.randn((1, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
-    w = torch.rand((1, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) * 40 + 10
+    vis = torch.randn((nf, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
+    w = torch.rand((nf, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) * 40 + 10
     mv, mw = mmode_forward(ctx, vis, w, lmax)
     mvh, mwh = mv.cpu().numpy(), mw.cpu().numpy()
     ms = [0, lmax // 3, (2 * lmax) // 3, lmax - 2]
     refs = {m: omm.ml_solve(osyn.beam_tile(5, m, 0, tel.npairs, 4, lmax), mvh[m, :, 0], mwh[m, :, 0]) for m in ms}
-    eng.solve("ml", mv, mw, [0], lmax, acond=1e-4, rcond=1e-3)
-    for inner, outer in ((1, 60), (2, 60)):
-        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_inner_sweeps", inner))
-        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_outer_sweeps", outer))
+    fl = list(range(nf))
+    eng.solve("ml", mv, mw, fl, lmax, acond=1e-4, rcond=1e-3)
+    import ctypes as C
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    labels = {0: "shortcut", 3: "telescope-side only", 2: "eigen always"}
+    for mode in modes:
+        label = labels[mode]
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", mode))
+        d0, e0 = counter(b"ml_tiles_direct"), counter(b"ml_tiles_eigen")
         ctx.sync()
         t0 = time.perf_counter()
-        alm = eng.solve("ml", mv, mw, [0], lmax, acond=1e-4, rcond=1e-3)
+        alm = eng.solve("ml", mv, mw, fl, lmax, acond=1e-4, rcond=1e-3)
         ctx.sync()
         dt = time.perf_counter() - t0
         err = max(np.abs(alm[0, :, m, :].cpu().numpy() - refs[m]).max() / np.abs(refs[m]).max() for m in ms)
-        print(json.dumps({"cfg": cfgn, "inner": inner, "outer": outer, "ms_per_tile": dt * 1e3 / (lmax + 1), "max_rel_err": err}))
+        print(json.dumps({"cfg": cfgn, "mode": label, "nfreq": nf, "ms_per_tile": dt * 1e3 / (nf * (lmax + 1)), "total_s": dt, "max_rel_err": err,
+                          "tiles_direct": counter(b"ml_tiles_direct") - d0, "tiles_eigen": counter(b"ml_tiles_eigen") - e0}), flush=True)
+    _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
 
 
 if __name__ == "__main__":
