@@ -89,6 +89,11 @@ __device__ __forceinline__ double2 load_bc(const void* B, int c128, int64_t off)
   return make_double2((double)v.x, (double)v.y);
 }
 
+// order of one matrix of the batch: sky-side batches mix tiles of several m (one padded order Np)
+__device__ __forceinline__ int order_of(const DenseParams& p, const dmm_tile& t) {
+  return p.sky ? p.npol * (p.lmax + 1 - t.m) : p.N;
+}
+
 // Staging of rows [row0, row0+64) x complex columns [k0, k0+KC) of an operand, split in two so the
 // global loads of chunk k+1 fly under the MFMAs of chunk k: fetch() -> 4 complex values per thread in
 // registers, commit() -> LDS as doubles [64][LP] (re, im interleaved).
@@ -155,7 +160,7 @@ __device__ __forceinline__ void fetch(double2 (&v)[4], const DenseParams& p, con
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int k = k0 + c0 + c;
-      v[c] = (row < p.N && k < K) ? p.X[((int64_t)mat * p.Np + row) * p.ldx + k] : make_double2(0.0, 0.0);
+      v[c] = (row < order_of(p, tile) && k < K) ? p.X[((int64_t)mat * p.Np + row) * p.ldx + k] : make_double2(0.0, 0.0);
     }
   }
 }
@@ -357,10 +362,10 @@ __global__ __launch_bounds__(kThreads) void k_chol_solve(DenseParams p) {
   const int mat = blockIdx.x;
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   const double2* A = p.A + (int64_t)mat * p.Np * p.Np;
-  const int Lsky = p.lmax + 1 - tile.m;
+  const int Lsky = p.lmax + 1 - tile.m, N = order_of(p, tile);
   for (int i = threadIdx.x; i < p.Np; i += kThreads) {
     double2 b = make_double2(0.0, 0.0);
-    if (i < p.N) {
+    if (i < N) {
       if (p.sky) {  // rhs = B^H Ni v, left in alm by the dirty pass
         const int pol = i / Lsky, lrel = i - pol * Lsky;
         b = p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel];
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void k_chol_solve(DenseParams p) {
     __syncthreads();
   }
   if (p.fail && p.fail[mat]) return;  // not certified: the eigen path owns this tile's output
-  for (int i = threadIdx.x; i < p.N; i += kThreads) {
+  for (int i = threadIdx.x; i < N; i += kThreads) {
     if (p.sky) {
       const int pol = i / Lsky, lrel = i - pol * Lsky;
       p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel] = y[i];
@@ -487,12 +492,13 @@ __global__ __launch_bounds__(kThreads) void k_xpose(DenseParams p, double2* X) {
 __global__ __launch_bounds__(kThreads) void k_rowsum(DenseParams p) {
   __shared__ double red[kThreads / 64];
   const int mat = blockIdx.x, n = p.Np;
+  const int N = order_of(p, p.tiles[p.tile0 + mat]);
   const double2* A = p.A + (int64_t)mat * n * n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double best = 0.0;
-  for (int i = wave; i < p.N; i += kThreads / 64) {
+  for (int i = wave; i < N; i += kThreads / 64) {
     double sum = 0.0;
-    for (int j = lane; j < p.N; j += 64) {
+    for (int j = lane; j < N; j += 64) {
       const double2 v = A[(int64_t)i * n + j];
       sum += sqrt(v.x * v.x + v.y * v.y);
     }
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(kThreads) void k_rowsum(DenseParams p) {
 // diagonal theta.  shift = max(rcond2 * theta, acond2) when `shifted`, else 0.
 __global__ __launch_bounds__(kThreads) void k_shift_copy(DenseParams p, double2* C, int shifted, double rcond2, double acond2) {
   const int mat = blockIdx.y, n = p.Np;
+  const int N = order_of(p, p.tiles[p.tile0 + mat]);
   const double2* A = p.A + (int64_t)mat * n * n;
   double2* dst = C + (int64_t)mat * n * n;
   const double th = p.theta[mat];
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void k_shift_copy(DenseParams p, double2*
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx / n), j = (int)(idx % n);
     double2 v = A[idx];
-    if (i == j) v = (i >= p.N || v.x == 0.0) ? make_double2(pin, 0.0) : make_double2(v.x - shift, 0.0);
+    if (i == j) v = (i >= N || v.x == 0.0) ? make_double2(pin, 0.0) : make_double2(v.x - shift, 0.0);
     dst[idx] = v;
   }
 }
@@ -825,10 +832,10 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   const double2* A = p.A + (int64_t)mat * n * n;
   const double2* V = jp.V + (int64_t)mat * n * n;
-  const int Lsky = p.lmax + 1 - tile.m;
+  const int Lsky = p.lmax + 1 - tile.m, N = order_of(p, tile);
   for (int i = threadIdx.x; i < n; i += kThreads) {
     double2 v = make_double2(0.0, 0.0);
-    if (i < p.N) {
+    if (i < N) {
       if (p.sky) {
         const int pol = i / Lsky, lrel = i - pol * Lsky;
         v = p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel];
@@ -867,7 +874,7 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
     c[k] = acc;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < p.N; i += kThreads) {
+  for (int i = threadIdx.x; i < N; i += kThreads) {
     double2 acc = make_double2(0.0, 0.0);
     for (int k = 0; k < n; ++k) {
       const double2 u = V[(int64_t)i * n + k], x = c[k];
@@ -1026,7 +1033,6 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
   const DenseParams base = make_params(pl, L, B, mvis, mweight, ws, cap);
-  double2* const Abuf = base.A;      // [cap] Gram matrices (kept intact for the eigen fallback)
   double2* const Vbuf = base.Linv;   // [cap] X, then the Cholesky copies, then the eigenvectors
   // small per-batch arrays live behind the per-matrix regions (sized in layout_of)
   unsigned char* extra = (unsigned char*)(base.wbuf + (size_t)cap * L.N);
@@ -1061,7 +1067,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const int m = pl->tiles_h[t].m;
     const int nsky = pl->npol * (pl->lmax + 1 - m);
     if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);  // 3: telescope side only
-    else sky_lists[m].push_back(t);
+    else sky_lists[(nsky + TB - 1) / TB * TB].push_back(t);  // tiles of one padded order share batches
   }
   if (!sky_lists.empty()) {  // B^H Ni v of every tile: the right-hand side of the sky-side systems
     int rc = dmm_dirty_run(pl, B, mvis, mweight, alm);
@@ -1079,13 +1085,17 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   std::vector<dmm_tile> tiles_c;
   std::vector<int32_t> work_c;
   std::vector<int> fail_h, msel_h;
-  auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int m) -> int {
+  // tiles whose certificate failed, collected over all batches so that the (launch-latency bound)
+  // eigen path runs on well filled batches at the end
+  std::vector<int64_t> tel_deferred;
+  std::map<int, std::vector<int64_t>> sky_deferred;
+  auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky, bool eigen_only) -> int {
     DenseParams p = base;
     p.tiles = tiles_d;
     p.tile0 = 0;
     p.nmat = nmat;
     p.sky = sky ? 1 : 0;
-    p.N = sky ? pl->npol * (pl->lmax + 1 - m) : ntel;
+    p.N = sky ? np_sky : ntel;  // sky side: the order of each matrix comes from its tile (order_of)
     p.Np = (p.N + TB - 1) / TB * TB;
     p.T = p.Np / TB;
     p.alm = (double2*)alm;
@@ -1113,7 +1123,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
     DMM_HIP(hipGetLastError());
     fail_h.assign(nmat, 1);
-    if (shortcut) {
+    if (shortcut && !eigen_only) {
       hipLaunchKernelGGL(k_rowsum, dim3(nmat), dim3(kThreads), 0, ctx->stream, p);
       DMM_HIP(hipMemsetAsync(fail_d, 0, nmat * sizeof(int), ctx->stream));
       DenseParams pc = p;  // factorisations run on a copy: A stays intact for the eigen path
@@ -1142,9 +1152,13 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     msel_h.clear();
     for (int i = 0; i < nmat; ++i)
       if (fail_h[i]) msel_h.push_back(i);
-    ctx->ml_tiles_direct += nmat - (int64_t)msel_h.size();
+    if (shortcut && !eigen_only) {
+      ctx->ml_tiles_direct += nmat - (int64_t)msel_h.size();
+      for (int i : msel_h) (sky ? sky_deferred[np_sky] : tel_deferred).push_back(list[i0 + i]);
+      msel_h.clear();  // (their wbuf / alm entries are rewritten by the deferred pass)
+    }
     ctx->ml_tiles_eigen += (int64_t)msel_h.size();
-    if (!msel_h.empty()) {  // eigen-decomposition of the same Gram matrices, reference's cut applied
+    if (!msel_h.empty()) {  // eigen-decomposition of the Gram matrices, reference's cut applied
       const int nsel = (int)msel_h.size();
       DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
@@ -1199,15 +1213,20 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     return DMM_OK;
   };
 
-  for (size_t i0 = 0; i0 < tel_list.size(); i0 += cap) {
-    int rc = run_batch(tel_list, i0, (int)std::min<size_t>(cap, tel_list.size() - i0), false, 0);
-    if (rc) return rc;
-  }
-  for (auto& kv : sky_lists)
-    for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
-      int rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first);
+  for (int pass = 0; pass < 2; ++pass) {  // 0: every tile, certificate first; 1: the tiles it rejected
+    const bool eigen_only = pass == 1;
+    const std::vector<int64_t>& tl = eigen_only ? tel_deferred : tel_list;
+    for (size_t i0 = 0; i0 < tl.size(); i0 += cap) {
+      int rc = run_batch(tl, i0, (int)std::min<size_t>(cap, tl.size() - i0), false, 0, eigen_only);
       if (rc) return rc;
     }
+    for (auto& kv : eigen_only ? sky_deferred : sky_lists)
+      for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
+        int rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first, eigen_only);
+        if (rc) return rc;
+      }
+    if (!shortcut) break;  // everything went through the eigen path already
+  }
   return DMM_OK;
 }
 
