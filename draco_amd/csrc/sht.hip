@@ -911,7 +911,8 @@ size_t chunk_freqs(int nfreq, int npol, int nring, int mmax) {
   size_t nf = ((size_t)1 << 30) / per_f;  // ~1 GiB of ring coefficients at a time
   if (nf < 1) nf = 1;
   if (nf > (size_t)nfreq) nf = nfreq;
-  return nf;
+  const size_t nchunk = ((size_t)nfreq + nf - 1) / nf;  // equal chunks: no near-empty tail launch
+  return ((size_t)nfreq + nchunk - 1) / nchunk;
 }
 
 // the ring classes of a geometry (see RingClass) with the launch shape of each
