@@ -317,6 +317,17 @@ class RingMap(ContainerBase, _FreqMixin):
         return self.datasets["dirty_beam_power"]
 
 
+class SVDSpectrum(ContainerBase):
+    """``spectrum [m, singularvalue]`` float64: the per-m SVD spectrum of MModes (``containers.py:2589-2607``)."""
+
+    _axes = ("m", "singularvalue")
+    _dataset_spec = {"spectrum": {"axes": ["m", "singularvalue"], "dtype": np.float64}}
+
+    @property
+    def spectrum(self):
+        return self.datasets["spectrum"]
+
+
 class Map(ContainerBase, _FreqMixin):
     """``map [freq, pol, pixel]`` float64, HEALPix RING (``containers.py:470-486``, cora ``Map`` [3P])."""
 

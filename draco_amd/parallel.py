@@ -1,4 +1,5 @@
-"""Frequency sharding across GPUs: one process per GPU, RCCL for the final map all-gather only.
+"""Frequency sharding across GPUs: one process per GPU; RCCL for the final map all-gather and, for the
+SVD filter alone, the frequency <-> m exchange.
 
 Frequency is the path's natural parallel axis (the reference distributes it with MPI,
 ``containers.py:505-506``): the m-FFT, every (m, f) solve and the SHT are independent per
@@ -112,3 +113,93 @@ def allgather_map(local_map, nfreq_total=None, group=None):
     else:
         out.datasets["map"] = containers.Dataset(host=gathered.numpy(), attrs=ds.attrs)
     return out
+
+
+# ---------------------------------------------------------------- frequency <-> m exchange
+# The SVD filter (analysis/svdfilter.py) couples all frequencies of one m: the one task on this
+# path with a real exchange step (the reference's ``mmodes.redistribute("m")``, svdfilter.py:34,93).
+# It is an all-to-all of ``[m-slab, msign, freq-slab, base]`` blocks, issued as one batch of
+# point-to-point sends/receives (RCCL groups them into a single all-to-all over xGMI; gloo, which
+# has no all-to-all, runs the same code in the CPU tests).
+
+
+def _wire(t):
+    """Complex tensors travel as their (re, im) float view (gloo has no complex types)."""
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+def _exchange(send_blocks, recv_blocks, group=None):
+    rank, world = _rank_world(group)
+    ops = []
+    for q in range(world):
+        if q == rank:
+            recv_blocks[q].copy_(send_blocks[q])
+            continue
+        ops.append(dist.P2POp(dist.isend, _wire(send_blocks[q]), q, group))
+        ops.append(dist.P2POp(dist.irecv, _wire(recv_blocks[q]), q, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def freq_to_m(mvis, mweight, group=None):
+    """Frequency-sharded ``[n_m, 2, nfreq_local, nbase]`` -> m-sharded ``[n_m_local, 2, nfreq_total, nbase]``.
+
+    Returns ``(mvis_m, mweight_m, layout)``; ``layout`` is what :func:`m_to_freq` / :func:`gather_m`
+    need to undo it (``None`` on a single rank, where this is the identity).
+    """
+    rank, world = _rank_world(group)
+    if world == 1:
+        return mvis, mweight, None
+    n_m, _, nf_loc, nbase = mvis.shape
+    cnt = torch.tensor([nf_loc], dtype=torch.int64, device=mvis.device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    nf = [int(c.item()) for c in cnts]
+    f0 = [sum(nf[:q]) for q in range(world)]
+    mc = [split_local(n_m, q, world) for q in range(world)]  # (count, start) of every rank's m slab
+    lay = {"world": world, "rank": rank, "nf": nf, "f0": f0, "mc": mc, "n_m": n_m, "group": group}
+    out = []
+    for src in (mvis, mweight):
+        send = [src[mc[q][1] : mc[q][1] + mc[q][0]].contiguous() for q in range(world)]
+        recv = [torch.empty((mc[rank][0], 2, nf[q], nbase), dtype=src.dtype, device=src.device) for q in range(world)]
+        _exchange(send, recv, group)
+        out.append(torch.cat(recv, dim=2).contiguous())
+    return out[0], out[1], lay
+
+
+def m_to_freq(mvis_m, lay):
+    """Inverse of :func:`freq_to_m` for one array: m-sharded -> this rank's frequency slab, all m."""
+    if lay is None:
+        return mvis_m
+    world, rank, nf, f0, mc = lay["world"], lay["rank"], lay["nf"], lay["f0"], lay["mc"]
+    nbase = mvis_m.shape[3]
+    send = [mvis_m[:, :, f0[q] : f0[q] + nf[q]].contiguous() for q in range(world)]
+    recv = [torch.empty((mc[q][0], 2, nf[rank], nbase), dtype=mvis_m.dtype, device=mvis_m.device) for q in range(world)]
+    _exchange(send, recv, lay["group"])
+    return torch.cat(recv, dim=0).contiguous()
+
+
+def gather_m(x_m, lay):
+    """All ranks' ``[n_m_local, ...]`` pieces -> the full ``[n_m, ...]`` array on every rank."""
+    if lay is None:
+        return x_m
+    world, mc = lay["world"], lay["mc"]
+    nmax = max(c for c, _ in mc)
+    pad = torch.zeros((nmax, *x_m.shape[1:]), dtype=x_m.dtype, device=x_m.device)
+    pad[: x_m.shape[0]] = x_m
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=lay["group"])
+    return torch.cat([parts[q][: mc[q][0]] for q in range(world)], dim=0).contiguous()
+
+
+def allreduce_max(x, device=None, group=None):
+    """Maximum of a Python float over all ranks (``svdfilter.py:113``)."""
+    rank, world = _rank_world(group)
+    if world == 1:
+        return float(x)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

@@ -212,6 +212,22 @@ int dmm_synth_beam_fill(dmm_ctx* ctx, const dmm_tile* tiles /*[host]*/, int64_t 
                         int npairs, int npol, int lmax, int b_dtype, int b_layout,
                         uint64_t seed, void* B);
 
+/* ------------------------------------------------- m-mode SVD filter
+ * dmm_mmode_svd replaces the per-m loops of SVDSpectrumEstimator.process (reference
+ * svdfilter.py:22-57) and SVDFilter.process (:79-149) including svd_em (:152-187): for every m
+ * the matrix [freq, (msign, base)] of the MModes array, missing entries (weight == 0) refilled
+ * `niter` times from its rank-`rank` approximation, is decomposed (frequency-side Gram matrix,
+ * f64 MFMA + blocked Jacobi).  mvis/mweight: [n_m, 2, nfreq, nbase] complex128 / float64 (device).
+ * fill0: [n_m] complex128 first guess of the missing entries (np.median of the present ones,
+ * :176) or NULL when no weight is zero.  spectrum: [n_m, min(2 nbase, nfreq)] float64 (device).
+ * mode 0: spectrum only; if u_out / uha_out are given (both or neither) the left singular vectors
+ * [n_m, nfreq, nmode] and U^H A = diag(sigma) V^H [n_m, nmode, 2 nbase] of the last decomposition
+ * are returned too (svd_em's factors).  mode 1: mvis is overwritten with the data whose
+ * cut = max(#(sigma > global_thr*global_max), #(sigma > local_thr*sigma_0)) largest modes are removed. */
+int dmm_mmode_svd(dmm_ctx* ctx, void* mvis, const double* mweight, int n_m, int nfreq, int nbase, int niter, int rank,
+                  const void* fill0, int mode, double global_max, double global_thr, double local_thr, double* spectrum,
+                  void* u_out, void* uha_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -691,6 +691,80 @@ def gen_collate(transform, out):
     np.savez_compressed(os.path.join(out, "transform_collate.npz"), **cases)
 
 
+class _EnumDS(_DS):
+    """Dataset whose slice also answers MPIArray.enumerate / local_array (single process)."""
+
+    def __init__(self, arr):
+        self.arr = arr.view(_EnumLocal)
+
+
+class _EnumLocal(_Arr):
+    def enumerate(self, axis):
+        return [(i, i) for i in range(self.shape[axis])]
+
+
+class _OneRankComm:
+    def allreduce(self, x, op=None):
+        return x
+
+
+class FakeSVDSpectrum(_FakeCont):
+    def __init__(self, singularvalue=None, axes_from=None, **kw):
+        self.spectrum = _DS(np.zeros((axes_from.vis.shape[0], singularvalue)))
+
+
+def gen_svd(out):
+    """svd_em, SVDSpectrumEstimator.process and SVDFilter.process (svdfilter.py) on duck-typed MModes."""
+    from draco.analysis import svdfilter
+
+    svdfilter.containers = type("C", (), {"SVDSpectrum": FakeSVDSpectrum})
+    rng = np.random.default_rng(8008)
+    cases = {}
+    # (a) svd_em on single matrices: no mask, 10 % mask, wide and tall
+    idx = 0
+    for shape, frac, niter, rank in (((6, 10), 0.0, 5, 5), ((6, 10), 0.15, 5, 5), ((12, 5), 0.1, 3, 2), ((8, 8), 0.2, 4, 3)):
+        # low-rank foreground + noise, like the data the task is meant for
+        nr, nc = shape
+        A = sum(10.0 ** (2 - k) * np.outer(crandn(rng, nr), crandn(rng, nc)) for k in range(3)) + 0.01 * crandn(rng, shape)
+        mask = rng.uniform(size=shape) < frac
+        u, sig, vh = svdfilter.svd_em(A, mask, niter=niter, rank=rank)
+        cases[f"e{idx}_A"], cases[f"e{idx}_mask"] = A, mask
+        cases[f"e{idx}_opts"] = np.array([niter, rank])
+        cases[f"e{idx}_sig"] = sig
+        cases[f"e{idx}_recon"] = np.dot(u * sig, vh)
+        idx += 1
+    cases["nem"] = np.int64(idx)
+    # (b) the two tasks
+    idx = 0
+    for nm, nfreq, nbase, frac, niter, gthr, lthr in ((4, 6, 5, 0.0, 5, 1e-3, 1e-2), (5, 8, 3, 0.1, 5, 1e-3, 1e-2), (3, 5, 6, 0.2, 2, 0.3, 0.5), (3, 7, 2, 0.05, 3, 2.0, 0.05)):
+        fg = np.zeros((nm, 2, nfreq, nbase), complex)
+        for k in range(2):  # frequency-smooth, bright components + noise
+            fg += 10.0 ** (3 - 2 * k) * crandn(rng, (nm, 2, 1, nbase)) * np.cos(0.3 * (k + 1) * np.arange(nfreq))[None, None, :, None]
+        vis = fg + 0.1 * crandn(rng, fg.shape)
+        w = rng.uniform(0.5, 1.5, vis.shape)
+        w[rng.uniform(size=w.shape) < frac] = 0.0
+        mm = FakeMModes(oddra=False, vis=vis.copy(), weight=w.copy())
+        mm.vis, mm.weight = _EnumDS(vis.copy()), _EnumDS(w.copy())
+        t = svdfilter.SVDSpectrumEstimator.__new__(svdfilter.SVDSpectrumEstimator)
+        t.log = _Log()
+        t.niter = niter
+        spec = t.process(mm)
+        mm2 = FakeMModes(oddra=False, vis=vis.copy(), weight=w.copy())
+        mm2.vis, mm2.weight = _EnumDS(vis.copy()), _EnumDS(w.copy())
+        mm2.comm = _OneRankComm()
+        t2 = svdfilter.SVDFilter.__new__(svdfilter.SVDFilter)
+        t2.log = _Log()
+        t2.niter, t2.global_threshold, t2.local_threshold = niter, gthr, lthr
+        res = t2.process(mm2)
+        cases[f"c{idx}_vis"], cases[f"c{idx}_w"] = vis, w
+        cases[f"c{idx}_opts"] = np.array([niter, gthr, lthr])
+        cases[f"c{idx}_spectrum"] = spec.spectrum.arr.view(np.ndarray)
+        cases[f"c{idx}_filtered"] = res.vis.arr.view(np.ndarray)
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "svdfilter.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -711,6 +785,8 @@ def main():
         gen_ringmap(GOLDEN)
     if not only or "--only-collate" in only:
         gen_collate(transform, GOLDEN)
+    if not only or "--only-svd" in only:
+        gen_svd(GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 

@@ -97,3 +97,42 @@ def test_two_rank_gloo_allgather(nfreq):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _xchg_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_m, nfreq, nbase = 5, 7, 3
+        rng = np.random.default_rng(1)
+        vis = rng.standard_normal((n_m, 2, nfreq, nbase)) + 1j * rng.standard_normal((n_m, 2, nfreq, nbase))
+        wgt = rng.uniform(size=vis.shape)
+        c, s0 = parallel.split_local(nfreq, rank, world)
+        mv = torch.from_numpy(np.ascontiguousarray(vis[:, :, s0 : s0 + c]))
+        mw = torch.from_numpy(np.ascontiguousarray(wgt[:, :, s0 : s0 + c]))
+        a, b, lay = parallel.freq_to_m(mv, mw)
+        mc, ms = parallel.split_local(n_m, rank, world)
+        ok = np.array_equal(a.numpy(), vis[ms : ms + mc]) and np.array_equal(b.numpy(), wgt[ms : ms + mc])
+        back = parallel.m_to_freq(a * 2.0, lay)
+        ok = ok and np.array_equal(back.numpy(), 2.0 * vis[:, :, s0 : s0 + c])
+        spec = parallel.gather_m(torch.from_numpy(np.arange(ms, ms + mc, dtype=np.float64)[:, None] * np.ones((1, 4))), lay)
+        ok = ok and np.array_equal(spec.numpy(), np.arange(n_m, dtype=np.float64)[:, None] * np.ones((1, 4)))
+        ok = ok and parallel.allreduce_max(float(rank) + 0.5) == world - 0.5
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_freq_m_exchange_world2():
+    """The SVD filter's frequency <-> m exchange (uneven slabs on both axes), gather and MAX-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xchg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

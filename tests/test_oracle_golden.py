@@ -195,3 +195,22 @@ def test_collate_products(golden_dir):
         np.testing.assert_allclose(v, g[f"c{i}_out_vis"], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(w, g[f"c{i}_out_w"], rtol=1e-6)
         np.testing.assert_array_equal(fl, g[f"c{i}_out_flags"])
+
+
+def test_svd_em_and_tasks(golden_dir):
+    """svdfilter.py: svd_em, SVDSpectrumEstimator.process, SVDFilter.process (outputs of the reference code)."""
+    from oracle import svdfilter as osvd
+
+    g = _load(golden_dir, "svdfilter.npz")
+    for i in range(int(g["nem"])):
+        niter, rank = (int(x) for x in g[f"e{i}_opts"])
+        u, sig, vh = osvd.svd_em(g[f"e{i}_A"], g[f"e{i}_mask"], niter=niter, rank=rank)
+        np.testing.assert_allclose(sig, g[f"e{i}_sig"], rtol=1e-12, atol=1e-13 * g[f"e{i}_sig"][0])
+        np.testing.assert_allclose(np.dot(u * sig, vh), g[f"e{i}_recon"], rtol=1e-11, atol=1e-12 * g[f"e{i}_sig"][0])
+    for i in range(int(g["ncase"])):
+        niter, gthr, lthr = g[f"c{i}_opts"]
+        vis, w = g[f"c{i}_vis"], g[f"c{i}_w"]
+        spec = osvd.svd_spectrum(vis, w, niter=int(niter))
+        np.testing.assert_allclose(spec, g[f"c{i}_spectrum"], rtol=1e-11, atol=1e-12 * spec.max())
+        out = osvd.svd_filter(vis, w, niter=int(niter), global_threshold=gthr, local_threshold=lthr)
+        np.testing.assert_allclose(out, g[f"c{i}_filtered"], rtol=0, atol=1e-11 * np.abs(vis).max())
