@@ -266,12 +266,33 @@ class TelescopeStreamMixIn:
         self.bt_rev["conjugate"] = np.where(fm, np.asarray(tel.feedconj)[triu], 0)
 
 
+def _redefine_stack_index_map(tel, tel_index, prod, stack, reverse_stack):
+    """Representative products made of present, unmasked inputs (``util/tools.py:359-414``)."""
+    stack_new = stack.copy()
+    stack_flag = np.zeros(stack_new.size, dtype=bool)
+    feedmask = np.asarray(tel.feedmask)
+    for sind, (ii, jj) in enumerate(zip(prod["input_a"][stack["prod"]], prod["input_b"][stack["prod"]])):
+        bi, bj = tel_index[ii], tel_index[jj]
+        if (bi is None) or (bj is None) or not feedmask[bi, bj]:
+            for ts in np.flatnonzero(reverse_stack["stack"] == sind):
+                ti, tj = tel_index[prod["input_a"][ts]], tel_index[prod["input_b"][ts]]
+                if (ti is not None) and (tj is not None) and feedmask[ti, tj]:
+                    stack_new["prod"][sind] = ts
+                    stack_new["conjugate"][sind] = reverse_stack["conjugate"][ts]
+                    stack_flag[sind] = True
+                    break
+        else:
+            stack_flag[sind] = True
+    return stack_new, stack_flag
+
+
 class CollateProducts(TelescopeStreamMixIn, ContainerTask):
     """Extract, order and stack the correlation products for map-making (``transform.py:142-330``).
 
     The input may hold more inputs and frequencies than the telescope; the converse raises
-    ``ValueError`` like the reference.  Inputs that are ALREADY redundancy-stacked are not supported
-    yet (the reference re-derives their representative products, ``transform.py:206-221``).
+    ``ValueError`` like the reference.  For inputs that are ALREADY redundancy-stacked the
+    representative product of every stack entry is re-derived so that it only involves inputs the
+    telescope has and does not mask (``transform.py:206-221``, ``util/tools.py:359-414``).
 
     Attributes
     ----------
@@ -289,9 +310,17 @@ class CollateProducts(TelescopeStreamMixIn, ContainerTask):
         rev_input_ind = _find_inputs(ss_input, tel.input_index, require_match=True)
         freq_ind = tools.find_keys(list(ss.index_map["freq"]["centre"]), list(tel.frequencies), require_match=True)
         bt_freq = ss.index_map["freq"][freq_ind]
-        if getattr(ss, "is_stacked", False):
-            raise NotImplementedError("CollateProducts on an already stacked stream is not built yet")
-        ss_prod = np.asarray(ss.index_map["prod"])
+        file_prod = np.asarray(ss.index_map["prod"])
+        stacked = bool(getattr(ss, "is_stacked", False))
+        if stacked:
+            stack_new, stack_flag = _redefine_stack_index_map(tel, input_ind, file_prod, np.asarray(ss.index_map["stack"]), np.asarray(ss.reverse_map["stack"]))
+            if not np.all(stack_flag):
+                self.log.warning(f"There are {np.sum(~stack_flag):0.0f} stacked baselines that are masked in the telescope instance.")
+            ss_prod = file_prod[stack_new["prod"]]
+            ss_conj = stack_new["conjugate"].astype(bool)
+        else:
+            ss_prod = file_prod
+            ss_conj = np.zeros(len(ss_prod), dtype=bool)
         if self.weight not in ("natural", "uniform", "inverse_variance"):
             raise ValueError(f"unknown weight {self.weight!r}")
 
@@ -311,7 +340,7 @@ class CollateProducts(TelescopeStreamMixIn, ContainerTask):
             sp_pi = int(tel.feedmap[bi, bj])
             if sp_pi < 0:
                 continue
-            lists[sp_pi].append((ss_pi, bool(tel.feedconj[bi, bj])))  # file products are not conjugated (unstacked)
+            lists[sp_pi].append((ss_pi, bool(tel.feedconj[bi, bj]) != bool(ss_conj[ss_pi])))  # conjugate unless feedconj == conj (:303)
         ptr_ = np.zeros(tel.npairs + 1, dtype=np.int32)
         ptr_[1:] = np.cumsum([len(x) for x in lists])
         src = np.array([p for x in lists for p, _ in x], dtype=np.int32)
@@ -323,7 +352,12 @@ class CollateProducts(TelescopeStreamMixIn, ContainerTask):
         red_d = None
         if self.weight != "inverse_variance":
             fl = flags if flags is not None and np.any(flags) else np.ones((len(ss_input), nt), np.float32)
-            red = fl[ss_prod["input_a"].astype(int)] * fl[ss_prod["input_b"].astype(int)]  # one product per "stack" entry
+            if stacked:  # products that went into each stack entry with both inputs good (util/tools.py:313-356)
+                red = np.zeros((nprod_in, nt), np.float32)
+                np.add.at(red, np.asarray(ss.reverse_map["stack"]["stack"]).astype(np.int64),
+                          fl[file_prod["input_a"].astype(int)] * fl[file_prod["input_b"].astype(int)])
+            else:
+                red = fl[ss_prod["input_a"].astype(int)] * fl[ss_prod["input_b"].astype(int)]  # one product per "stack" entry
             if self.weight == "uniform":
                 red = (red > 0).astype(np.float32)
             red_d = ctx.to_device(np.ascontiguousarray(red, dtype=np.float32))

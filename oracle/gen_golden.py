@@ -686,6 +686,51 @@ def gen_collate(transform, out):
         cases[f"c{idx}_out_rev_stack"] = sp.reverse_map["stack"]["stack"]
         idx += 1
     cases["ncase"] = np.int64(idx)
+    # already redundancy-stacked inputs (transform.py:206-221 + tools.redefine_stack_index_map): the file's
+    # products are stacked by separation; representatives are chosen to involve the input the telescope
+    # lacks, and one telescope pair is masked, so that the representative products must be re-derived
+    sidx = 0
+    for weight, mask_pair in (("inverse_variance", False), ("natural", True), ("uniform", True)):
+        tel = _CollateTel(nfeed_tel, tel_freq)
+        if mask_pair:
+            tel.feedmask[0, 1] = tel.feedmask[1, 0] = False
+        file_ids = [100 + i for i in range(nfeed_tel)] + [999]
+        ninp = len(file_ids)
+        inputs = np.array([(c,) for c in file_ids], dtype=[("chan_id", "<u2")])
+        fm = np.zeros(len(tel_freq), dtype=[("centre", float), ("width", float)])
+        fm["centre"], fm["width"] = tel_freq, 10.0
+        prod = np.array([(i, j) for i in range(ninp) for j in range(i, ninp)], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        rev = np.zeros(len(prod), dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        rev["stack"] = prod["input_b"].astype(int) - prod["input_a"].astype(int)
+        rev["conjugate"] = prod["input_a"] % 2
+        nst = ninp
+        stack = np.zeros(nst, dtype=[("prod", "<u4"), ("conjugate", "u1")])
+        for s_ in range(nst):  # representative: the LAST product of the stack (involves input 999)
+            members = np.flatnonzero(rev["stack"] == s_)
+            stack["prod"][s_] = members[-1]
+            stack["conjugate"][s_] = rev["conjugate"][members[-1]]
+        vis = crandn(rng, (len(tel_freq), nst, nra), np.complex64)
+        w = rng.uniform(0.5, 1.5, vis.shape).astype(np.float32)
+        w[rng.uniform(size=w.shape) < 0.15] = 0.0
+        flags = (rng.uniform(size=(ninp, nra)) > 0.2).astype(np.float32)
+        ss = FakeCollateStream(freq=fm, input=inputs, prod=prod, stack=stack, reverse_map_stack=rev, vis=vis.copy(), weight=w.copy(), input_flags=flags.copy())
+        assert ss.is_stacked
+        t = transform.CollateProducts.__new__(transform.CollateProducts)
+        t.log = _Log()
+        t.log.warning = lambda *a, **k: None
+        t.weight = weight
+        transform.TelescopeStreamMixIn.setup(t, tel)
+        sp = t.process(ss)
+        cases[f"s{sidx}_weight"] = np.array(weight)
+        cases[f"s{sidx}_mask_pair"] = np.int64(mask_pair)
+        cases[f"s{sidx}_file_ids"] = np.array(file_ids)
+        cases[f"s{sidx}_vis"], cases[f"s{sidx}_w"], cases[f"s{sidx}_flags"] = vis, w, flags
+        cases[f"s{sidx}_stack_prod"], cases[f"s{sidx}_stack_conj"] = stack["prod"], stack["conjugate"]
+        cases[f"s{sidx}_rev_stack"], cases[f"s{sidx}_rev_conj"] = rev["stack"], rev["conjugate"]
+        cases[f"s{sidx}_out_vis"] = sp.vis.arr.view(np.ndarray)
+        cases[f"s{sidx}_out_w"] = sp.weight.arr.view(np.ndarray)
+        sidx += 1
+    cases["nstacked"] = np.int64(sidx)
     cases["nfeed_tel"] = np.int64(nfeed_tel)
     cases["tel_freq"] = np.array(tel_freq)
     np.savez_compressed(os.path.join(out, "transform_collate.npz"), **cases)

@@ -190,7 +190,7 @@ def test_mask_mmode_data_golden(golden_dir):
 
 def test_collate_products_golden(golden_dir):
     """CollateProducts against the reference's own outputs (unstacked full-triangle inputs, extra feed,
-    permuted/extra frequencies, all three weight schemes)."""
+    permuted/extra frequencies, all three weight schemes; already stacked inputs)."""
     import os
 
     from draco_amd.analysis.transform import CollateProducts
@@ -235,6 +235,34 @@ def test_collate_products_golden(golden_dir):
         assert np.array_equal(sp.index_map["stack"]["prod"], g[f"c{i}_out_stack_prod"])
         assert np.array_equal(sp.reverse_map["stack"]["stack"], g[f"c{i}_out_rev_stack"])
         assert np.array_equal(sp.index_map["freq"]["centre"], g["tel_freq"])
+    # already redundancy-stacked inputs: representatives re-derived (input 999 absent, one telescope pair masked)
+    for i in range(int(g["nstacked"])):
+        ids = g[f"s{i}_file_ids"]
+        ninp = len(ids)
+        inputs = np.array([(c,) for c in ids], dtype=[("chan_id", "<u2")])
+        prod = np.array([(a, b) for a in range(ninp) for b in range(a, ninp)], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        stack = np.zeros(len(g[f"s{i}_stack_prod"]), dtype=[("prod", "<u4"), ("conjugate", "u1")])
+        stack["prod"], stack["conjugate"] = g[f"s{i}_stack_prod"], g[f"s{i}_stack_conj"]
+        rev = np.zeros(len(prod), dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        rev["stack"], rev["conjugate"] = g[f"s{i}_rev_stack"], g[f"s{i}_rev_conj"]
+        fm = np.zeros(len(g["tel_freq"]), dtype=[("centre", float), ("width", float)])
+        fm["centre"], fm["width"] = g["tel_freq"], 10.0
+        vis = g[f"s{i}_vis"]
+        ss2 = containers.SiderealStream(freq=fm, ra=vis.shape[-1], input=inputs, prod=prod, stack=stack, reverse_map_stack=rev)
+        assert ss2.is_stacked
+        ss2.vis[:] = vis
+        ss2.weight[:] = g[f"s{i}_w"]
+        ss2.add_dataset("input_flags")
+        ss2.input_flags[:] = g[f"s{i}_flags"]
+        tel.feedmask = np.ones((nfeed, nfeed), bool)
+        if int(g[f"s{i}_mask_pair"]):
+            tel.feedmask[0, 1] = tel.feedmask[1, 0] = False
+        t2 = CollateProducts(weight=str(g[f"s{i}_weight"]))
+        t2.setup(tel)
+        sp = t2.process(ss2)
+        np.testing.assert_allclose(sp.vis[:], g[f"s{i}_out_vis"], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(sp.weight[:], g[f"s{i}_out_w"], rtol=2e-6)
+    tel.feedmask = np.ones((nfeed, nfeed), bool)
     # the telescope needs every one of its frequencies in the file
     tel.frequencies = np.array([400.0, 123.0])
     t.setup(tel)

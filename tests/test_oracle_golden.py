@@ -195,6 +195,23 @@ def test_collate_products(golden_dir):
         np.testing.assert_allclose(v, g[f"c{i}_out_vis"], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(w, g[f"c{i}_out_w"], rtol=1e-6)
         np.testing.assert_array_equal(fl, g[f"c{i}_out_flags"])
+    # already stacked inputs: representatives re-derived (input 999 absent from the telescope, one pair masked)
+    for i in range(int(g["nstacked"])):
+        ids = g[f"s{i}_file_ids"]
+        ninp = len(ids)
+        prod = np.array([(a, b) for a in range(ninp) for b in range(a, ninp)], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        stack = np.zeros(len(g[f"s{i}_stack_prod"]), dtype=[("prod", "<u4"), ("conjugate", "u1")])
+        stack["prod"], stack["conjugate"] = g[f"s{i}_stack_prod"], g[f"s{i}_stack_conj"]
+        rev = np.zeros(len(prod), dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        rev["stack"], rev["conjugate"] = g[f"s{i}_rev_stack"], g[f"s{i}_rev_conj"]
+        feedmask = np.ones((nfeed, nfeed), dtype=bool)
+        if int(g[f"s{i}_mask_pair"]):
+            feedmask[0, 1] = feedmask[1, 0] = False
+        v, w, _ = oc.collate(g[f"s{i}_vis"], g[f"s{i}_w"], g[f"s{i}_flags"], ids, g["tel_freq"], prod, 100 + np.arange(nfeed), g["tel_freq"], feedmap, feedconj,
+                             str(g[f"s{i}_weight"]), stack=stack, reverse_stack=rev, feedmask=feedmask)
+        assert np.abs(g[f"s{i}_out_vis"]).max() > 0
+        np.testing.assert_allclose(v, g[f"s{i}_out_vis"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(w, g[f"s{i}_out_w"], rtol=1e-6)
 
 
 def test_svd_em_and_tasks(golden_dir):
