@@ -115,3 +115,86 @@ def test_cfg3_alm2map_against_oracle():
     _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(a_dev), 1, 4, lmax, lmax, nside, ptr(out)))
     ref = osht.sphtrans_inv_sky(alm, nside)
     assert _rel(out.cpu().numpy(), ref) < 1e-10
+
+
+def test_cfg4_tile_wiener_and_ml_properties():
+    """cfg-4/5 tile size (ntel = 1526 -> padded order 1536, nsky up to 4100): Wiener normal equations; ML on the
+    telescope side (m = 0) and on the sky side (m = 900, order 500) satisfies the least-squares / minimum-norm
+    conditions of the pseudo-inverse with nothing cut, and agrees with the eigen path."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker, WienerMapMaker
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    rng = np.random.default_rng(44)
+    tel = _tel(4, 1)
+    assert tel.npairs == 763
+    bt = SyntheticProvider(tel, seed=44)
+    lmax = 1024
+    w = WienerMapMaker()
+    w.setup(bt)
+    ml = MaximumLikelihoodMapMaker()
+    ml.setup(bt)
+    for m in (0, 900):
+        v = rng.standard_normal((2, 763)) + 1j * rng.standard_normal((2, 763))
+        Ni = rng.uniform(0.5, 1.5, (2, 763)) * 20
+        Ni[rng.uniform(size=Ni.shape) < 0.03] = 0
+        B = osyn.beam_tile(44, m, 0, 763, 4, lmax)[..., m:].reshape(1526, -1)
+        nv, vv = Ni.reshape(-1), v.reshape(-1)
+        a = w._solve_m(m, 0, v, Ni)
+        x = a[:, m:].reshape(-1)
+        S = omm.wiener_prior(lmax, m)
+        lhs = x / S + B.conj().T @ (nv * (B @ x))
+        assert _rel(lhs, B.conj().T @ (nv * vv)) < 1e-10, m
+        a = ml._solve_m(m, 0, v, Ni)
+        x = a[:, m:].reshape(-1)
+        Bt = np.sqrt(nv)[:, None] * B  # D B
+        r = Bt @ x - np.sqrt(nv) * vv
+        if B.shape[1] >= 1526:  # more unknowns than data: exact fit of the weighted data, minimum norm (x in range(Bt^H))
+            assert np.abs(r).max() < 1e-9 * np.abs(np.sqrt(nv) * vv).max(), m
+            y = np.linalg.lstsq(Bt.conj().T, x, rcond=None)[0]
+            assert np.abs(Bt.conj().T @ y - x).max() < 1e-9 * np.abs(x).max(), m
+        else:  # overdetermined: normal equations
+            assert np.abs(Bt.conj().T @ r).max() < 1e-9 * np.abs(Bt.conj().T @ (np.sqrt(nv) * vv)).max(), m
+        try:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+            a_eig = ml._solve_m(m, 0, v, Ni)
+        finally:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        assert _rel(a, a_eig) < 1e-9, m
+
+
+def test_cfg4_sht_roundtrip_nside512():
+    """lmax = 1024, nside = 512 (cfg 4/5's SHT): Bluestein classes up to M = 2048, the direct-sum fallback for the
+    widest cap rings (their M = 4096 transform does not fit the LDS), and a band-limited round trip."""
+    from draco_amd import _lib
+    from draco_amd.device import Context, ptr
+    import torch
+
+    ctx = Context.get()
+    lmax, nside = 1024, 512
+    gen = torch.Generator(device=ctx.device).manual_seed(12)
+    alm = torch.randn((1, 4, lmax + 1, lmax + 1), dtype=torch.complex128, device=ctx.device, generator=gen)  # [f, pol, m, l]
+    m_idx = torch.arange(lmax + 1, device=ctx.device)
+    keep = (m_idx[None, :] >= m_idx[:, None]).to(alm.dtype)  # l >= m
+    alm = alm * keep[None, None]
+    alm[:, :, 0] = alm[:, :, 0].real.to(alm.dtype)  # m = 0 is real
+    alm[:, 1:3, :, :2] = 0                          # E, B start at l = 2
+    alm = alm.contiguous()
+    maps = ctx.empty((1, 4, 12 * nside * nside), np.float64)
+    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), 1, 4, lmax, lmax, nside, ptr(maps)))
+    try:  # every ring through the direct sums
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"sht_variant", 4))
+        maps_d = ctx.empty((1, 4, 12 * nside * nside), np.float64)
+        _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), 1, 4, lmax, lmax, nside, ptr(maps_d)))
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"sht_variant", 0))
+    assert float((maps - maps_d).abs().max()) < 1e-11 * float(maps_d.abs().max())
+    back = ctx.empty((1, 4, lmax + 1, lmax + 1), np.complex128)
+    _lib.check(_lib.lib.dmm_map2alm(ctx.handle, ptr(maps), 1, 4, lmax, lmax, nside, 3, ptr(back)))
+    err = float((back - alm).abs().max()) / float(alm.abs().max())
+    assert err < 5e-5, err  # lmax = 2 nside, white spectrum: the HEALPix quadrature is not exact; 3 Jacobi iterations
+    _lib.check(_lib.lib.dmm_map2alm(ctx.handle, ptr(maps), 1, 4, lmax, lmax, nside, 8, ptr(back)))
+    err8 = float((back - alm).abs().max()) / float(alm.abs().max())
+    assert err8 < 0.5 * err, (err, err8)  # and the iteration converges
