@@ -263,6 +263,167 @@ __global__ __launch_bounds__(kThreads, MINW) void k_leg_synth(LegParams p) {
   }
 }
 
+// ---- synthesis, stage 1 on the matrix cores (NPOL = 4).
+// For one m the Legendre stage is a product: rings x l (lambda, F1, F2, generated by the
+// recurrence) times l x (frequency, component) (the a_lm).  A block owns 256 ring pairs and kLegF
+// frequencies: every thread runs the recurrence of its ring pair for kLegL steps and parks
+// lambda / F1 / F2 in a wave-private LDS slab; the wave then contracts its 64 rings against the
+// a_lm of the kLegF frequencies with v_mfma_f64_16x16x4_f64 -- A = 16 rings x 4 l of one parity
+// (stride-2 rows of the slab), B = 4 l x 16 columns = kLegF frequencies x 4 reals:
+//   TV[par]     += lambda * ( T.x,  T.y,  V.x,  V.y)
+//   QU[par]     += F1     * (-E.x, -E.y, -B.x, -B.y)      Q: -(E F1 + i B F2)
+//   QU[1 - par] += F2     * ( B.y, -B.x, -E.y,  E.x)      U: -(B F1 - i E F2)
+// so the generation cost is shared by the frequencies and the accumulation (3/4 of the flops)
+// leaves the vector ALU.  The slab is written and read by the same wave (LDS operations of a wave
+// complete in order): the l loop has no barrier at all.  Slab pitch 72 doubles: the 16 rings of a
+// lane group and the two l rows of a half wave fall on disjoint banks.
+constexpr int kLegL = 8, kLegF = 4, kLegPitch = 72;
+
+__global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  __shared__ double slab[kThreads / 64][3][kLegL][kLegPitch];
+  const int m = blockIdx.x, rc = blockIdx.y, f0 = blockIdx.z * kLegF;
+  const int lmax = p.g.lmax, nl = lmax - m + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nring = p.g.nring, npair = (nring + 1) / 2;
+  const int64_t mstride = p.g.mmax + 1;
+  double(*sl)[kLegL][kLegPitch] = slab[wave];
+
+  // generation state of this thread's ring pair
+  const int r = rc * kThreads + threadIdx.x;
+  double x = 0.0, inv_s2 = 0.0, xs2 = 0.0, lam = 0.0, lam_prev = 0.0;
+  int nsc = -1;
+  if (r < npair) {
+    const double sth = p.g.sth[r];
+    x = p.g.z[r];
+    inv_s2 = 1.0 / (sth * sth);
+    xs2 = x * inv_s2;
+    if (!ring_skips_m(m, lmax, sth)) lam_start(p.g.lfac[m], m, sth, lam, nsc);
+  }
+  const bool wave_live = __any(nsc >= 0);
+
+  // MFMA operand coordinates of this lane
+  const int li = lane & 15, kq = lane >> 4;
+  const int col = li, fi = col >> 2, c = col & 3, f = f0 + fi;
+  const bool fok = f < p.nf;
+  // B columns as (pointer to the real array of one a_lm column, sign)
+  auto colptr = [&](int pol, int comp) {
+    return reinterpret_cast<const double*>(p.alm + (((int64_t)(fok ? f : 0) * 4 + pol) * p.n_m + m) * (lmax + 1) + m) + comp;
+  };
+  const double* pTV = colptr(c < 2 ? 0 : 3, c & 1);
+  const double* p1 = colptr(c < 2 ? 1 : 2, c & 1);
+  const double* p2 = colptr(c < 2 ? 2 : 1, (c & 1) ^ 1);
+  const double s2 = (c == 0 || c == 3) ? 1.0 : -1.0;
+
+  v4d acc[4][4];  // [ring tile][TV sym, TV anti, QU sym, QU anti]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[t][q] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  if (wave_live) {
+    // The kLegL coefficient rows of a chunk are 64 doubles: one per lane, fetched as ONE coalesced vector
+    // load a whole chunk ahead (its latency hides under the MFMA phase) and broadcast to scalars with
+    // v_readlane when a step needs them -- no scalar-memory wait inside the recurrence.
+    const double* cgv = reinterpret_cast<const double*>(p.g.coef) + 8 * coef_row0(m, lmax);
+    auto fetch_rows = [&](int c0) {
+      const int row = c0 + (lane >> 3);
+      return cgv[8 * (int64_t)(row < nl ? row : nl - 1) + (lane & 7)];
+    };
+    auto bcast = [&](double v, int src) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+      return __hiloint2double(hi, lo);
+    };
+    double cv = fetch_rows(0);
+    for (int c0 = 0; c0 < nl; c0 += kLegL) {
+      const double cv_next = fetch_rows(c0 + kLegL < nl ? c0 + kLegL : c0);
+      // this chunk's B operands: raw, unconditional loads (clamped addresses) that stay in flight under the
+      // recurrence below; signs and the out-of-range zeros are applied when the MFMAs consume them
+      double rTV[2], r1[2], r2[2];
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int k = c0 + 2 * kq + par;
+        const int kc = k < nl ? k : nl - 1;
+        rTV[par] = pTV[2 * kc];
+        r1[par] = p1[2 * kc];
+        r2[par] = p2[2 * kc];
+      }
+      // kLegL steps of the recurrence -> slab
+#pragma unroll
+      for (int kk = 0; kk < kLegL; ++kk) {
+        const int k = c0 + kk;
+        Coef q;
+        q.ra = bcast(cv, 8 * kk + 0);
+        q.rb = bcast(cv, 8 * kk + 1);
+        q.c1 = bcast(cv, 8 * kk + 2);
+        q.c2 = bcast(cv, 8 * kk + 3);
+        q.cd = bcast(cv, 8 * kk + 4);
+        q.c3 = bcast(cv, 8 * kk + 5);
+        q.c4 = bcast(cv, 8 * kk + 6);
+        double le = 0.0, F1 = 0.0, F2 = 0.0;
+        if (k < nl) {
+          if (k > 0 && nsc >= 0) {
+            const double nxt = x * lam * q.ra - lam_prev * q.rb;
+            lam_prev = lam;
+            lam = nxt;
+            if (nsc > 0 && fabs(lam) > kBig) {
+              lam *= kSmallStep;
+              lam_prev *= kSmallStep;
+              --nsc;
+            }
+          }
+          if (nsc == 0) {
+            le = lam;
+            F1 = fma(q.cd * xs2, lam_prev, -fma(q.c1, inv_s2, q.c2) * lam);
+            F2 = fma(q.c4 * inv_s2, lam_prev, -q.c3 * xs2 * lam);
+          }
+        }
+        sl[0][kk][lane] = le;
+        sl[1][kk][lane] = F1;
+        sl[2][kk][lane] = F2;
+      }
+      cv = cv_next;
+      // contraction: two parities x four ring tiles x three matrices
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const bool ok = fok && c0 + 2 * kq + par < nl;
+        const double bTV[2] = {ok ? rTV[0] : 0.0, ok ? rTV[1] : 0.0};
+        const double b1[2] = {ok ? -r1[0] : 0.0, ok ? -r1[1] : 0.0};
+        const double b2[2] = {ok ? s2 * r2[0] : 0.0, ok ? s2 * r2[1] : 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double aL = sl[0][2 * kq + par][16 * t + li];
+          const double a1 = sl[1][2 * kq + par][16 * t + li];
+          const double a2 = sl[2][2 * kq + par][16 * t + li];
+          acc[t][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, bTV[par], acc[t][par], 0, 0, 0);
+          acc[t][2 + par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[par], acc[t][2 + par], 0, 0, 0);
+          acc[t][3 - par] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2[par], acc[t][3 - par], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ring coefficients: north = sym + anti, south = sym - anti; D rows = rings (kq + 4 reg), D columns = this lane's column
+  if (!fok) return;
+  double* bout = reinterpret_cast<double*>(p.b);
+  const int comp = c & 1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int rr = rc * kThreads + wave * 64 + 16 * t + kq + 4 * reg;
+      if (rr >= npair) continue;
+      const int rs = nring - 1 - rr;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {  // g = 0: (T | V), g = 1: (Q | U)
+        const int pol = g == 0 ? (c < 2 ? 0 : 3) : (c < 2 ? 1 : 2);
+        const double sy = acc[t][2 * g][reg], an = acc[t][2 * g + 1][reg];
+        bout[((((int64_t)f * 4 + pol) * nring + rr) * mstride + m) * 2 + comp] = sy + an;
+        if (rs != rr) bout[((((int64_t)f * 4 + pol) * nring + rs) * mstride + m) * 2 + comp] = sy - an;
+      }
+    }
+}
+
 // ---------------------------------------------------------------- ring stages (2 and 1')
 struct RingParams {
   ShtGeom g;
@@ -981,6 +1142,10 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   lp.n_m = n_m;
   lp.alm = alm;
   lp.b = b;
+  if (NPOL == 4 && !(ctx->opt_sht_variant & 8)) {  // bit 3: force the vector-ALU kernel
+    const int npair = (g.nring + 1) / 2;
+    hipLaunchKernelGGL(k_leg_synth_mfma, dim3(g.mmax + 1, (npair + kThreads - 1) / kThreads, (nf + kLegF - 1) / kLegF), dim3(kThreads), 0, ctx->stream, lp);
+  } else
   switch (ctx->opt_sht_variant & 3) {
     case 1: hipLaunchKernelGGL((k_leg_synth<NPOL, 1, 1>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;
     case 2: hipLaunchKernelGGL((k_leg_synth<NPOL, 2, 1>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;
