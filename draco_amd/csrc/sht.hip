@@ -561,36 +561,81 @@ __device__ __forceinline__ dmm_fft::C<double> ring_dft_at(const RingLds& l, int 
 // Synthesis: the Hermitian spectrum H_k = b_k e^{i k phi0} (k <= mmax), H_{N-k} = conj(H_k),
 // folded modulo N, makes the map real, so two polarisations ride one transform:
 // z = H_a + i H_b  ->  IDFT(z) = map_a + i map_b, and IDFT(z) = conj(DFT(conj z)).
-template <int NPOL, bool BLUE>
+// NROW complex transforms per block; for NPOL = 4 transform r carries polarisations 2(r + rb), 2(r + rb) + 1 with
+// rb = blockIdx.z * NROW: the large rings run ONE transform per block so that two blocks fit a CU's LDS.
+template <int NPOL, int NROW, bool BLUE>
 __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, RingClass rc) {
   using dmm_fft::C;
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  const int rb = blockIdx.z * NROW;
   const int ring = class_ring(rc, p.g, blockIdx.x), f = blockIdx.y;
   const int n = p.g.nphi[ring], M = rc.M, P = M + 1;
   const RingLds l = ring_lds<NROW, BLUE>(smem, n, M);
   if (BLUE) __syncthreads();  // the chirp is used by the load below
   const int nm = p.g.mmax + 1;
   const double phi0 = p.g.phi0[ring];
-  const double2* brow[NPOL];
+  const double2 *browa[NROW], *browb[NROW];  // the two polarisations of transform r
 #pragma unroll
-  for (int q = 0; q < NPOL; ++q) brow[q] = p.b + (((int64_t)f * NPOL + q) * p.g.nring + ring) * nm;
+  for (int r = 0; r < NROW; ++r) {
+    browa[r] = p.b + (((int64_t)f * NPOL + (NPOL == 4 ? 2 * (r + rb) : 0)) * p.g.nring + ring) * nm;
+    browb[r] = p.b + (((int64_t)f * NPOL + (NPOL == 4 ? 2 * (r + rb) + 1 : 0)) * p.g.nring + ring) * nm;
+  }
+  // Rings shorter than the band limit (n < nm) alias many m onto one k: there the phase rotation runs in
+  // parallel over m first, into LDS, and the fold below only adds (a fixed order, so still reproducible).
+  const bool aliased = n < nm;
+  C<double>* rot = l.chirp + (BLUE ? 4 * rc.r_hi : 0);  // [NROW][2][nm], present when the class has such rings
+  if (aliased) {
+    for (int m = threadIdx.x; m < nm; m += kFftThreads) {
+      double sn, cs;
+      sincos((double)m * phi0, &sn, &cs);
+#pragma unroll
+      for (int r = 0; r < NROW; ++r) {
+        const double2 va = browa[r][m];
+        C<double> a = {va.x * cs - va.y * sn, va.x * sn + va.y * cs}, b = {0.0, 0.0};
+        if (NPOL == 4) {
+          const double2 vb = browb[r][m];
+          b = {vb.x * cs - vb.y * sn, vb.x * sn + vb.y * cs};
+        }
+        if (m == 0) a.y = b.y = 0.0;  // the m = 0 term of a real field is real
+        rot[(r * 2 + 0) * nm + m] = a;
+        rot[(r * 2 + 1) * nm + m] = b;
+      }
+    }
+    __syncthreads();
+  }
   for (int k = threadIdx.x; k < M; k += kFftThreads) {
     double zr[NROW], zi[NROW];
 #pragma unroll
     for (int r = 0; r < NROW; ++r) zr[r] = zi[r] = 0.0;
-    if (k < n) {
+    if (k < n && aliased) {
+      for (int m = k; m < nm; m += n) {  // direct terms: z += H_a + i H_b
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const C<double> a = rot[(r * 2 + 0) * nm + m], b = rot[(r * 2 + 1) * nm + m];
+          zr[r] += a.x - b.y;
+          zi[r] += a.y + b.x;
+        }
+      }
+      for (int m = (k == 0 ? n : n - k); m < nm; m += n) {  // mirrored terms: z += conj(H_a) + i conj(H_b)
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const C<double> a = rot[(r * 2 + 0) * nm + m], b = rot[(r * 2 + 1) * nm + m];
+          zr[r] += a.x + b.y;
+          zi[r] += b.x - a.y;
+        }
+      }
+    } else if (k < n) {
       // direct terms m == k (mod n)
       for (int m = k; m < nm; m += n) {
         double sn, cs;
         sincos((double)m * phi0, &sn, &cs);
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
-          const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
+          const double2 va = browa[r][m];
           double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
           double br = 0.0, bi = 0.0;
           if (NPOL == 4) {
-            const double2 vb = brow[NPOL == 4 ? 2 * r + 1 : 0][m];
+            const double2 vb = browb[r][m];
             br = vb.x * cs - vb.y * sn;
             bi = vb.x * sn + vb.y * cs;
           }
@@ -605,11 +650,11 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, Ri
         sincos((double)m * phi0, &sn, &cs);
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
-          const double2 va = brow[NPOL == 4 ? 2 * r : 0][m];
+          const double2 va = browa[r][m];
           const double ar = va.x * cs - va.y * sn, ai = va.x * sn + va.y * cs;
           double br = 0.0, bi = 0.0;
           if (NPOL == 4) {
-            const double2 vb = brow[NPOL == 4 ? 2 * r + 1 : 0][m];
+            const double2 vb = browb[r][m];
             br = vb.x * cs - vb.y * sn;
             bi = vb.x * sn + vb.y * cs;
           }
@@ -633,8 +678,8 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, Ri
 #pragma unroll
     for (int r = 0; r < NROW; ++r) {
       const C<double> y = ring_dft_at<BLUE>(l, r, j, M, rc.logM);  // IDFT(z)_j = conj(y)
-      p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * r : 0)) * p.npix + base + j] = y.x;
-      if (NPOL == 4) p.map[((int64_t)f * NPOL + 2 * r + 1) * p.npix + base + j] = -y.y;
+      p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * (r + rb) : 0)) * p.npix + base + j] = y.x;
+      if (NPOL == 4) p.map[((int64_t)f * NPOL + 2 * (r + rb) + 1) * p.npix + base + j] = -y.y;
     }
   }
 }
@@ -687,11 +732,11 @@ __global__ __launch_bounds__(kThreads) void k_ring_anal(RingParams p, RingClass 
 
 // FFT version: x = map_a + i map_b, X = DFT_N(x); the two real fields separate through
 // A_k = (X_k + conj X_{N-k}) / 2, B_k = (X_k - conj X_{N-k}) / (2i); g_m = w e^{-i m phi0} A_{m mod N}.
-template <int NPOL, bool BLUE>
+template <int NPOL, int NROW, bool BLUE>
 __global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, RingClass rc) {
   using dmm_fft::C;
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  const int rb = blockIdx.z * NROW;
   const int ring = class_ring(rc, p.g, blockIdx.x), f = blockIdx.y;
   const int n = p.g.nphi[ring], M = rc.M, P = M + 1;
   const RingLds l = ring_lds<NROW, BLUE>(smem, n, M);
@@ -702,8 +747,8 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, Rin
     for (int r = 0; r < NROW; ++r) {
       C<double> v = {0.0, 0.0};
       if (k < n) {
-        v.x = p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * r : 0)) * p.npix + base + k];
-        if (NPOL == 4) v.y = p.map[((int64_t)f * NPOL + 2 * r + 1) * p.npix + base + k];
+        v.x = p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * (r + rb) : 0)) * p.npix + base + k];
+        if (NPOL == 4) v.y = p.map[((int64_t)f * NPOL + 2 * (r + rb) + 1) * p.npix + base + k];
         if (BLUE) v = dmm_fft::cmul<double>(v, l.chirp[k]);
       }
       l.buf[r * P + k] = v;
@@ -723,11 +768,11 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, Rin
     for (int r = 0; r < NROW; ++r) {
       const C<double> X = ring_dft_at<BLUE>(l, r, k, M, rc.logM), Y = ring_dft_at<BLUE>(l, r, k2, M, rc.logM);
       const double ar = 0.5 * (X.x + Y.x), ai = 0.5 * (X.y - Y.y);
-      p.b[(((int64_t)f * NPOL + (NPOL == 4 ? 2 * r : 0)) * p.g.nring + ring) * nm + m] =
+      p.b[(((int64_t)f * NPOL + (NPOL == 4 ? 2 * (r + rb) : 0)) * p.g.nring + ring) * nm + m] =
           make_double2(w * (ar * c0 - ai * s0), w * (ar * s0 + ai * c0));
       if (NPOL == 4) {
         const double br = 0.5 * (X.y + Y.y), bi = -0.5 * (X.x - Y.x);
-        p.b[(((int64_t)f * NPOL + 2 * r + 1) * p.g.nring + ring) * nm + m] =
+        p.b[(((int64_t)f * NPOL + 2 * (r + rb) + 1) * p.g.nring + ring) * nm + m] =
             make_double2(w * (br * c0 - bi * s0), w * (br * s0 + bi * c0));
       }
     }
@@ -1117,10 +1162,12 @@ std::vector<ClassLaunch> ring_classes(const ShtGeom& g) {
 }
 
 // LDS bytes of the FFT ring kernels for a class; 0 if the class must take the direct kernel
-size_t ring_fft_lds(const ShtGeom& g, const ClassLaunch& c, int nrow, int force_direct) {
+size_t ring_fft_lds(const ShtGeom& g, const ClassLaunch& c, int nrow, int force_direct, bool synth = false) {
   if (force_direct) return 0;
   if (c.blue && c.rc.r_hi > g.blue_rmax) return 0;
-  const size_t lds = ((size_t)nrow * (c.rc.M + 1) + c.rc.M / 2 + (c.blue ? c.nphi_max : 0)) * sizeof(double2);
+  // synthesis: rings shorter than the band limit stage their rotated coefficients [nrow][2][mmax+1] (k_ring_synth_fft)
+  const size_t rot = synth && c.blue && 4 * c.rc.r_lo < g.mmax + 1 ? (size_t)nrow * 2 * (g.mmax + 1) : 0;
+  const size_t lds = ((size_t)nrow * (c.rc.M + 1) + c.rc.M / 2 + (c.blue ? c.nphi_max : 0) + rot) * sizeof(double2);
   return lds <= 160 * 1024 ? lds : 0;
 }
 
@@ -1160,17 +1207,20 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   rp.b = b;
   rp.map = map;
   rp.npix = 12LL * g.nside * g.nside;
-  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  constexpr int NROWS = NPOL == 4 ? 2 : 1;  // complex transforms per ring (two polarisations each)
   const int force_direct = ctx->opt_sht_variant & 4;
   for (const ClassLaunch& c : ring_classes(g)) {
-    const size_t lds = ring_fft_lds(g, c, NROW, force_direct);
+    const size_t lds2 = ring_fft_lds(g, c, NROWS, force_direct, true), lds1 = ring_fft_lds(g, c, 1, force_direct, true);
     int rc;
-    if (lds == 0)
+    if (lds1 == 0) {
       rc = launch_ring(k_ring_synth<NPOL>, dim3(c.nblock, nf), kThreads, (size_t)NPOL * (g.mmax + 1) * sizeof(double2), ctx->stream, rp, c.rc);
-    else if (c.blue)
-      rc = launch_ring(k_ring_synth_fft<NPOL, true>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
-    else
-      rc = launch_ring(k_ring_synth_fft<NPOL, false>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
+    } else if (NROWS == 2 && lds2 != 0 && lds2 <= 80 * 1024) {  // both transforms in one block while two blocks still fit a CU
+      rc = c.blue ? launch_ring(k_ring_synth_fft<NPOL, NROWS, true>, dim3(c.nblock, nf), kFftThreads, lds2, ctx->stream, rp, c.rc)
+                  : launch_ring(k_ring_synth_fft<NPOL, NROWS, false>, dim3(c.nblock, nf), kFftThreads, lds2, ctx->stream, rp, c.rc);
+    } else {
+      rc = c.blue ? launch_ring(k_ring_synth_fft<NPOL, 1, true>, dim3(c.nblock, nf, NROWS), kFftThreads, lds1, ctx->stream, rp, c.rc)
+                  : launch_ring(k_ring_synth_fft<NPOL, 1, false>, dim3(c.nblock, nf, NROWS), kFftThreads, lds1, ctx->stream, rp, c.rc);
+    }
     if (rc) return rc;
   }
   return DMM_OK;
@@ -1185,17 +1235,20 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   rp.b = b;
   rp.map = const_cast<double*>(map);
   rp.npix = 12LL * g.nside * g.nside;
-  constexpr int NROW = NPOL == 4 ? 2 : 1;
+  constexpr int NROWS = NPOL == 4 ? 2 : 1;
   const int force_direct = ctx->opt_sht_variant & 4;
   for (const ClassLaunch& c : ring_classes(g)) {
-    const size_t lds = ring_fft_lds(g, c, NROW, force_direct);
+    const size_t lds2 = ring_fft_lds(g, c, NROWS, force_direct), lds1 = ring_fft_lds(g, c, 1, force_direct);
     int rc;
-    if (lds == 0)
+    if (lds1 == 0) {
       rc = launch_ring(k_ring_anal<NPOL>, dim3(c.nblock, nf), kThreads, (size_t)NPOL * c.nphi_max * sizeof(double), ctx->stream, rp, c.rc);
-    else if (c.blue)
-      rc = launch_ring(k_ring_anal_fft<NPOL, true>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
-    else
-      rc = launch_ring(k_ring_anal_fft<NPOL, false>, dim3(c.nblock, nf), kFftThreads, lds, ctx->stream, rp, c.rc);
+    } else if (NROWS == 2 && lds2 != 0 && lds2 <= 80 * 1024) {
+      rc = c.blue ? launch_ring(k_ring_anal_fft<NPOL, NROWS, true>, dim3(c.nblock, nf), kFftThreads, lds2, ctx->stream, rp, c.rc)
+                  : launch_ring(k_ring_anal_fft<NPOL, NROWS, false>, dim3(c.nblock, nf), kFftThreads, lds2, ctx->stream, rp, c.rc);
+    } else {
+      rc = c.blue ? launch_ring(k_ring_anal_fft<NPOL, 1, true>, dim3(c.nblock, nf, NROWS), kFftThreads, lds1, ctx->stream, rp, c.rc)
+                  : launch_ring(k_ring_anal_fft<NPOL, 1, false>, dim3(c.nblock, nf, NROWS), kFftThreads, lds1, ctx->stream, rp, c.rc);
+    }
     if (rc) return rc;
   }
   LegAnalParams lp;
