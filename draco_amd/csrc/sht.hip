@@ -993,6 +993,185 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
   }
 }
 
+// ---- analysis, stage 2' on the matrix cores (NPOL = 4).
+// a_lm = sum over ring pairs of {lambda, F1, F2}(ring, l) x ring data: for one m a product
+// (l x ring) . (ring x (frequency, component)).  A block owns one m and kLegF frequencies; each of its 8
+// waves owns 64 ring pairs: the lanes run the recurrences of their ring for kAnL steps and park lambda in a
+// wave-private LDS slab; the wave then contracts its rings, four per MFMA, against the ring data it
+// keeps in registers for the whole kernel:
+//   TV[q] += lambda x (T, V)_q            q = 0 / 1: the north+south / north-south combination
+//   EB[q] += F1 x (-Q, -U)_q  +  F2 x (U.y, -U.x, -Q.y, Q.x)_{1-q}
+// with M = 16 consecutive l (rows of parity q are the valid ones of tile q: l parity = row parity),
+// K = 4 rings, N = 16 = kLegF frequencies x 4 reals.  F1 / F2 are formed from lambda_l, lambda_{l-1} of the
+// slab and the lane's own l coefficients when the operand is built, so the slab holds lambda only.  The
+// F2 operand is the F1 operand with its four columns reversed and two signs flipped: one DPP move.
+// The 8 waves' tiles are summed through LDS in a fixed order once per chunk and added to a_lm.
+constexpr int kAnL = 16, kAnPitch = 66, kAnThreads = 512, kAnWaves = kAnThreads / 64;
+
+__global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  __shared__ double slab[kAnWaves][kAnL + 1][kAnPitch];  // row 0: lambda of the step before the chunk
+  __shared__ double ringtab[kAnWaves][2][64];            // x / sin^2, 1 / sin^2 of the wave's rings
+  __shared__ double red[kAnWaves][2][kAnL][16];          // per-wave output tiles of one chunk
+  const int m = blockIdx.x, f0 = blockIdx.y * kLegF;
+  const int lmax = p.g.lmax, nl = lmax - m + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nring = p.g.nring, npair = (nring + 1) / 2;
+  const int64_t mstride = p.g.mmax + 1;
+  const double* cgv = reinterpret_cast<const double*>(p.g.coef) + 8 * coef_row0(m, lmax);
+  double(*sl)[kAnPitch] = slab[wave];
+  double* alm_d = reinterpret_cast<double*>(p.alm);
+
+  // structural zeros l < m
+  for (int idx = threadIdx.x; idx < kLegF * 4 * m; idx += kAnThreads) {
+    const int fp = idx / m, l = idx - fp * m;
+    const int f = f0 + (fp >> 2);
+    if (f < p.nf) p.alm[(((int64_t)f * 4 + (fp & 3)) * p.n_m + m) * (lmax + 1) + l] = make_double2(0.0, 0.0);
+  }
+
+  const int li = lane & 15, kq = lane >> 4;
+  const int col = li, fi = col >> 2, c = col & 3, f = f0 + fi;
+  const bool fok = f < p.nf;
+  const double* bsrc = reinterpret_cast<const double*>(p.b);
+
+  for (int r0 = 0; r0 < npair; r0 += kAnThreads) {  // ring super-chunks of 512 pairs (one at nside <= 256)
+    // generation state of this thread's ring pair
+    const int r = r0 + threadIdx.x;
+    double x = 0.0, inv_s2 = 0.0, xs2 = 0.0, lam = 0.0, lam_prev = 0.0;
+    int nsc = -1;
+    if (r < npair) {
+      const double sth = p.g.sth[r];
+      x = p.g.z[r];
+      inv_s2 = 1.0 / (sth * sth);
+      xs2 = x * inv_s2;
+      if (!ring_skips_m(m, lmax, sth)) lam_start(p.g.lfac[m], m, sth, lam, nsc);
+    }
+    ringtab[wave][0][lane] = xs2;
+    ringtab[wave][1][lane] = inv_s2;
+    sl[0][lane] = 0.0;
+    const bool wave_live = __any(nsc >= 0);
+
+    // ring data of the wave's 64 pairs as MFMA B operands, kept for every l: per K step ks the lane holds
+    // column `col` of ring 4 ks + kq -- (T | V) and -(Q | U), north+south and north-south
+    double bTV[16][2], g1[16][2];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int rr = r0 + wave * 64 + 4 * ks + kq;
+      double tn = 0.0, ts = 0.0, qn = 0.0, qs = 0.0;
+      if (wave_live && fok && rr < npair) {
+        const int rs = nring - 1 - rr;
+        const int64_t on = (((int64_t)f * 4) * nring + rr) * mstride + m, os = (((int64_t)f * 4) * nring + rs) * mstride + m;
+        const int64_t pstride = (int64_t)nring * mstride;
+        const int polTV = c < 2 ? 0 : 3, pol1 = c < 2 ? 1 : 2, comp = c & 1;
+        tn = bsrc[(on + polTV * pstride) * 2 + comp];
+        qn = bsrc[(on + pol1 * pstride) * 2 + comp];
+        if (rs != rr) {
+          ts = bsrc[(os + polTV * pstride) * 2 + comp];
+          qs = bsrc[(os + pol1 * pstride) * 2 + comp];
+        }
+      }
+      bTV[ks][0] = tn + ts;
+      bTV[ks][1] = tn - ts;
+      g1[ks][0] = -(qn + qs);
+      g1[ks][1] = -(qn - qs);
+    }
+    const double sg2 = (c == 0 || c == 3) ? -1.0 : 1.0;  // g2[c] = sg2 * g1[3 - c]
+
+    auto fetch_rows = [&](int row0) {  // 8 coefficient rows, one double per lane
+      const int row = row0 + (lane >> 3);
+      return cgv[8 * (int64_t)(row < nl ? row : nl - 1) + (lane & 7)];
+    };
+    auto bcast = [&](double v, int src) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+      return __hiloint2double(hi, lo);
+    };
+    double cvA = fetch_rows(0), cvB = fetch_rows(8);
+
+    for (int c0 = 0; c0 < nl; c0 += kAnL) {
+      v4d acc[4];  // TV q=0, TV q=1, EB q=0, EB q=1
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+      if (wave_live) {
+        const double cvA_next = fetch_rows(c0 + kAnL < nl ? c0 + kAnL : c0);
+        const double cvB_next = fetch_rows(c0 + kAnL < nl ? c0 + kAnL + 8 : c0 + 8);
+        // this lane's l = c0 + li: the spin-2 factors of its A operands
+        const int lrow = c0 + li < nl ? c0 + li : nl - 1;
+        const double qc1 = cgv[8 * (int64_t)lrow + 2], qc2 = cgv[8 * (int64_t)lrow + 3], qcd = cgv[8 * (int64_t)lrow + 4];
+        const double qc3 = cgv[8 * (int64_t)lrow + 5], qc4 = cgv[8 * (int64_t)lrow + 6];
+        // kAnL steps of the recurrence -> slab rows 1..kAnL
+#pragma unroll
+        for (int kk = 0; kk < kAnL; ++kk) {
+          const int k = c0 + kk;
+          const double ra = bcast(kk < 8 ? cvA : cvB, 8 * (kk & 7) + 0);
+          const double rb = bcast(kk < 8 ? cvA : cvB, 8 * (kk & 7) + 1);
+          double le = 0.0;
+          if (k < nl) {
+            if (k > 0 && nsc >= 0) {
+              const double nxt = x * lam * ra - lam_prev * rb;
+              lam_prev = lam;
+              lam = nxt;
+              if (nsc > 0 && fabs(lam) > kBig) {
+                lam *= kSmallStep;
+                lam_prev *= kSmallStep;
+                --nsc;
+              }
+            }
+            if (nsc == 0) le = lam;
+          }
+          sl[1 + kk][lane] = le;
+        }
+        cvA = cvA_next;
+        cvB = cvB_next;
+        // contraction over the wave's rings, four per step
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const int rk = 4 * ks + kq;
+          const double aL = sl[1 + li][rk], aP = sl[li][rk];
+          const double rx = ringtab[wave][0][rk], ri = ringtab[wave][1][rk];
+          const double a1 = fma(qcd * rx, aP, -fma(qc1, ri, qc2) * aL);
+          const double a2 = fma(qc4 * ri, aP, -qc3 * rx * aL);
+          // F2 operands: columns reversed within each frequency (quad_perm 3,2,1,0), signs (-,+,+,-)
+          double g2[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int lo = __builtin_amdgcn_mov_dpp(__double2loint(g1[ks][q]), 0x1b, 0xf, 0xf, true);
+            const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(g1[ks][q]), 0x1b, 0xf, 0xf, true);
+            g2[q] = sg2 * __hiloint2double(hi, lo);
+          }
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, bTV[ks][0], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, bTV[ks][1], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g1[ks][0], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g1[ks][1], acc[3], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g2[1], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g2[0], acc[3], 0, 0, 0);
+        }
+        sl[0][lane] = sl[kAnL][lane];  // lambda of the last step: "l - 1" of the next chunk
+      }
+      // rows of parity q are the valid rows of tile q: row = kq + 4 reg has the parity of kq (c0 is even)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        red[wave][0][kq + 4 * reg][li] = (kq & 1) ? acc[1][reg] : acc[0][reg];
+        red[wave][1][kq + 4 * reg][li] = (kq & 1) ? acc[3][reg] : acc[2][reg];
+      }
+      __syncthreads();
+      {  // one value per thread: fixed-order sum over the waves, then into a_lm
+        const int tile = threadIdx.x >> 8, row = (threadIdx.x >> 4) & 15, oc = threadIdx.x & 15;
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < kAnWaves; ++w) sum += red[w][tile][row][oc];
+        const int k = c0 + row, of = f0 + (oc >> 2), cc = oc & 3;
+        if (k < nl && of < p.nf) {
+          const int pol = tile == 0 ? (cc < 2 ? 0 : 3) : (cc < 2 ? 1 : 2);
+          double* dst = alm_d + ((((int64_t)of * 4 + pol) * p.n_m + m) * (lmax + 1) + m + k) * 2 + (cc & 1);
+          *dst = (p.accumulate || r0 > 0) ? *dst + sum : sum;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __global__ void k_sub(double* __restrict__ a, const double* __restrict__ b, int64_t n) {  // a = b - a
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1259,6 +1438,11 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   lp.b = b;
   lp.alm = alm;
   lp.accumulate = accumulate;
+  if (NPOL == 4 && !(ctx->opt_sht_variant & 8)) {  // bit 3: force the vector-ALU kernels
+    hipLaunchKernelGGL(k_leg_anal_mfma, dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(kAnThreads), 0, ctx->stream, lp);
+    DMM_HIP(hipGetLastError());
+    return DMM_OK;
+  }
   constexpr int NV = NPOL == 4 ? 8 : 2;
   const size_t lds2 = (size_t)(g.lmax + 1) * NV * sizeof(double) + (size_t)2 * (kThreads / 64) * kAnalBatch * NV * sizeof(double);
   DMM_HIP(hipFuncSetAttribute((const void*)k_leg_anal<NPOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
