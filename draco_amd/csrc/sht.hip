@@ -996,30 +996,30 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
 // ---- analysis, stage 2' on the matrix cores (NPOL = 4).
 // a_lm = sum over ring pairs of {lambda, F1, F2}(ring, l) x ring data: for one m a product
 // (l x ring) . (ring x (frequency, component)).  A block owns one m and kLegF frequencies; each of its 8
-// waves owns 64 ring pairs: the lanes run the recurrences of their ring for kAnL steps and park lambda in a
-// wave-private LDS slab; the wave then contracts its rings, four per MFMA, against the ring data it
+// waves owns 64 ring pairs: the lanes run the recurrences of their ring for kAnL = 32 steps and park lambda
+// in a wave-private LDS slab; the wave then contracts its rings, four per MFMA, against the ring data it
 // keeps in registers for the whole kernel:
 //   TV[q] += lambda x (T, V)_q            q = 0 / 1: the north+south / north-south combination
 //   EB[q] += F1 x (-Q, -U)_q  +  F2 x (U.y, -U.x, -Q.y, Q.x)_{1-q}
-// with M = 16 consecutive l (rows of parity q are the valid ones of tile q: l parity = row parity),
+// with M = the 16 l of parity q of the chunk (rows 2i + q of the slab: every row of every tile is used),
 // K = 4 rings, N = 16 = kLegF frequencies x 4 reals.  F1 / F2 are formed from lambda_l, lambda_{l-1} of the
 // slab and the lane's own l coefficients when the operand is built, so the slab holds lambda only.  The
 // F2 operand is the F1 operand with its four columns reversed and two signs flipped: one DPP move.
-// The 8 waves' tiles are summed through LDS in a fixed order once per chunk and added to a_lm.
-constexpr int kAnL = 16, kAnPitch = 66, kAnThreads = 512, kAnWaves = kAnThreads / 64;
+// The 8 waves' tiles are parked in their (then free) slabs, summed in a fixed order once per chunk and
+// added to a_lm.  Slab pitch 65: the 16 rows (stride 2) x 2 rings of a half wave fall on disjoint banks.
+constexpr int kAnL = 32, kAnPitch = 65, kAnThreads = 512, kAnWaves = kAnThreads / 64;
 
 __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
   typedef double v4d __attribute__((ext_vector_type(4)));
-  __shared__ double slab[kAnWaves][kAnL + 1][kAnPitch];  // row 0: lambda of the step before the chunk
-  __shared__ double ringtab[kAnWaves][2][64];            // x / sin^2, 1 / sin^2 of the wave's rings
-  __shared__ double red[kAnWaves][2][kAnL][16];          // per-wave output tiles of one chunk
+  __shared__ double slab[kAnWaves][(kAnL + 1) * kAnPitch];  // row 0: lambda of the step before the chunk
+  __shared__ double ringtab[kAnWaves][2][64];                // x / sin^2, 1 / sin^2 of the wave's rings
   const int m = blockIdx.x, f0 = blockIdx.y * kLegF;
   const int lmax = p.g.lmax, nl = lmax - m + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nring = p.g.nring, npair = (nring + 1) / 2;
   const int64_t mstride = p.g.mmax + 1;
   const double* cgv = reinterpret_cast<const double*>(p.g.coef) + 8 * coef_row0(m, lmax);
-  double(*sl)[kAnPitch] = slab[wave];
+  double* sl = slab[wave];
   double* alm_d = reinterpret_cast<double*>(p.alm);
 
   // structural zeros l < m
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
     }
     ringtab[wave][0][lane] = xs2;
     ringtab[wave][1][lane] = inv_s2;
-    sl[0][lane] = 0.0;
+    sl[lane] = 0.0;
     const bool wave_live = __any(nsc >= 0);
 
     // ring data of the wave's 64 pairs as MFMA B operands, kept for every l: per K step ks the lane holds
@@ -1077,34 +1077,40 @@ __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
     }
     const double sg2 = (c == 0 || c == 3) ? -1.0 : 1.0;  // g2[c] = sg2 * g1[3 - c]
 
-    auto fetch_rows = [&](int row0) {  // 8 coefficient rows, one double per lane
-      const int row = row0 + (lane >> 3);
-      return cgv[8 * (int64_t)(row < nl ? row : nl - 1) + (lane & 7)];
+    auto fetch_rr = [&](int row0) {  // (ra, rb) of the chunk's 32 rows: one double per lane
+      const int row = row0 + (lane >> 1);
+      return cgv[8 * (int64_t)(row < nl ? row : nl - 1) + (lane & 1)];
     };
     auto bcast = [&](double v, int src) {
       const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
       const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
       return __hiloint2double(hi, lo);
     };
-    double cvA = fetch_rows(0), cvB = fetch_rows(8);
+    double cvr = fetch_rr(0);
 
     for (int c0 = 0; c0 < nl; c0 += kAnL) {
       v4d acc[4];  // TV q=0, TV q=1, EB q=0, EB q=1
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
       if (wave_live) {
-        const double cvA_next = fetch_rows(c0 + kAnL < nl ? c0 + kAnL : c0);
-        const double cvB_next = fetch_rows(c0 + kAnL < nl ? c0 + kAnL + 8 : c0 + 8);
-        // this lane's l = c0 + li: the spin-2 factors of its A operands
-        const int lrow = c0 + li < nl ? c0 + li : nl - 1;
-        const double qc1 = cgv[8 * (int64_t)lrow + 2], qc2 = cgv[8 * (int64_t)lrow + 3], qcd = cgv[8 * (int64_t)lrow + 4];
-        const double qc3 = cgv[8 * (int64_t)lrow + 5], qc4 = cgv[8 * (int64_t)lrow + 6];
+        const double cvr_next = fetch_rr(c0 + kAnL < nl ? c0 + kAnL : c0);
+        // this lane's two l (one per parity tile): the spin-2 factors of its A operands
+        double qc1[2], qc2[2], qcd[2], qc3[2], qc4[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int lrow = c0 + 2 * li + q < nl ? c0 + 2 * li + q : nl - 1;
+          const double* cr = cgv + 8 * (int64_t)lrow;
+          qc1[q] = cr[2];
+          qc2[q] = cr[3];
+          qcd[q] = cr[4];
+          qc3[q] = cr[5];
+          qc4[q] = cr[6];
+        }
         // kAnL steps of the recurrence -> slab rows 1..kAnL
 #pragma unroll
         for (int kk = 0; kk < kAnL; ++kk) {
           const int k = c0 + kk;
-          const double ra = bcast(kk < 8 ? cvA : cvB, 8 * (kk & 7) + 0);
-          const double rb = bcast(kk < 8 ? cvA : cvB, 8 * (kk & 7) + 1);
+          const double ra = bcast(cvr, 2 * kk), rb = bcast(cvr, 2 * kk + 1);
           double le = 0.0;
           if (k < nl) {
             if (k > 0 && nsc >= 0) {
@@ -1119,19 +1125,21 @@ __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
             }
             if (nsc == 0) le = lam;
           }
-          sl[1 + kk][lane] = le;
+          sl[(1 + kk) * kAnPitch + lane] = le;
         }
-        cvA = cvA_next;
-        cvB = cvB_next;
+        cvr = cvr_next;
         // contraction over the wave's rings, four per step
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           const int rk = 4 * ks + kq;
-          const double aL = sl[1 + li][rk], aP = sl[li][rk];
+          // lambda at l - 1, l (parity 0 row), l + 1 (parity 1 row) of this lane's row pair
+          const double l0 = sl[(2 * li) * kAnPitch + rk], l1 = sl[(2 * li + 1) * kAnPitch + rk], l2 = sl[(2 * li + 2) * kAnPitch + rk];
           const double rx = ringtab[wave][0][rk], ri = ringtab[wave][1][rk];
-          const double a1 = fma(qcd * rx, aP, -fma(qc1, ri, qc2) * aL);
-          const double a2 = fma(qc4 * ri, aP, -qc3 * rx * aL);
-          // F2 operands: columns reversed within each frequency (quad_perm 3,2,1,0), signs (-,+,+,-)
+          const double a1e = fma(qcd[0] * rx, l0, -fma(qc1[0], ri, qc2[0]) * l1);
+          const double a2e = fma(qc4[0] * ri, l0, -qc3[0] * rx * l1);
+          const double a1o = fma(qcd[1] * rx, l1, -fma(qc1[1], ri, qc2[1]) * l2);
+          const double a2o = fma(qc4[1] * ri, l1, -qc3[1] * rx * l2);
+          // F2 data: columns reversed within each frequency (quad_perm 3,2,1,0), signs (-,+,+,-)
           double g2[2];
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
@@ -1139,27 +1147,35 @@ __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
             const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(g1[ks][q]), 0x1b, 0xf, 0xf, true);
             g2[q] = sg2 * __hiloint2double(hi, lo);
           }
-          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, bTV[ks][0], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL, bTV[ks][1], acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g1[ks][0], acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, g1[ks][1], acc[3], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g2[1], acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, g2[0], acc[3], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, bTV[ks][0], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l2, bTV[ks][1], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1e, g1[ks][0], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1o, g1[ks][1], acc[3], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2e, g2[1], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2o, g2[0], acc[3], 0, 0, 0);
         }
-        sl[0][lane] = sl[kAnL][lane];  // lambda of the last step: "l - 1" of the next chunk
+        sl[lane] = sl[kAnL * kAnPitch + lane];  // lambda of the last step: "l - 1" of the next chunk
       }
-      // rows of parity q are the valid rows of tile q: row = kq + 4 reg has the parity of kq (c0 is even)
+      // park the tiles in the (now free) rows 1.. of the own slab as [TV | EB][l row 0..31][16 columns]:
+      // tile q row i = kq + 4 reg is l row 2 i + q
+      double* out = sl + kAnPitch;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        red[wave][0][kq + 4 * reg][li] = (kq & 1) ? acc[1][reg] : acc[0][reg];
-        red[wave][1][kq + 4 * reg][li] = (kq & 1) ? acc[3][reg] : acc[2][reg];
+        const int i = kq + 4 * reg;
+        out[(0 * kAnL + 2 * i + 0) * 16 + li] = acc[0][reg];
+        out[(0 * kAnL + 2 * i + 1) * 16 + li] = acc[1][reg];
+        out[(1 * kAnL + 2 * i + 0) * 16 + li] = acc[2][reg];
+        out[(1 * kAnL + 2 * i + 1) * 16 + li] = acc[3][reg];
       }
       __syncthreads();
-      {  // one value per thread: fixed-order sum over the waves, then into a_lm
-        const int tile = threadIdx.x >> 8, row = (threadIdx.x >> 4) & 15, oc = threadIdx.x & 15;
+      // two values per thread: fixed-order sum over the waves, then into a_lm
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int idx = threadIdx.x + h * kAnThreads;  // [tile][row][col]
+        const int tile = idx >> 9, row = (idx >> 4) & 31, oc = idx & 15;
         double sum = 0.0;
 #pragma unroll
-        for (int w = 0; w < kAnWaves; ++w) sum += red[w][tile][row][oc];
+        for (int w = 0; w < kAnWaves; ++w) sum += slab[w][kAnPitch + idx];
         const int k = c0 + row, of = f0 + (oc >> 2), cc = oc & 3;
         if (k < nl && of < p.nf) {
           const int pol = tile == 0 ? (cc < 2 ? 0 : 3) : (cc < 2 ? 1 : 2);
