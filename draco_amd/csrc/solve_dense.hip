@@ -49,8 +49,13 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int TB = 64;        // tile edge (rows and columns of an output tile)
-constexpr int KC = 16;        // complex columns per staged chunk
-constexpr int LP = 2 * KC + 2;  // LDS row pitch in doubles: == 2 (mod 32) -> conflict-free ds_read_b64
+constexpr int KC = 16;        // complex columns per staged chunk (32 halves the barriers per MFMA but also the blocks per CU: 7 % slower)
+constexpr int CPT = KC / 4;   // complex columns a thread stages per operand and chunk
+// LDS row pitch in doubles.  The compiler pairs the two row-tile reads of an operand into ds_read2_b64, whose
+// banking is (dword address) mod 32 over 16 contiguous lanes (MI355X_MICROARCH.md, LDS): the 16 rows of a lane
+// group must step through the 32 banks in twos, i.e. an ODD pitch in doubles (the even pitch 2 KC + 2 this
+// started with was 2-way conflicted: SQ_LDS_BANK_CONFLICT = 8 extra cycles per LDS instruction in the Gram kernel).
+constexpr int LP = 2 * KC + 1;
 
 enum { MODE_GRAM = 0, MODE_UPDATE = 1, MODE_PANEL = 2, MODE_GRAMX = 3 };
 
@@ -100,25 +105,25 @@ __device__ __forceinline__ int order_of(const DenseParams& p, const dmm_tile& t)
 // registers, commit() -> LDS as doubles [64][LP] (re, im interleaved).
 // SRC: 0 = beam tile (gram), 1 = matrix A, 2 = Linv block.
 template <int SRC>
-__device__ __forceinline__ void fetch(double2 (&v)[4], const DenseParams& p, const dmm_tile& tile, int mat, int row0,
+__device__ __forceinline__ void fetch(double2 (&v)[CPT], const DenseParams& p, const dmm_tile& tile, int mat, int row0,
                                       int k0, int K, bool scale_s) {
-  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
   const int row = row0 + r;
   if (SRC == 0) {
     const int L = p.lmax + 1 - tile.m;
     int k = k0 + c0;
     if (!p.full_layout && p.b_c128 && (K & 3) == 0) {
       // fast path (packed complex128 tiles, npol*L a multiple of 4): the row is contiguous in k and the
-      // thread's 4 columns are all inside or all outside -> four 16-byte loads, one predicate
-      const bool in = row < p.N && k < K;
+      // thread's columns are inside or outside in groups of four -> 16-byte loads, one predicate per group
+      const bool rin = row < p.N;
       const double2* src = reinterpret_cast<const double2*>(p.B) + tile.b_off + (int64_t)row * K + k;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = in ? src[c] : make_double2(0.0, 0.0);
-      if (scale_s && p.Sl && in) {
+      for (int c = 0; c < CPT; ++c) v[c] = (rin && k + (c & ~3) < K) ? src[c] : make_double2(0.0, 0.0);
+      if (scale_s && p.Sl && rin) {
         int lrel = k % L;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double sc = p.Sl[tile.m + lrel];
+        for (int c = 0; c < CPT; ++c) {
+          const double sc = k + c < K ? p.Sl[tile.m + lrel] : 0.0;
           v[c].x *= sc;
           v[c].y *= sc;
           if (++lrel == L) lrel = 0;
@@ -131,7 +136,7 @@ __device__ __forceinline__ void fetch(double2 (&v)[4], const DenseParams& p, con
       for (int q = 1; q < p.npol; ++q) pol += (k >= q * L);
       int lrel = k - pol * L;
 #pragma unroll
-      for (int c = 0; c < 4; ++c, ++k) {
+      for (int c = 0; c < CPT; ++c, ++k) {
         v[c] = make_double2(0.0, 0.0);
         if (row < p.N && k < K) {
           v[c] = load_bc(p.B, p.b_c128, rbase + (int64_t)pol * pol_stride + lrel);
@@ -149,27 +154,30 @@ __device__ __forceinline__ void fetch(double2 (&v)[4], const DenseParams& p, con
     }
   } else if (SRC == 1) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CPT; ++c) {
       const int k = k0 + c0 + c;
       v[c] = k < K ? p.A[((int64_t)mat * p.Np + row) * p.Np + k] : make_double2(0.0, 0.0);
     }
   } else if (SRC == 2) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CPT; ++c)
       v[c] = p.Linv[(((int64_t)mat * p.T + p.J) * TB + (row - row0)) * TB + k0 + c0 + c];
   } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CPT; ++c) {
       const int k = k0 + c0 + c;
       v[c] = (row < order_of(p, tile) && k < K) ? p.X[((int64_t)mat * p.Np + row) * p.ldx + k] : make_double2(0.0, 0.0);
     }
   }
 }
 
-__device__ __forceinline__ void commit(double* lds, const double2 (&v)[4]) {
-  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
+__device__ __forceinline__ void commit(double* lds, const double2 (&v)[CPT]) {
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) *reinterpret_cast<double2*>(lds + r * LP + 2 * (c0 + c)) = v[c];
+  for (int c = 0; c < CPT; ++c) {  // rows are 8-byte aligned only (odd pitch): two 8-byte stores
+    lds[r * LP + 2 * (c0 + c)] = v[c].x;
+    lds[r * LP + 2 * (c0 + c) + 1] = v[c].y;
+  }
 }
 
 // One 64x64 complex output tile C(I,J) per block; 4 waves, each a 32x32 quadrant = 2x2 MFMA tiles.
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  double2 xr[4], yr[4];
+  double2 xr[CPT], yr[CPT];
   auto fetch_chunk = [&](int k0) {
     if (MODE == MODE_GRAM) {
       fetch<0>(xr, p, tile, mat, I0, k0, K, false);
@@ -762,11 +770,11 @@ __global__ __launch_bounds__(kThreads) void k_bj_apply(BjParams bp) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 4;
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
   for (int k0 = 0; k0 < TB; k0 += KC) {
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < CPT; ++c) {
       const int k = k0 + c0 + c;                       // contraction index 0..63 over the pair's rows/cols
       const int gk = k < JB ? P0 + k : Q0 + k - JB;    // its global row/column
       double2 xv, yv;
@@ -778,8 +786,10 @@ __global__ __launch_bounds__(kThreads) void k_bj_apply(BjParams bp) {
         const double2 t = T[(int64_t)gk * n + T0 + r];  // Y[j][k] = conj(A[row(k)][j])
         yv = make_double2(t.x, -t.y);
       }
-      *reinterpret_cast<double2*>(xs + r * LP + 2 * (c0 + c)) = xv;
-      *reinterpret_cast<double2*>(ys + r * LP + 2 * (c0 + c)) = yv;
+      xs[r * LP + 2 * (c0 + c)] = xv.x;
+      xs[r * LP + 2 * (c0 + c) + 1] = xv.y;
+      ys[r * LP + 2 * (c0 + c)] = yv.x;
+      ys[r * LP + 2 * (c0 + c) + 1] = yv.y;
     }
     __syncthreads();
 #pragma unroll
