@@ -55,7 +55,10 @@ class Slab:
             self.plan = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the binding module may already be gone
+            pass
 
 
 class SolveEngine:
