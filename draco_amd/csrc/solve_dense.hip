@@ -34,438 +34,9 @@
 //   k_dirty (w mode, solve_dirty.hip)  a = S o B^H w
 // The complex products run on v_mfma_f64_16x16x4_f64 through the real embedding
 //   Re = [Xr Xi].[Yr Yi]^T,  Im = [Xr Xi].[-Yi Yr]^T   (4 real k per 2 complex k).
-#include <math.h>
-#include <string.h>
-
-#include <algorithm>
-#include <map>
-#include <vector>
-
-#include "dmm_internal.h"
+#include "dense_kernels.h"
 
 namespace {
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;
-constexpr int TB = 64;        // tile edge (rows and columns of an output tile)
-constexpr int KC = 16;        // complex columns per staged chunk (32 halves the barriers per MFMA but also the blocks per CU: 7 % slower)
-constexpr int CPT = KC / 4;   // complex columns a thread stages per operand and chunk
-// LDS row pitch in doubles.  The compiler pairs the two row-tile reads of an operand into ds_read2_b64, whose
-// banking is (dword address) mod 32 over 16 contiguous lanes (MI355X_MICROARCH.md, LDS): the 16 rows of a lane
-// group must step through the 32 banks in twos, i.e. an ODD pitch in doubles (the even pitch 2 KC + 2 this
-// started with was 2-way conflicted: SQ_LDS_BANK_CONFLICT = 8 extra cycles per LDS instruction in the Gram kernel).
-constexpr int LP = 2 * KC + 1;
-
-enum { MODE_GRAM = 0, MODE_UPDATE = 1, MODE_PANEL = 2, MODE_GRAMX = 3 };
-
-struct DenseParams {
-  // batch
-  const dmm_tile* tiles;   // plan tiles (device), this sub-batch starts at tile0
-  int64_t tile0;
-  int nmat;
-  int N, Np, T;            // matrix order, padded order (multiple of 64), Np/64
-  // gram sources
-  const void* B;
-  int b_c128, full_layout;
-  int npairs, npol, lmax, nfreq;
-  const double2* mvis;
-  const double* mweight;
-  const double* Sl;        // [lmax+1] prior per l, or nullptr (S = 1)
-  int add_identity;
-  // storage
-  double2* A;              // [nmat][Np][Np]
-  double2* Linv;           // [nmat][T][64][64]
-  double2* wbuf;           // [nmat][N]
-  int J;                   // current column block (update / panel / diag)
-  // ML extras
-  int sky;                 // 1: the matrices are sky-side (order npol*(lmax+1-m)), rhs/solution live in alm
-  const double2* X;        // [nmat][Np][ldx] rows of (D B)^H for the sky-side Gram (MODE_GRAMX)
-  int ldx;                 // row pitch of X (>= 2*npairs)
-  double2* alm;            // [nfreq][npol][n_m][lmax+1] (sky side: rhs in, solution out)
-  int n_m;
-  int* fail;               // [nmat] set when a Cholesky pivot is not positive (nullptr: not tracked)
-  const int* msel;         // Jacobi kernels: matrix index of the k-th selected matrix (nullptr: identity)
-  double* theta;           // [nmat] upper bound of the largest eigenvalue
-};
-
-__device__ __forceinline__ double2 load_bc(const void* B, int c128, int64_t off) {
-  if (c128) return reinterpret_cast<const double2*>(B)[off];
-  const float2 v = reinterpret_cast<const float2*>(B)[off];
-  return make_double2((double)v.x, (double)v.y);
-}
-
-// order of one matrix of the batch: sky-side batches mix tiles of several m (one padded order Np)
-__device__ __forceinline__ int order_of(const DenseParams& p, const dmm_tile& t) {
-  return p.sky ? p.npol * (p.lmax + 1 - t.m) : p.N;
-}
-
-// Staging of rows [row0, row0+64) x complex columns [k0, k0+KC) of an operand, split in two so the
-// global loads of chunk k+1 fly under the MFMAs of chunk k: fetch() -> 4 complex values per thread in
-// registers, commit() -> LDS as doubles [64][LP] (re, im interleaved).
-// SRC: 0 = beam tile (gram), 1 = matrix A, 2 = Linv block.
-template <int SRC>
-__device__ __forceinline__ void fetch(double2 (&v)[CPT], const DenseParams& p, const dmm_tile& tile, int mat, int row0,
-                                      int k0, int K, bool scale_s) {
-  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
-  const int row = row0 + r;
-  if (SRC == 0) {
-    const int L = p.lmax + 1 - tile.m;
-    int k = k0 + c0;
-    if (!p.full_layout && p.b_c128 && (K & 3) == 0) {
-      // fast path (packed complex128 tiles, npol*L a multiple of 4): the row is contiguous in k and the
-      // thread's columns are inside or outside in groups of four -> 16-byte loads, one predicate per group
-      const bool rin = row < p.N;
-      const double2* src = reinterpret_cast<const double2*>(p.B) + tile.b_off + (int64_t)row * K + k;
-#pragma unroll
-      for (int c = 0; c < CPT; ++c) v[c] = (rin && k + (c & ~3) < K) ? src[c] : make_double2(0.0, 0.0);
-      if (scale_s && p.Sl && rin) {
-        int lrel = k % L;
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-          const double sc = k + c < K ? p.Sl[tile.m + lrel] : 0.0;
-          v[c].x *= sc;
-          v[c].y *= sc;
-          if (++lrel == L) lrel = 0;
-        }
-      }
-    } else {
-      const int pol_stride = p.full_layout ? p.lmax + 1 : L;
-      const int64_t rbase = tile.b_off + (int64_t)row * p.npol * pol_stride + (p.full_layout ? tile.m : 0);
-      int pol = 0;  // pol = k / L without a division (npol is tiny)
-      for (int q = 1; q < p.npol; ++q) pol += (k >= q * L);
-      int lrel = k - pol * L;
-#pragma unroll
-      for (int c = 0; c < CPT; ++c, ++k) {
-        v[c] = make_double2(0.0, 0.0);
-        if (row < p.N && k < K) {
-          v[c] = load_bc(p.B, p.b_c128, rbase + (int64_t)pol * pol_stride + lrel);
-          if (scale_s && p.Sl) {
-            const double sc = p.Sl[tile.m + lrel];
-            v[c].x *= sc;
-            v[c].y *= sc;
-          }
-        }
-        if (++lrel == L) {
-          lrel = 0;
-          ++pol;
-        }
-      }
-    }
-  } else if (SRC == 1) {
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      const int k = k0 + c0 + c;
-      v[c] = k < K ? p.A[((int64_t)mat * p.Np + row) * p.Np + k] : make_double2(0.0, 0.0);
-    }
-  } else if (SRC == 2) {
-#pragma unroll
-    for (int c = 0; c < CPT; ++c)
-      v[c] = p.Linv[(((int64_t)mat * p.T + p.J) * TB + (row - row0)) * TB + k0 + c0 + c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      const int k = k0 + c0 + c;
-      v[c] = (row < order_of(p, tile) && k < K) ? p.X[((int64_t)mat * p.Np + row) * p.ldx + k] : make_double2(0.0, 0.0);
-    }
-  }
-}
-
-__device__ __forceinline__ void commit(double* lds, const double2 (&v)[CPT]) {
-  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
-#pragma unroll
-  for (int c = 0; c < CPT; ++c) {  // rows are 8-byte aligned only (odd pitch): two 8-byte stores
-    lds[r * LP + 2 * (c0 + c)] = v[c].x;
-    lds[r * LP + 2 * (c0 + c) + 1] = v[c].y;
-  }
-}
-
-// One 64x64 complex output tile C(I,J) per block; 4 waves, each a 32x32 quadrant = 2x2 MFMA tiles.
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
-  __shared__ __align__(16) double xs[TB * LP];
-  __shared__ __align__(16) double ys[TB * LP];
-  const int mat = blockIdx.y;
-  const dmm_tile tile = p.tiles[p.tile0 + mat];
-  int bi, bj;
-  if (MODE == MODE_GRAM || MODE == MODE_GRAMX) {
-    const int tt = blockIdx.x;
-    bi = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5);
-    while ((bi + 1) * (bi + 2) / 2 <= tt) ++bi;
-    while (bi * (bi + 1) / 2 > tt) --bi;
-    bj = tt - bi * (bi + 1) / 2;
-  } else if (MODE == MODE_UPDATE) {
-    bi = p.J + blockIdx.x;
-    bj = p.J;
-  } else {
-    bi = p.J + 1 + blockIdx.x;
-    bj = p.J;
-  }
-  const int I0 = bi * TB, J0 = bj * TB;
-  const int K = MODE == MODE_GRAM    ? p.npol * (p.lmax + 1 - tile.m)
-                : MODE == MODE_GRAMX ? 2 * p.npairs
-                : MODE == MODE_UPDATE ? p.J * TB
-                                      : TB;
-  const int kbase = MODE == MODE_PANEL ? J0 : 0;  // panel: X = A(I, J-block columns)
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-  v4d cre[2][2], cim[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-  double2 xr[CPT], yr[CPT];
-  auto fetch_chunk = [&](int k0) {
-    if (MODE == MODE_GRAM) {
-      fetch<0>(xr, p, tile, mat, I0, k0, K, false);
-      fetch<0>(yr, p, tile, mat, J0, k0, K, true);
-    } else if (MODE == MODE_GRAMX) {
-      fetch<3>(xr, p, tile, mat, I0, k0, K, false);
-      fetch<3>(yr, p, tile, mat, J0, k0, K, false);
-    } else if (MODE == MODE_UPDATE) {
-      fetch<1>(xr, p, tile, mat, I0, k0, K, false);
-      fetch<1>(yr, p, tile, mat, J0, k0, K, false);
-    } else {
-      fetch<1>(xr, p, tile, mat, I0, kbase + k0, kbase + K, false);
-      fetch<2>(yr, p, tile, mat, 0, k0, K, false);
-    }
-  };
-  if (K > 0) fetch_chunk(0);
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    __syncthreads();  // the previous chunk's MFMAs have read LDS
-    commit(xs, xr);
-    commit(ys, yr);
-    __syncthreads();
-    if (k0 + KC < K) fetch_chunk(k0 + KC);  // in flight under this chunk's MFMAs
-#pragma unroll
-    for (int kk = 0; kk < 2 * KC; kk += 4) {
-      double a[2], b[2], b2[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = xs[(32 * wr + 16 * t + lr) * LP + kk + lk];
-        b[t] = ys[(32 * wc + 16 * t + lr) * LP + kk + lk];
-        const double o = ys[(32 * wc + 16 * t + lr) * LP + kk + (lk ^ 1)];
-        b2[t] = (lk & 1) ? o : -o;
-      }
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-          cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], cre[ti][tj], 0, 0, 0);
-          cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b2[tj], cim[ti][tj], 0, 0, 0);
-        }
-    }
-  }
-
-  // epilogue: lane holds rows (lk + 4*reg), column lr of each 16x16 tile
-#pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = I0 + 32 * wr + 16 * ti + lk + 4 * reg;
-        const int j = J0 + 32 * wc + 16 * tj + lr;
-        double2* dst = p.A + ((int64_t)mat * p.Np + i) * p.Np + j;
-        double re = cre[ti][tj][reg], im = cim[ti][tj][reg];
-        if (MODE == MODE_GRAM) {
-          double di = 0.0, dj = 0.0;
-          if (i < p.N) {
-            const int s = i >= p.npairs, pp = i - s * p.npairs;
-            di = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
-          }
-          if (j < p.N) {
-            const int s = j >= p.npairs, pp = j - s * p.npairs;
-            dj = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
-          }
-          re *= di * dj;
-          im *= di * dj;
-          if (i == j) {
-            im = 0.0;  // Hermitian diagonal is real by construction; drop rounding dust
-            if (p.add_identity) re += 1.0;  // padded rows (d = 0): unit diagonal for Cholesky, zero eigenvalue for ML
-          }
-          *dst = make_double2(re, im);
-        } else if (MODE == MODE_GRAMX) {
-          if (i == j) im = 0.0;
-          *dst = make_double2(re, im);
-        } else if (MODE == MODE_UPDATE) {
-          const double2 old = *dst;
-          *dst = make_double2(old.x - re, old.y - im);
-        } else {
-          *dst = make_double2(re, im);
-        }
-      }
-}
-
-// Factor the 64x64 diagonal block J of every matrix in LDS and invert the factor.
-__global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
-  extern __shared__ __align__(16) unsigned char smem_cd[];
-  double2(*a)[TB + 1] = reinterpret_cast<double2(*)[TB + 1]>(smem_cd);
-  double2(*li)[TB + 1] = a + TB;
-  const int mat = blockIdx.x;
-  const int J0 = p.J * TB;
-  double2* Ablk = p.A + ((int64_t)mat * p.Np + J0) * p.Np + J0;
-  for (int idx = threadIdx.x; idx < TB * TB; idx += kThreads) {
-    const int i = idx >> 6, j = idx & 63;
-    a[i][j] = j <= i ? Ablk[(int64_t)i * p.Np + j] : make_double2(0.0, 0.0);
-  }
-  __syncthreads();
-  for (int k = 0; k < TB; ++k) {
-    const double akk = a[k][k].x;
-    if (p.fail && threadIdx.x == 0 && !(akk > 0.0)) p.fail[mat] = 1;  // not positive definite (NaN included)
-    const double d = sqrt(akk);
-    const double inv = 1.0 / d;
-    __syncthreads();
-    if (threadIdx.x == 0) a[k][k] = make_double2(d, 0.0);
-    for (int i = k + 1 + threadIdx.x; i < TB; i += kThreads) {
-      a[i][k].x *= inv;
-      a[i][k].y *= inv;
-    }
-    __syncthreads();
-    // trailing update of the lower triangle: a[i][j] -= a[i][k] conj(a[j][k]),  k < j <= i
-    const int n = TB - 1 - k;
-    for (int idx = threadIdx.x; idx < n * n; idx += kThreads) {
-      const int i = k + 1 + idx / n, j = k + 1 + idx % n;
-      if (j <= i) {
-        const double2 x = a[i][k], y = a[j][k];
-        a[i][j].x -= x.x * y.x + x.y * y.y;
-        a[i][j].y -= x.y * y.x - x.x * y.y;
-      }
-    }
-    __syncthreads();
-  }
-  // inverse of the lower-triangular factor: column j by forward substitution (one thread per column)
-  if (threadIdx.x < TB) {
-    const int j = threadIdx.x;
-    for (int i = 0; i < TB; ++i) li[i][j] = make_double2(0.0, 0.0);
-    li[j][j] = make_double2(1.0 / a[j][j].x, 0.0);
-    for (int i = j + 1; i < TB; ++i) {
-      double sx = 0.0, sy = 0.0;
-      for (int q = j; q < i; ++q) {
-        const double2 l = a[i][q], x = li[q][j];
-        sx += l.x * x.x - l.y * x.y;
-        sy += l.x * x.y + l.y * x.x;
-      }
-      const double inv = 1.0 / a[i][i].x;
-      li[i][j] = make_double2(-sx * inv, -sy * inv);
-    }
-  }
-  __syncthreads();
-  double2* Lout = p.Linv + ((int64_t)mat * p.T + p.J) * TB * TB;
-  for (int idx = threadIdx.x; idx < TB * TB; idx += kThreads) {
-    const int i = idx >> 6, j = idx & 63;
-    Ablk[(int64_t)i * p.Np + j] = a[i][j];  // upper part zeroed
-    Lout[idx] = li[i][j];
-  }
-}
-
-// y = L^-H L^-1 (D v); w = D y.  One block per matrix, the vector lives in LDS.
-__global__ __launch_bounds__(kThreads) void k_chol_solve(DenseParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  double2* y = reinterpret_cast<double2*>(smem);  // [Np]
-  double2* t = y + p.Np;                          // [64]
-  double2* red = t + TB;                          // [4][64]
-  const int mat = blockIdx.x;
-  const dmm_tile tile = p.tiles[p.tile0 + mat];
-  const double2* A = p.A + (int64_t)mat * p.Np * p.Np;
-  const int Lsky = p.lmax + 1 - tile.m, N = order_of(p, tile);
-  for (int i = threadIdx.x; i < p.Np; i += kThreads) {
-    double2 b = make_double2(0.0, 0.0);
-    if (i < N) {
-      if (p.sky) {  // rhs = B^H Ni v, left in alm by the dirty pass
-        const int pol = i / Lsky, lrel = i - pol * Lsky;
-        b = p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel];
-      } else {
-        const int s = i >= p.npairs, pp = i - s * p.npairs;
-        const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
-        const double d = sqrt(p.mweight[o]);
-        const double2 v = p.mvis[o];
-        b = make_double2(d * v.x, d * v.y);
-      }
-    }
-    y[i] = b;
-  }
-  __syncthreads();
-  const int i64 = threadIdx.x & 63, part = threadIdx.x >> 6;
-  // forward: L z = b, block row by block row
-  for (int J = 0; J < p.T; ++J) {
-    const int r = J * TB + i64;
-    double sx = 0.0, sy = 0.0;
-    for (int k = part; k < J * TB; k += 4) {  // each of 4 thread groups takes every 4th column
-      const double2 l = A[(int64_t)r * p.Np + k], z = y[k];
-      sx += l.x * z.x - l.y * z.y;
-      sy += l.x * z.y + l.y * z.x;
-    }
-    red[part * TB + i64] = make_double2(sx, sy);
-    __syncthreads();
-    if (part == 0) {
-      double2 s = y[r];
-      for (int q = 0; q < 4; ++q) {
-        s.x -= red[q * TB + i64].x;
-        s.y -= red[q * TB + i64].y;
-      }
-      t[i64] = s;
-    }
-    __syncthreads();
-    if (part == 0) {  // z_J = Linv_J t   (lower triangular)
-      const double2* Li = p.Linv + (((int64_t)mat * p.T + J) * TB + i64) * TB;
-      double zx = 0.0, zy = 0.0;
-      for (int q = 0; q <= i64; ++q) {
-        const double2 l = Li[q], v = t[q];
-        zx += l.x * v.x - l.y * v.y;
-        zy += l.x * v.y + l.y * v.x;
-      }
-      y[r] = make_double2(zx, zy);
-    }
-    __syncthreads();
-  }
-  // backward: L^H x = z
-  for (int J = p.T - 1; J >= 0; --J) {
-    const int c = J * TB + i64;
-    double sx = 0.0, sy = 0.0;
-    for (int k = (J + 1) * TB + part; k < p.Np; k += 4) {  // conj(L[k][c]) * x[k]; lanes -> adjacent c: coalesced
-      const double2 l = A[(int64_t)k * p.Np + c], z = y[k];
-      sx += l.x * z.x + l.y * z.y;
-      sy += l.x * z.y - l.y * z.x;
-    }
-    red[part * TB + i64] = make_double2(sx, sy);
-    __syncthreads();
-    if (part == 0) {
-      double2 s = y[c];
-      for (int q = 0; q < 4; ++q) {
-        s.x -= red[q * TB + i64].x;
-        s.y -= red[q * TB + i64].y;
-      }
-      t[i64] = s;
-    }
-    __syncthreads();
-    if (part == 0) {  // x_J = Linv_J^H t
-      const double2* Lb = p.Linv + ((int64_t)mat * p.T + J) * TB * TB;
-      double zx = 0.0, zy = 0.0;
-      for (int q = i64; q < TB; ++q) {
-        const double2 l = Lb[q * TB + i64], v = t[q];
-        zx += l.x * v.x + l.y * v.y;
-        zy += l.x * v.y - l.y * v.x;
-      }
-      y[c] = make_double2(zx, zy);
-    }
-    __syncthreads();
-  }
-  if (p.fail && p.fail[mat]) return;  // not certified: the eigen path owns this tile's output
-  for (int i = threadIdx.x; i < N; i += kThreads) {
-    if (p.sky) {
-      const int pol = i / Lsky, lrel = i - pol * Lsky;
-      p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel] = y[i];
-    } else {
-      const int s = i >= p.npairs, pp = i - s * p.npairs;
-      const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
-      p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * y[i].x, d * y[i].y);
-    }
-  }
-}
 
 // ---------------------------------------------------------------- ML: certificate of "nothing cut"
 // X[mat][k][i] = d_i conj(B[i][k]): the rows of (D B)^H, so that the NT tile product gives B^H Ni B
@@ -540,295 +111,6 @@ __global__ __launch_bounds__(kThreads) void k_shift_copy(DenseParams p, double2*
     if (i == j) v = (i >= N || v.x == 0.0) ? make_double2(pin, 0.0) : make_double2(v.x - shift, 0.0);
     dst[idx] = v;
   }
-}
-
-// ---------------------------------------------------------------- Hermitian Jacobi (ML)
-// Cyclic two-sided Jacobi on G (Np x Np, full storage after mirroring), eigenvectors
-// accumulated in V; one block per matrix, rotations of a round applied by rows then columns.
-// Round-robin ordering gives Np/2 disjoint pairs per round.  O(sweeps * Np^3): meant for the
-// moderate orders of the parity configs; see DESIGN.md for the blocked successor.
-struct JacobiParams {
-  DenseParams d;
-  double2* V;      // [nmat][Np][Np]
-  double acond, rcond;
-  int max_sweeps;
-};
-
-__global__ __launch_bounds__(kThreads) void k_mirror(DenseParams p) {  // fill the upper triangle: A[j][i] = conj(A[i][j])
-  const int mat = blockIdx.y;
-  double2* A = p.A + (int64_t)mat * p.Np * p.Np;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)p.Np * p.Np;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx / p.Np), j = (int)(idx % p.Np);
-    if (j > i) {
-      const double2 v = A[(int64_t)j * p.Np + i];
-      A[idx] = make_double2(v.x, -v.y);
-    }
-  }
-}
-
-// ---- blocked two-sided Jacobi.  Blocks of 32 rows/columns; a "pair" (P, Q) is a 64x64
-// Hermitian sub-problem solved to convergence in LDS (k_bj_sub); its unitary W is applied
-// to the block columns of A and V and to the block rows of A with the f64-MFMA tile product
-// (k_bj_apply).  Round-robin over block pairs: nb-1 rounds of nb/2 disjoint pairs per sweep.
-constexpr int JB = 32;  // block size
-
-__device__ __forceinline__ void rr_pair(int round, int k, int players, int& a, int& b) {
-  // round-robin tournament: player `players-1` is fixed, the others rotate
-  const int m1 = players - 1;
-  if (k == 0) {
-    a = m1;
-    b = round % m1;
-  } else {
-    a = (round + k) % m1;
-    b = (round - k + m1) % m1;
-  }
-  if (a > b) {
-    const int t = a;
-    a = b;
-    b = t;
-  }
-}
-
-struct BjParams {
-  DenseParams d;
-  double2* V;       // [nmat][Np][Np]
-  double2* Wh;      // [nmat][npairs_blk][64][64]  W^H of each pair's sub-problem (row-major)
-  int* flag;        // [nmat][npairs_blk] 1 = rotation to apply
-  double* scale;    // [nmat] spectrum scale (max diagonal)
-  int round;        // current outer round
-  int nb;           // number of 32-blocks
-  int target;       // k_bj_apply: 0 = A columns, 1 = V columns, 2 = A rows
-  int inner_sweeps; // cap on the in-LDS Jacobi sweeps per visit (W stays exactly unitary either way)
-  int* any_rot;     // device word: set when any pair of the sweep still needed a rotation
-};
-
-__global__ __launch_bounds__(kThreads) void k_bj_init(BjParams bp) {  // V = I, scale = max diag
-  const DenseParams& p = bp.d;
-  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y, n = p.Np;
-  double2* V = bp.V + (int64_t)mat * n * n;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int i = (int)(idx / n), j = (int)(idx % n);
-    V[idx] = make_double2(i == j ? 1.0 : 0.0, 0.0);
-  }
-  if (blockIdx.x == 0) {
-    __shared__ double red[kThreads];
-    const double2* A = p.A + (int64_t)mat * n * n;
-    double mx = 0.0;
-    for (int i = threadIdx.x; i < n; i += kThreads) mx = fmax(mx, fabs(A[(int64_t)i * n + i].x));
-    red[threadIdx.x] = mx;
-    __syncthreads();
-    for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
-      if (threadIdx.x < s2) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s2]);
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) bp.scale[mat] = red[0];
-  }
-}
-
-// Solve one 64x64 Hermitian sub-problem per block entirely in LDS (cyclic Jacobi, parallel
-// ordering: 63 rounds of 32 disjoint rotations per sweep), emit W^H.
-__global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
-  extern __shared__ __align__(16) unsigned char smem_bj[];
-  constexpr int M = 2 * JB, MP = M + 1;
-  double2(*s)[MP] = reinterpret_cast<double2(*)[MP]>(smem_bj);
-  double2(*w)[MP] = s + M;
-  __shared__ double rc[M / 2];
-  __shared__ double2 rs[M / 2];
-  __shared__ int pa[M / 2], pb[M / 2];
-  __shared__ int any_rot, need, work;
-  const DenseParams& p = bp.d;
-  const int pr = blockIdx.x, mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y, n = p.Np;
-  int P, Q;
-  rr_pair(bp.round, pr, bp.nb, P, Q);
-  const int P0 = P * JB, Q0 = Q * JB;
-  const double2* A = p.A + (int64_t)mat * n * n;
-  const double scale = bp.scale[mat];
-  // off-diagonals below 1e-14 of the spectrum's scale are converged (the MFMA block updates
-  // re-inject O(eps * sqrt(n)) noise, a tighter test would never settle); the eigenvalue cut of the
-  // ML filter sits at 1e-6 of the scale, eight digits above this
-  const double tol2 = 1e-28 * scale * scale;
-  if (threadIdx.x == 0) need = work = 0;
-  __syncthreads();
-  int my_need = 0, my_work = 0;
-  for (int idx = threadIdx.x; idx < M * M; idx += kThreads) {
-    const int i = idx / M, j = idx % M;
-    const int gi = i < JB ? P0 + i : Q0 + i - JB, gj = j < JB ? P0 + j : Q0 + j - JB;
-    const double2 v = A[(int64_t)gi * n + gj];
-    s[i][j] = v;
-    w[i][j] = make_double2(i == j ? 1.0 : 0.0, 0.0);
-    const double a2 = v.x * v.x + v.y * v.y;
-    if (i != j && a2 > tol2) my_need = 1;
-    // the sweep loop on the host stops once no pair holds an off-diagonal above 1e-11 of the scale
-    // (eigenvalues then carry errors ~ delta^2 / gap); elements between 1e-14 and 1e-11 are still
-    // rotated here but are at the level the MFMA block updates re-inject, so they never all vanish
-    if (i != j && a2 > tol2 * 1e6) my_work = 1;
-  }
-  if (my_need) need = 1;
-  if (my_work) work = 1;
-  __syncthreads();
-  int* flag = bp.flag + (int64_t)mat * (bp.nb / 2) + pr;
-  if (!need) {  // already diagonal to working precision: nothing to rotate
-    if (threadIdx.x == 0) *flag = 0;
-    return;
-  }
-  if (threadIdx.x == 0 && work) *bp.any_rot = 1;  // benign race: every writer stores 1
-  for (int sweep = 0; sweep < bp.inner_sweeps; ++sweep) {
-    if (threadIdx.x == 0) any_rot = 0;
-    __syncthreads();
-    for (int r = 0; r < M - 1; ++r) {
-      if (threadIdx.x < M / 2) {
-        int a, b;
-        rr_pair(r, threadIdx.x, M, a, b);
-        const double app = s[a][a].x, aqq = s[b][b].x;
-        const double2 apq = s[a][b];
-        const double mag2 = apq.x * apq.x + apq.y * apq.y;
-        double c = 1.0;
-        double2 sn = make_double2(0.0, 0.0);
-        if (mag2 > tol2 * (1.0 / 64.0)) {
-          const double mag = sqrt(mag2);
-          const double tau = (aqq - app) / (2.0 * mag);
-          const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + tt * tt);
-          const double sr = tt * c;
-          sn = make_double2(sr * apq.x / mag, sr * apq.y / mag);
-          any_rot = 1;
-        }
-        rc[threadIdx.x] = c;
-        rs[threadIdx.x] = sn;
-        pa[threadIdx.x] = a;
-        pb[threadIdx.x] = b;
-      }
-      __syncthreads();
-      // columns of S and W:  new_p = c col_p - conj(s) col_q ; new_q = s col_p + c col_q
-      for (int idx = threadIdx.x; idx < M * (M / 2); idx += kThreads) {
-        const int row = idx / (M / 2), k = idx % (M / 2);
-        const double2 sn = rs[k];
-        if (sn.x == 0.0 && sn.y == 0.0) continue;
-        const double c = rc[k];
-        const int a = pa[k], b = pb[k];
-        {
-          const double2 x = s[row][a], y = s[row][b];
-          s[row][a] = make_double2(c * x.x - (sn.x * y.x + sn.y * y.y), c * x.y - (sn.x * y.y - sn.y * y.x));
-          s[row][b] = make_double2(sn.x * x.x - sn.y * x.y + c * y.x, sn.x * x.y + sn.y * x.x + c * y.y);
-        }
-        {
-          const double2 x = w[row][a], y = w[row][b];
-          w[row][a] = make_double2(c * x.x - (sn.x * y.x + sn.y * y.y), c * x.y - (sn.x * y.y - sn.y * y.x));
-          w[row][b] = make_double2(sn.x * x.x - sn.y * x.y + c * y.x, sn.x * x.y + sn.y * x.x + c * y.y);
-        }
-      }
-      __syncthreads();
-      // rows of S:  new_p = c row_p - s row_q ; new_q = conj(s) row_p + c row_q
-      for (int idx = threadIdx.x; idx < (M / 2) * M; idx += kThreads) {
-        const int k = idx / M, col = idx % M;
-        const double2 sn = rs[k];
-        if (sn.x == 0.0 && sn.y == 0.0) continue;
-        const double c = rc[k];
-        const int a = pa[k], b = pb[k];
-        const double2 x = s[a][col], y = s[b][col];
-        s[a][col] = make_double2(c * x.x - (sn.x * y.x - sn.y * y.y), c * x.y - (sn.x * y.y + sn.y * y.x));
-        s[b][col] = make_double2(sn.x * x.x + sn.y * x.y + c * y.x, sn.x * x.y - sn.y * x.x + c * y.y);
-      }
-      __syncthreads();
-    }
-    if (!any_rot) break;
-    __syncthreads();
-  }
-  double2* Wh = bp.Wh + ((int64_t)mat * (bp.nb / 2) + pr) * M * M;
-  for (int idx = threadIdx.x; idx < M * M; idx += kThreads) {
-    const int j = idx / M, k = idx % M;
-    const double2 v = w[k][j];
-    Wh[idx] = make_double2(v.x, -v.y);  // W^H[j][k] = conj(W[k][j])
-  }
-  if (threadIdx.x == 0) *flag = 1;
-}
-
-// Apply the pair's rotation with the MFMA tile product (K = 64):
-//   target 0/1: T[I-tile rows, pair columns] <- T[:, pair columns] W      (T = A or V)
-//   target 2  : A[pair rows, J-tile columns] <- W^H A[pair rows, :]
-__global__ __launch_bounds__(kThreads) void k_bj_apply(BjParams bp) {
-  __shared__ __align__(16) double xs[TB * LP];
-  __shared__ __align__(16) double ys[TB * LP];
-  const DenseParams& p = bp.d;
-  const int tileidx = blockIdx.x, pr = blockIdx.y, mat = p.msel ? p.msel[blockIdx.z] : blockIdx.z, n = p.Np;
-  if (!bp.flag[(int64_t)mat * (bp.nb / 2) + pr]) return;
-  int P, Q;
-  rr_pair(bp.round, pr, bp.nb, P, Q);
-  const int P0 = P * JB, Q0 = Q * JB;
-  double2* T = (bp.target == 1 ? bp.V : p.A) + (int64_t)mat * n * n;
-  const double2* Wh = bp.Wh + ((int64_t)mat * (bp.nb / 2) + pr) * TB * TB;
-  const int T0 = tileidx * TB;  // first row (targets 0/1) or first column (target 2) of this tile
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-  v4d cre[2][2], cim[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
-  for (int k0 = 0; k0 < TB; k0 += KC) {
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      const int k = k0 + c0 + c;                       // contraction index 0..63 over the pair's rows/cols
-      const int gk = k < JB ? P0 + k : Q0 + k - JB;    // its global row/column
-      double2 xv, yv;
-      if (bp.target != 2) {
-        xv = T[(int64_t)(T0 + r) * n + gk];            // X[i][k] = T[i][col(k)]
-        yv = Wh[r * TB + k];                           // Y[j][k] = W^H[j][k]
-      } else {
-        xv = Wh[r * TB + k];                           // X[r][k] = W^H[r][k]
-        const double2 t = T[(int64_t)gk * n + T0 + r];  // Y[j][k] = conj(A[row(k)][j])
-        yv = make_double2(t.x, -t.y);
-      }
-      xs[r * LP + 2 * (c0 + c)] = xv.x;
-      xs[r * LP + 2 * (c0 + c) + 1] = xv.y;
-      ys[r * LP + 2 * (c0 + c)] = yv.x;
-      ys[r * LP + 2 * (c0 + c) + 1] = yv.y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 2 * KC; kk += 4) {
-      double a[2], b[2], b2[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = xs[(32 * wr + 16 * t + lr) * LP + kk + lk];
-        b[t] = ys[(32 * wc + 16 * t + lr) * LP + kk + lk];
-        const double o = ys[(32 * wc + 16 * t + lr) * LP + kk + (lk ^ 1)];
-        b2[t] = (lk & 1) ? o : -o;
-      }
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-          cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], cre[ti][tj], 0, 0, 0);
-          cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b2[tj], cim[ti][tj], 0, 0, 0);
-        }
-    }
-  }
-  __syncthreads();  // every input of this tile has been consumed: in-place store is safe
-#pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = 32 * wr + 16 * ti + lk + 4 * reg;  // X-side index
-        const int j = 32 * wc + 16 * tj + lr;            // Y-side index
-        const double2 val = make_double2(cre[ti][tj][reg], cim[ti][tj][reg]);
-        if (bp.target != 2) {
-          const int gj = j < JB ? P0 + j : Q0 + j - JB;
-          T[(int64_t)(T0 + i) * n + gj] = val;
-        } else {
-          const int gi = i < JB ? P0 + i : Q0 + i - JB;
-          T[(int64_t)gi * n + T0 + j] = val;
-        }
-      }
 }
 
 // w = D U_r L_r^-1 U_r^H D v with the reference's cut on sigma = sqrt(lambda)
@@ -907,104 +189,6 @@ __global__ void k_prior(double* Sl, int lmax, double amp, double tilt) {
   for (int l = blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
     const double dl = l == 0 ? 1.0 : (double)l;  // mapmaker.py:261: l[0] = 1
     Sl[l] = amp * amp * pow(dl, -tilt);
-  }
-}
-
-// ---------------------------------------------------------------- m-mode SVD filter (svdfilter.py)
-// Per m the matrix W [freq, (msign, base)] is decomposed through the eigen-decomposition of its
-// frequency-side Gram matrix G = W W^H (order nfreq): sigma = sqrt(lambda), left vectors U.  Everything the
-// reference does with the factors needs only U and W: the low-rank refill of missing entries is
-// (U_r U_r^H W)[mask], the filtered data W - U_c U_c^H W.
-struct SvdParams {
-  double2* vis;            // [n_m][2][nfreq][nbase] (read; written by k_svd_remove)
-  const double* weight;    // same shape; 0 marks a missing entry
-  int nfreq, nbase, Fp, ldw;   // Fp = 64*ceil(nfreq/64), ldw = 2*nbase
-  int m0, nmat;            // this batch: m0 .. m0+nmat
-  double2* W;              // [nmat][Fp][ldw]
-  const double2* fill0;    // [n_m] first guess of the missing entries, or nullptr (nothing is missing)
-  const double2* U;        // [nmat][Fp][Fp] eigenvectors in columns
-  const int* idx;          // [nmat][kmax] columns of U to use (largest eigenvalues first)
-  const int* cnt;          // [nmat] how many of them
-  int kmax;
-  double2* P;              // [nmat][kmax][ldw]  U_k^H W
-};
-
-__device__ __forceinline__ int64_t svd_src(const SvdParams& sp, int m, int f, int j) {
-  const int s = j >= sp.nbase, b = j - s * sp.nbase;
-  return (((int64_t)m * 2 + s) * sp.nfreq + f) * sp.nbase + b;
-}
-
-// W[mat][f][j] = vis (or the first guess where the weight is zero); grid (ceil(ldw/256), nfreq, nmat)
-__global__ __launch_bounds__(kThreads) void k_svd_gather(SvdParams sp) {
-  const int j = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y, mat = blockIdx.z;
-  if (j >= sp.ldw) return;
-  const int m = sp.m0 + mat;
-  const int64_t o = svd_src(sp, m, f, j);
-  double2 v = sp.vis[o];
-  if (sp.fill0 && sp.weight[o] == 0.0) v = sp.fill0[m];
-  sp.W[((int64_t)mat * sp.Fp + f) * sp.ldw + j] = v;
-}
-
-// P[mat][k][j] = sum_f conj(U[f][idx_k]) W[f][j]; grid (ceil(ldw/256), kmax, nmat)
-__global__ __launch_bounds__(kThreads) void k_svd_project(SvdParams sp) {
-  const int j = blockIdx.x * kThreads + threadIdx.x, k = blockIdx.y, mat = blockIdx.z;
-  if (k >= sp.cnt[mat] || j >= sp.ldw) return;
-  const int col = sp.idx[(int64_t)mat * sp.kmax + k];
-  const double2* U = sp.U + (int64_t)mat * sp.Fp * sp.Fp;
-  const double2* W = sp.W + (int64_t)mat * sp.Fp * sp.ldw;
-  double re = 0.0, im = 0.0;
-  for (int f = 0; f < sp.nfreq; ++f) {
-    const double2 u = U[(int64_t)f * sp.Fp + col], w = W[(int64_t)f * sp.ldw + j];
-    re += u.x * w.x + u.y * w.y;
-    im += u.x * w.y - u.y * w.x;
-  }
-  sp.P[((int64_t)mat * sp.kmax + k) * sp.ldw + j] = make_double2(re, im);
-}
-
-// missing entries <- (U_r P)[f][j]  (svdfilter.py:184-185); grid as k_svd_gather
-__global__ __launch_bounds__(kThreads) void k_svd_fill(SvdParams sp) {
-  const int j = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y, mat = blockIdx.z;
-  if (j >= sp.ldw) return;
-  if (sp.weight[svd_src(sp, sp.m0 + mat, f, j)] != 0.0) return;
-  const double2* U = sp.U + (int64_t)mat * sp.Fp * sp.Fp;
-  double re = 0.0, im = 0.0;
-  for (int k = 0; k < sp.cnt[mat]; ++k) {
-    const double2 u = U[(int64_t)f * sp.Fp + sp.idx[(int64_t)mat * sp.kmax + k]];
-    const double2 p = sp.P[((int64_t)mat * sp.kmax + k) * sp.ldw + j];
-    re += u.x * p.x - u.y * p.y;
-    im += u.x * p.y + u.y * p.x;
-  }
-  sp.W[((int64_t)mat * sp.Fp + f) * sp.ldw + j] = make_double2(re, im);
-}
-
-// vis <- W - U_c P  (svdfilter.py:139-145: the `cut` largest modes removed); grid as k_svd_gather
-__global__ __launch_bounds__(kThreads) void k_svd_remove(SvdParams sp) {
-  const int j = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y, mat = blockIdx.z;
-  if (j >= sp.ldw) return;
-  const double2* U = sp.U + (int64_t)mat * sp.Fp * sp.Fp;
-  double2 v = sp.W[((int64_t)mat * sp.Fp + f) * sp.ldw + j];
-  for (int k = 0; k < sp.cnt[mat]; ++k) {
-    const double2 u = U[(int64_t)f * sp.Fp + sp.idx[(int64_t)mat * sp.kmax + k]];
-    const double2 p = sp.P[((int64_t)mat * sp.kmax + k) * sp.ldw + j];
-    v.x -= u.x * p.x - u.y * p.y;
-    v.y -= u.x * p.y + u.y * p.x;
-  }
-  sp.vis[svd_src(sp, sp.m0 + mat, f, j)] = v;
-}
-
-// u_out[mat][f][k] = U[f][idx_k]; grid (ceil(nmode/256), nfreq, nmat)
-__global__ __launch_bounds__(kThreads) void k_svd_u_out(SvdParams sp, double2* u_out, int nmode) {
-  const int k = blockIdx.x * kThreads + threadIdx.x, f = blockIdx.y, mat = blockIdx.z;
-  if (k >= nmode) return;
-  const double2* U = sp.U + (int64_t)mat * sp.Fp * sp.Fp;
-  u_out[((int64_t)mat * sp.nfreq + f) * nmode + k] = U[(int64_t)f * sp.Fp + sp.idx[(int64_t)mat * sp.kmax + k]];
-}
-
-__global__ void k_diag_out(const double2* A, int Np, int nmat, double* out) {  // out[mat][i] = Re A[mat][i][i]
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (int64_t)nmat * Np) {
-    const int mat = (int)(i / Np), r = (int)(i % Np);
-    out[i] = A[((int64_t)mat * Np + r) * Np + r].x;
   }
 }
 
@@ -1335,187 +519,6 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         if (rc) return rc;
       }
     if (!shortcut) break;  // everything went through the eigen path already
-  }
-  return DMM_OK;
-}
-
-// SVD with missing entries of every m of an MModes array, through the frequency-side Gram matrix.
-//   mode 0: spectrum[m][0..nmode) = singular values, largest first        (SVDSpectrumEstimator, svdfilter.py:22-57)
-//   mode 1: additionally vis <- data with its `cut` largest modes removed  (SVDFilter, svdfilter.py:122-147),
-//           cut = max(#(sigma > global_thr * global_max), #(sigma > local_thr * sigma_0))
-int dmm_mmode_svd(dmm_ctx* ctx, void* mvis, const double* mweight, int n_m, int nfreq, int nbase, int niter, int rank,
-                  const void* fill0, int mode, double global_max, double global_thr, double local_thr, double* spectrum,
-                  void* u_out, void* uha_out) {
-  DMM_REQUIRE(ctx && mvis && mweight && spectrum, "dmm_mmode_svd: NULL argument");
-  DMM_REQUIRE(n_m >= 0 && nfreq >= 1 && nbase >= 1 && niter >= 1 && rank >= 1, "dmm_mmode_svd: bad sizes");
-  DMM_REQUIRE(mode == 0 || mode == 1, "dmm_mmode_svd: mode must be 0 or 1");
-  DMM_REQUIRE((u_out == nullptr) == (uha_out == nullptr) && !(u_out && mode == 1), "dmm_mmode_svd: u_out and uha_out come together, mode 0 only");
-  if (n_m == 0) return DMM_OK;
-  DMM_HIP(hipSetDevice(ctx->device));
-  const int Fp = (nfreq + TB - 1) / TB * TB, T = Fp / TB, ldw = 2 * nbase;
-  const int nmode = std::min(ldw, nfreq);
-  const int kmax = (mode == 1 || u_out) ? nmode : std::min(rank, nmode);
-  const int npr = Fp / 64;
-  // per-matrix scratch: W, G, V, pair rotations, P, small arrays
-  const size_t b_w = (size_t)Fp * ldw * sizeof(double2), b_g = (size_t)Fp * Fp * sizeof(double2);
-  const size_t b_wh = (size_t)npr * TB * TB * sizeof(double2), b_p = (size_t)kmax * ldw * sizeof(double2);
-  const size_t b_small = (size_t)npr * sizeof(int) + (size_t)kmax * sizeof(int) + sizeof(int) + 2 * sizeof(double) + (size_t)Fp * sizeof(double) + sizeof(dmm_tile) + 64;
-  const size_t per = b_w + 2 * b_g + b_wh + b_p + b_small;
-  size_t cap = ((size_t)4 << 30) / per;
-  if (cap < 1) cap = 1;
-  if (cap > (size_t)n_m) cap = n_m;
-  void* scratch = nullptr;
-  int rc = dmm_get_scratch(ctx, cap * per + 4096, &scratch);
-  if (rc) return rc;
-  unsigned char* q = (unsigned char*)scratch;
-  auto take = [&](size_t bytes) {
-    unsigned char* r = q;
-    q += (bytes + 255) & ~(size_t)255;
-    return r;
-  };
-  double2* W = (double2*)take(cap * b_w);
-  double2* G = (double2*)take(cap * b_g);
-  double2* V = (double2*)take(cap * b_g);
-  double2* Wh = (double2*)take(cap * b_wh);
-  double2* P = (double2*)take(cap * b_p);
-  int* flag_d = (int*)take(cap * npr * sizeof(int));
-  int* idx_d = (int*)take(cap * kmax * sizeof(int));
-  int* cnt_d = (int*)take(cap * sizeof(int));
-  double* scale_d = (double*)take(cap * sizeof(double));
-  double* lam_d = (double*)take(cap * Fp * sizeof(double));
-  dmm_tile* tiles_d = (dmm_tile*)take(cap * sizeof(dmm_tile));
-  int* any_rot_d = (int*)take(sizeof(int));
-  DMM_HIP(hipMemsetAsync(tiles_d, 0, cap * sizeof(dmm_tile), ctx->stream));
-
-  const size_t sub_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_bj_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
-  const int max_sweeps = ctx->opt_ml_outer_sweeps > 0 ? ctx->opt_ml_outer_sweeps : 60;
-  std::vector<double> lam_h, spec_h;
-  std::vector<int> idx_h, cnt_h, order;
-  const int n_em = fill0 ? niter : 1;  // nothing missing: every EM pass would repeat the same decomposition
-
-  for (int m0 = 0; m0 < n_m; m0 += (int)cap) {
-    const int nmat = std::min<int>((int)cap, n_m - m0);
-    SvdParams sp;
-    sp.vis = (double2*)mvis;
-    sp.weight = mweight;
-    sp.nfreq = nfreq;
-    sp.nbase = nbase;
-    sp.Fp = Fp;
-    sp.ldw = ldw;
-    sp.m0 = m0;
-    sp.nmat = nmat;
-    sp.W = W;
-    sp.fill0 = (const double2*)fill0;
-    sp.U = V;
-    sp.idx = idx_d;
-    sp.cnt = cnt_d;
-    sp.kmax = kmax;
-    sp.P = P;
-    const dim3 egrid((ldw + kThreads - 1) / kThreads, nfreq, nmat);
-    hipLaunchKernelGGL(k_svd_gather, egrid, dim3(kThreads), 0, ctx->stream, sp);
-
-    DenseParams p;
-    memset(&p, 0, sizeof(p));
-    p.tiles = tiles_d;
-    p.nmat = nmat;
-    p.N = nfreq;
-    p.Np = Fp;
-    p.T = T;
-    p.npairs = nbase;  // the contraction length of MODE_GRAMX is 2*npairs = ldw
-    p.A = G;
-    p.X = W;
-    p.ldx = ldw;
-    BjParams bp;
-    bp.d = p;
-    bp.V = V;
-    bp.Wh = Wh;
-    bp.flag = flag_d;
-    bp.scale = scale_d;
-    bp.any_rot = any_rot_d;
-    bp.inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;
-    bp.nb = Fp / JB;
-    bp.round = 0;
-    bp.target = 0;
-
-    for (int it = 0; it < n_em; ++it) {
-      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
-      hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
-      hipLaunchKernelGGL(k_bj_init, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, bp);
-      for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-        DMM_HIP(hipMemsetAsync(any_rot_d, 0, sizeof(int), ctx->stream));
-        for (int round = 0; round < bp.nb - 1; ++round) {
-          bp.round = round;
-          hipLaunchKernelGGL(k_bj_sub, dim3(npr, nmat), dim3(kThreads), sub_lds, ctx->stream, bp);
-          bp.target = 0;
-          hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
-          bp.target = 2;
-          hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
-          bp.target = 1;
-          hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
-        }
-        int any = 1;
-        DMM_HIP(hipMemcpyAsync(&any, any_rot_d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        DMM_HIP(hipStreamSynchronize(ctx->stream));
-        if (!any) break;
-        if (sweep == max_sweeps - 1)
-          return dmm_set_error(DMM_E_STATE, "dmm_mmode_svd: Jacobi did not converge in %d sweeps", max_sweeps);
-      }
-      DMM_HIP(hipGetLastError());
-      // eigenvalues to the host: order them (largest first) and pick the columns each matrix uses next
-      hipLaunchKernelGGL(k_diag_out, dim3((unsigned)(((size_t)nmat * Fp + 255) / 256)), dim3(256), 0, ctx->stream, G, Fp, nmat, lam_d);
-      lam_h.resize((size_t)nmat * Fp);
-      DMM_HIP(hipMemcpyAsync(lam_h.data(), lam_d, lam_h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      DMM_HIP(hipStreamSynchronize(ctx->stream));
-      const bool last = it == n_em - 1;
-      idx_h.assign((size_t)nmat * kmax, 0);
-      cnt_h.assign(nmat, 0);
-      if (last) spec_h.assign((size_t)nmat * nmode, 0.0);
-      order.resize(nfreq);
-      for (int mat = 0; mat < nmat; ++mat) {
-        const double* lam = lam_h.data() + (size_t)mat * Fp;
-        for (int i = 0; i < nfreq; ++i) order[i] = i;  // padded coordinates (i >= nfreq) are exact zero modes
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lam[a] > lam[b]; });
-        int take_n;
-        if (!last) {
-          take_n = std::min(rank, nmode);  // svdfilter.py:183
-        } else {
-          double* sg = spec_h.data() + (size_t)mat * nmode;
-          for (int k = 0; k < nmode; ++k) sg[k] = sqrt(std::max(lam[order[k]], 0.0));
-          take_n = 0;
-          if (mode == 1) {  // svdfilter.py:135-139
-            int gcut = 0, lcut = 0;
-            for (int k = 0; k < nmode; ++k) {
-              gcut += sg[k] > global_thr * global_max;
-              lcut += sg[k] > local_thr * sg[0];
-            }
-            take_n = std::max(gcut, lcut);
-          } else if (u_out) {
-            take_n = nmode;  // all left vectors, largest singular value first
-          }
-        }
-        cnt_h[mat] = take_n;
-        for (int k = 0; k < take_n; ++k) idx_h[(size_t)mat * kmax + k] = order[k];
-      }
-      if (last) DMM_HIP(hipMemcpyAsync(spectrum + (size_t)m0 * nmode, spec_h.data(), spec_h.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-      if (!last || mode == 1 || u_out) {
-        DMM_HIP(hipMemcpyAsync(idx_d, idx_h.data(), idx_h.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        DMM_HIP(hipMemcpyAsync(cnt_d, cnt_h.data(), cnt_h.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_svd_project, dim3((ldw + kThreads - 1) / kThreads, kmax, nmat), dim3(kThreads), 0, ctx->stream, sp);
-        if (!last) {
-          hipLaunchKernelGGL(k_svd_fill, egrid, dim3(kThreads), 0, ctx->stream, sp);
-        } else if (mode == 1) {
-          hipLaunchKernelGGL(k_svd_remove, egrid, dim3(kThreads), 0, ctx->stream, sp);
-        } else {  // factors out: U (sorted columns) and U^H A = diag(sigma) V^H
-          hipLaunchKernelGGL(k_svd_u_out, dim3((nmode + kThreads - 1) / kThreads, nfreq, nmat), dim3(kThreads), 0, ctx->stream, sp,
-                             (double2*)u_out + (size_t)m0 * nfreq * nmode, nmode);
-          DMM_HIP(hipMemcpyAsync((double2*)uha_out + (size_t)m0 * nmode * ldw, P, (size_t)nmat * nmode * ldw * sizeof(double2),
-                                 hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        DMM_HIP(hipGetLastError());
-      }
-      DMM_HIP(hipStreamSynchronize(ctx->stream));  // host staging vectors are reused
-    }
   }
   return DMM_OK;
 }
