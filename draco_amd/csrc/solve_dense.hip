@@ -192,6 +192,17 @@ __global__ void k_prior(double* Sl, int lmax, double amp, double tilt) {
   }
 }
 
+// Wiener, sky side: C^-1 = diag(1 / S_l) + B^H Ni B (mapmaker.py:267-270); padded rows get a unit diagonal
+__global__ void k_add_prior_diag(DenseParams p, const double* Sl) {
+  const int mat = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.Np) return;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  const int L = p.lmax + 1 - tile.m, N = p.npol * L;
+  double2* d = p.A + ((int64_t)mat * p.Np + i) * p.Np + i;
+  if (i < N) d->x += 1.0 / Sl[tile.m + i % L];
+  else *d = make_double2(1.0, 0.0);
+}
+
 // ---------------------------------------------------------------- host
 struct Layout {
   int N, Np, T;
@@ -272,7 +283,8 @@ int dmm_dirty_w_launch_list(dmm_plan* pl, const void* B, const double2* wbuf, co
 
 extern "C" {
 
-int64_t dmm_wiener_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, false); }
+// (the Wiener solve stages the sky-side operand like ML does: same workspace layout)
+int64_t dmm_wiener_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, true); }
 int64_t dmm_ml_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, true); }
 
 int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, double prior_amp,
@@ -282,35 +294,100 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   if (pl->ntile == 0) return DMM_OK;
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
-  const Layout L = layout_of(pl, false);
+  const Layout L = layout_of(pl, true);
   const int64_t wsb = dmm_wiener_workspace_bytes(pl);
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
   double* Sl = (double*)ws;
   hipLaunchKernelGGL(k_prior, dim3(4), dim3(256), 0, ctx->stream, Sl, pl->lmax, prior_amp, prior_tilt);
-  DenseParams p = make_params(pl, L, B, mvis, mweight, ws, cap);
-  p.Sl = Sl;
-  p.add_identity = 1;
+  const DenseParams base = make_params(pl, L, B, mvis, mweight, ws, cap);
+  double2* const Xbuf = base.Linv;  // [cap] rows of (D B)^H for the sky-side Gram matrices
+  unsigned char* extra = (unsigned char*)(base.wbuf + (size_t)cap * L.N);
+  extra = (unsigned char*)(((uintptr_t)extra + 255) & ~(uintptr_t)255);
+  double2* const Linvbuf = (double2*)extra;  // inverted diagonal blocks of the factorisations
+  unsigned char* q = (unsigned char*)(Linvbuf + (size_t)cap * (L.Np / 64) * TB * TB);
+  dmm_tile* const tiles_d = (dmm_tile*)q;
+  q += (size_t)cap * sizeof(dmm_tile);
+  int32_t* const work_d = (int32_t*)q;
+
+  // Both of the reference's branches (mapmaker.py:267-278) are the same estimator; the smaller system is
+  // solved: telescope side G = I + D B S B^H D while nsky_m >= ntel, sky side C^-1 = S^-1 + B^H Ni B at high m
+  const int ntel = 2 * pl->npairs;
+  std::vector<int64_t> tel_list;
+  std::map<int, std::vector<int64_t>> sky_lists;  // by padded order
+  for (int64_t t = 0; t < pl->ntile; ++t) {
+    const int nsky = pl->npol * (pl->lmax + 1 - pl->tiles_h[t].m);
+    if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);
+    else sky_lists[(nsky + TB - 1) / TB * TB].push_back(t);
+  }
+  if (!sky_lists.empty()) {  // B^H Ni v of every tile: the right-hand side of the sky-side systems
+    int rc = dmm_dirty_run(pl, B, mvis, mweight, alm);
+    if (rc) return rc;
+  }
   const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
   const size_t diag_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-  for (int64_t t0 = 0; t0 < pl->ntile; t0 += cap) {
-    const int nmat = (int)std::min<int64_t>(cap, pl->ntile - t0);
-    p.tile0 = t0;
+
+  std::vector<dmm_tile> tiles_c;
+  std::vector<int32_t> work_c;
+  auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky) -> int {
+    DenseParams p = base;
+    p.tiles = tiles_d;
+    p.tile0 = 0;
     p.nmat = nmat;
-    hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(L.T * (L.T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
-    for (int J = 0; J < L.T; ++J) {
-      p.J = J;
-      if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(L.T - J, nmat), dim3(kThreads), 0, ctx->stream, p);
-      hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, ctx->stream, p);
-      if (J < L.T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(L.T - J - 1, nmat), dim3(kThreads), 0, ctx->stream, p);
+    p.sky = sky ? 1 : 0;
+    p.N = sky ? np_sky : ntel;
+    p.Np = (p.N + TB - 1) / TB * TB;
+    p.T = p.Np / TB;
+    p.alm = (double2*)alm;
+    p.Linv = Linvbuf;
+    tiles_c.resize(nmat);
+    work_c.assign(nmat + 1, 0);
+    for (int i = 0; i < nmat; ++i) {
+      tiles_c[i] = pl->tiles_h[list[i0 + i]];
+      const int ncol = pl->npol * (pl->lmax + 1 - tiles_c[i].m);
+      work_c[i + 1] = work_c[i] + (ncol + pl->cols_per_block - 1) / pl->cols_per_block;
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, p);
+    DMM_HIP(hipMemcpyAsync(tiles_d, tiles_c.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, ctx->stream));
+    DMM_HIP(hipMemcpyAsync(work_d, work_c.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    DMM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors are reused by the next batch
+    const int T = p.T;
+    if (sky) {
+      p.ldx = ntel;
+      p.X = Xbuf;
+      hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Xbuf);
+      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+      hipLaunchKernelGGL(k_add_prior_diag, dim3((p.Np + 255) / 256, nmat), dim3(256), 0, ctx->stream, p, (const double*)Sl);
+    } else {
+      p.Sl = Sl;
+      p.add_identity = 1;
+      hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+    }
+    for (int J = 0; J < T; ++J) {
+      p.J = J;
+      if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(T - J, nmat), dim3(kThreads), 0, ctx->stream, p);
+      hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, ctx->stream, p);
+      if (J < T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(T - J - 1, nmat), dim3(kThreads), 0, ctx->stream, p);
+    }
+    hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, p);  // sky: a_lm in place
     DMM_HIP(hipGetLastError());
-    int rc = dmm_dirty_w_launch(pl, B, p.wbuf, Sl, t0, nmat, alm);
+    if (!sky) {
+      int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, Sl, tiles_d, work_d, nmat, work_c[nmat], alm);
+      if (rc) return rc;
+    }
+    DMM_HIP(hipStreamSynchronize(ctx->stream));  // tiles_d / work_d are rewritten by the next batch
+    return DMM_OK;
+  };
+  for (size_t i0 = 0; i0 < tel_list.size(); i0 += cap) {
+    int rc = run_batch(tel_list, i0, (int)std::min<size_t>(cap, tel_list.size() - i0), false, 0);
     if (rc) return rc;
   }
+  for (auto& kv : sky_lists)
+    for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
+      int rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first);
+      if (rc) return rc;
+    }
   return DMM_OK;
 }
 

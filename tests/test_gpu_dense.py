@@ -160,6 +160,42 @@ def test_ml_certified_shortcut_vs_eigen_path():
     assert _rel(out[0], out[2]) < 1e-9
 
 
+def test_wiener_sky_side_vs_telescope_side():
+    """Wiener: at high m (nsky_m < ntel) the sky-side system S^-1 + B^H Ni B is solved instead of the telescope-side
+    one; both are the reference's own branches (mapmaker.py:267-278) and must agree with each other and the oracle."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import WienerMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    nfreq, lmax = 2, 60
+    tel = _tel(nfreq, lmax, 2, 4)  # ntel = 86: sky side for m >= 40
+    bt = SyntheticProvider(tel, seed=606)
+    rng = np.random.default_rng(6)
+    mv = rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs)) + 1j * rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs))
+    mw = rng.uniform(0.5, 1.5, mv.shape) * 30.0
+    mw[rng.uniform(size=mw.shape) < 0.1] = 0.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    out = {}
+    try:
+        for mode in (0, 3):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", mode))
+            task = WienerMapMaker(prior_amp=2.0, prior_tilt=0.75)
+            task.setup(bt)
+            out[mode] = task.alm_square(task.make_alm(mm))
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+    beam = lambda m, f: osyn.beam_tile(606, m, f, tel.npairs, 4, lmax)  # noqa: E731
+    ref = omm.solve_alm("wiener", beam, mv, mw, lmax, tel.mmax, list(range(nfreq)), prior_amp=2.0, prior_tilt=0.75)
+    assert _rel(out[0], ref) < 1e-10
+    assert _rel(out[3], ref) < 1e-10
+    assert _rel(out[0], out[3]) < 1e-11
+
+
 def test_wiener_cfg2_sized_tile_properties():
     """cfg-2 sized tile (374 x 1028): Wiener solution satisfies its normal equations (size-independent check)."""
     import torch

@@ -21,6 +21,7 @@ def main():
     cfgn = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     kind = sys.argv[3] if len(sys.argv) > 3 else "wiener"
+    side = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 3: telescope-side systems only
     cfg = osyn.CONFIGS[cfgn]
     ctx = Context.get()
     tel = TransitTelescope(osyn.frequencies(nf), lmax=cfg["lmax"], ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
@@ -29,6 +30,7 @@ def main():
     vis = torch.randn((nf, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
     w = torch.rand((nf, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
     mv, mw = mmode_forward(ctx, vis, w, cfg["lmax"])
+    _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", side))
     for _ in range(2):
         ctx.sync()
         t0 = time.perf_counter()
