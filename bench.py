@@ -192,6 +192,20 @@ class Job:
         self._lib = _lib
         ctx.sync()
 
+    def dirty_alone_ms(self, reps=2):
+        """Mean HIP-event time of one pool cycle's Dirty launch with nothing else on the GPU."""
+        from draco_amd.analysis.transform import mmode_forward
+        from draco_amd.device import ptr
+
+        ctx = self.ctx
+        mv, mw = mmode_forward(ctx, self.vis, self.weight, self.lmax)
+        ctx.sync()
+        self.torch.cuda.synchronize()
+        ctx.timer_start()
+        for _ in range(reps):
+            self._lib.check(self._lib.lib.dmm_dirty_run(self.slab.plan, ptr(self.slab.pool), mv.data_ptr(), mw.data_ptr(), self.alm.data_ptr()))
+        return ctx.timer_stop() / reps
+
     def step(self, time_dirty=False):
         """One pass; returns the HIP-event time of the Dirty launches if asked."""
         from draco_amd.analysis.transform import mmode_forward
@@ -260,6 +274,9 @@ def main():
 
     for _ in range(args.warmup):
         job.step()
+    # reference point for the roofline object, outside the timed region: the Dirty kernel with the GPU to itself
+    # (inside the step the side stream's alm2map shares CUs and HBM with it)
+    alone_ms = job.dirty_alone_ms()
     barrier()
     t0 = time.perf_counter()
     dirty_ms = 0.0
@@ -317,6 +334,12 @@ def main():
             "bytes_per_launch": job.dirty_bytes,
             "avg_launch_ms": dirty_avg_ms,
             "launches": nlaunch,
+            "alone": {
+                "avg_launch_ms": alone_ms,
+                "achieved": job.dirty_bytes / (alone_ms * 1e-3) / 1e9,
+                "frac": job.dirty_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "same kernel, same launch, no concurrent alm2map (untimed reference launches after warmup)",
+            },
         },
     }
 
