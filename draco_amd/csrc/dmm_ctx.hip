@@ -29,6 +29,15 @@ int dmm_get_scratch(dmm_ctx* ctx, size_t bytes, void** out) {
   return DMM_OK;
 }
 
+hipError_t dmm_ticket(dmm_ctx* ctx, unsigned long long** out) {
+  if (!ctx->ticket) {
+    hipError_t e = hipMalloc((void**)&ctx->ticket, sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+  }
+  *out = ctx->ticket;
+  return hipSuccess;
+}
+
 extern "C" {
 
 int dmm_version(void) { return DMM_VERSION; }
@@ -70,6 +79,7 @@ int dmm_ctx_destroy(dmm_ctx* c) {
   for (auto& kv : c->sht)
     if (kv.second) (void)hipFree(kv.second);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->ticket) (void)hipFree(c->ticket);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
@@ -86,6 +96,7 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   DMM_REQUIRE(c != nullptr && name != nullptr, "dmm_ctx_set_option: NULL argument");
   if (!strcmp(name, "dirty_variant")) c->opt_dirty_variant = (int)value;
   else if (!strcmp(name, "grid_mult")) c->opt_grid_mult = (int)value;
+  else if (!strcmp(name, "dirty_static")) c->opt_dirty_static = (int)value;
   else if (!strcmp(name, "project_grid_mult")) c->opt_project_grid_mult = (int)value;
   else if (!strcmp(name, "project_variant")) c->opt_project_variant = (int)value;
   else if (!strcmp(name, "ml_inner_sweeps")) c->opt_ml_inner_sweeps = (int)value;

@@ -38,6 +38,9 @@ struct SolveParams {
   const double* Sl;
   int64_t tile0;
   int64_t work_base;
+  // dynamic task hand-out: a device counter (zeroed before the launch) from which blocks draw their next task, so a
+  // CU slowed down by a neighbour on another stream simply takes fewer tasks; nullptr = static striding
+  unsigned long long* ticket;
 };
 
 __device__ __forceinline__ int64_t find_tile(const int32_t* __restrict__ ws, int64_t ntile, int64_t w) {
@@ -95,7 +98,15 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntel = p.ntel, npairs = p.npairs;
 
-  for (int64_t work0 = blockIdx.x; work0 < p.nwork; work0 += gridDim.x) {
+  __shared__ unsigned long long s_next;
+  for (int64_t work0 = blockIdx.x;; work0 += gridDim.x) {
+    if (p.ticket) {
+      // (the previous task's reads of s_next all happened before its second barrier: thread 0 may overwrite it)
+      if (threadIdx.x == 0) s_next = atomicAdd(p.ticket, 1ull);
+      __syncthreads();
+      work0 = (int64_t)s_next;
+    }
+    if (work0 >= p.nwork) break;
     const int64_t work = work0 + (WMODE ? p.work_base : 0);
     const int64_t t = find_tile(p.work_start, p.ntile, work);
     const dmm_tile tile = p.tiles[t];
@@ -269,20 +280,27 @@ SolveParams base_params(const dmm_plan* pl) {
   p.Sl = nullptr;
   p.tile0 = 0;
   p.work_base = 0;
+  p.ticket = nullptr;
   return p;
 }
 
 template <bool WMODE>
-int launch_dirty(dmm_plan* pl, const SolveParams& p, const void* B, const double2* v, const double* mweight, double2* a) {
+int launch_dirty(dmm_plan* pl, const SolveParams& p_in, const void* B, const double2* v, const double* mweight, double2* a) {
   dmm_ctx* ctx = pl->ctx;
-  const size_t lds = (size_t)p.ntel * sizeof(double2);
+  const size_t lds = (size_t)p_in.ntel * sizeof(double2);
   // defaults from tools/tune_dirty.py on MI355X (profiles/r01_tune_dirty.txt): non-temporal loads, 8 row
   // loads in flight per wave and ONE 4-wave block per CU (one wave per SIMD, 32 KB in flight per CU) --
   // more resident waves only add contention at the memory side (6.7 vs 6.0 TB/s at 8 blocks per CU)
   const int gm_default = 1;
   int64_t grid = (int64_t)ctx->num_cu * (ctx->opt_grid_mult > 0 ? ctx->opt_grid_mult : gm_default);
-  if (grid > p.nwork) grid = p.nwork;
+  if (grid > p_in.nwork) grid = p_in.nwork;
   if (grid <= 0) return DMM_OK;
+  SolveParams pd = p_in;
+  if (ctx->opt_dirty_static == 0) {
+    DMM_HIP(dmm_ticket(ctx, &pd.ticket));
+    DMM_HIP(hipMemsetAsync(pd.ticket, 0, sizeof(unsigned long long), ctx->stream));
+  }
+  const SolveParams& p = pd;
 #define DMM_LAUNCH_DIRTY(KERN, BTYPE)                                                                            \
   do {                                                                                                           \
     auto k = KERN;                                                                                               \
