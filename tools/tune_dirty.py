@@ -30,22 +30,23 @@ def main():
     def run():
         _lib.check(lib.dmm_dirty_run(job.slab.plan, ptr(job.slab.pool), mv.data_ptr(), mw.data_ptr(), job.alm.data_ptr()))
 
-    variants = [(v, g) for v in (0, 2, 3, 4) for g in (1, 2, 3)]
+    variants = [(v, g, st) for v in (0, 2, 3, 4) for g in (1, 2, 3) for st in (0, 1)]  # st = 1: static striding
     times = {k: [] for k in variants}
     for rnd in range(6):
-        for v, g in variants:
+        for v, g, st in variants:
             _lib.check(lib.dmm_ctx_set_option(ctx.handle, b"dirty_variant", v))
             _lib.check(lib.dmm_ctx_set_option(ctx.handle, b"grid_mult", g))
+            _lib.check(lib.dmm_ctx_set_option(ctx.handle, b"dirty_static", st))
             if rnd == 0:
                 run()
                 ctx.sync()
             ctx.timer_start()
             run()
-            times[(v, g)].append(ctx.timer_stop())
+            times[(v, g, st)].append(ctx.timer_stop())
     res = []
-    for (v, g), ts in times.items():
+    for (v, g, st), ts in times.items():
         ts = np.array(ts[1:])
-        res.append({"variant": v, "grid_mult": g, "median_ms": float(np.median(ts)), "min_ms": float(ts.min()),
+        res.append({"variant": v, "grid_mult": g, "static": st, "median_ms": float(np.median(ts)), "min_ms": float(ts.min()),
                     "TBs_median": job.dirty_bytes / np.median(ts) / 1e9})
     res.sort(key=lambda r: r["median_ms"])
     for r in res:
