@@ -230,6 +230,38 @@ class MModeInverseTransform(ContainerTask):
         return sstream
 
 
+class SiderealMModeResample(ContainerTask):
+    """Resample a sidereal stream by FFT: a forward then an inverse m-mode transform
+    (``transform.py:795-811``, the reference's ``group_tasks(MModeTransform, MModeInverseTransform)``).
+
+    Attributes
+    ----------
+    nra : int
+        The number of RA bins for the output stream.
+    remove_integration_window, apply_integration_window : bool
+        Remove the integration window from the incoming data, and/or apply it to the output stream.
+    use_fftw : bool
+        Accepted and ignored, as in :class:`MModeTransform`.
+    """
+
+    nra = None
+    remove_integration_window = False
+    apply_integration_window = False
+    use_fftw = True
+    _config_names = ("nra", "remove_integration_window", "apply_integration_window", "use_fftw")
+
+    _manager = None
+
+    def setup(self, manager=None):
+        self._manager = manager
+
+    def process(self, sstream):
+        fwd = MModeTransform(remove_integration_window=self.remove_integration_window, use_fftw=self.use_fftw)
+        fwd.setup(self._manager)
+        inv = MModeInverseTransform(nra=self.nra, apply_integration_window=self.apply_integration_window)
+        return inv.process(fwd.process(sstream))  # the m-modes never leave the device
+
+
 def _cmap(i, j, n):
     if i > j:
         i, j = j, i
