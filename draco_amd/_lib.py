@@ -63,6 +63,7 @@ _SIGS = {
     "dmm_mifft_unpack": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "dmm_mrow_is_zero": (_i, [_vp, _vp, _i, _i64, _i, _i, C.POINTER(_i)]),
     "dmm_mask_mmode_weight": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _i, _i, _i]),
+    "dmm_expand_products": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dmm_collate_products": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dmm_solve_plan_create": (_i, [_vp, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "dmm_plan_destroy": (_i, [_vp]),

@@ -572,6 +572,28 @@ __global__ void k_collate(const float2* __restrict__ ssv, const float* __restric
     out_w[i] = (float)(var != 0.0 ? cnt * cnt / var : 0.0);
   }
 }
+
+// ExpandProducts (reference synthesis/stream.py:228-244): out[f, p, t] = (conj?) in[f, src[p], t], weight 1; products
+// of a masked pair (src < 0) stay zero with zero weight.  One thread per output sample, t fastest.
+__global__ void k_expand(const float2* __restrict__ in, int nstack, int nt, int nprod, const int* __restrict__ src,
+                         const unsigned char* __restrict__ cj, float2* __restrict__ out, float* __restrict__ out_w,
+                         int64_t total) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int t = (int)(i % nt);
+    const int64_t fp = i / nt;
+    const int p = (int)(fp % nprod);
+    const int64_t f = fp / nprod;
+    const int sp = src[p];
+    float2 v = make_float2(0.f, 0.f);
+    if (sp >= 0) {
+      v = in[(f * nstack + sp) * nt + t];
+      if (cj[p]) v.y = -v.y;
+    }
+    out[i] = v;
+    out_w[i] = sp >= 0 ? 1.f : 0.f;
+  }
+}
 }  // namespace
 
 extern "C" int dmm_collate_products(dmm_ctx* ctx, const void* ssv, const float* ssw, int nf_in, int nprod_in, int nt,
@@ -588,6 +610,22 @@ extern "C" int dmm_collate_products(dmm_ctx* ctx, const void* ssv, const float* 
   if (nb > 16384) nb = 16384;
   hipLaunchKernelGGL(k_collate, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float2*)ssv, ssw, nprod_in, nt, nf_out,
                      freq_ind, nstack_out, csr_ptr, csr_src, csr_conj, red, (float2*)out_vis, out_w);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+extern "C" int dmm_expand_products(dmm_ctx* ctx, const void* vis_in, int nfreq, int nstack, int nt, int nprod,
+                                   const int* src, const unsigned char* conj, void* out_vis, float* out_w) {
+  DMM_REQUIRE(ctx != nullptr, "dmm_expand_products: ctx is NULL");
+  DMM_REQUIRE(nfreq >= 0 && nstack >= 0 && nt >= 0 && nprod >= 0, "dmm_expand_products: bad sizes");
+  const int64_t total = (int64_t)nfreq * nprod * nt;
+  if (total == 0) return DMM_OK;
+  DMM_REQUIRE(vis_in && src && conj && out_vis && out_w, "dmm_expand_products: NULL argument");
+  DMM_HIP(hipSetDevice(ctx->device));
+  int64_t nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(k_expand, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float2*)vis_in, nstack, nt, nprod, src, conj,
+                     (float2*)out_vis, out_w, total);
   DMM_HIP(hipGetLastError());
   return DMM_OK;
 }

@@ -104,3 +104,46 @@ class SimulateSidereal(ContainerTask):
         sstream.attach("vis", vis_stream)
         sstream.attach("vis_weight", torch.ones(vis_stream.shape, dtype=torch.float32, device=ctx.device))  # stream.py:176
         return sstream
+
+
+class ExpandProducts(ContainerTask):
+    """Un-wrap collated products to the full triangle (``synthesis/stream.py:181-246``).
+
+    The inverse data-format step of :class:`~draco_amd.analysis.transform.CollateProducts`: every
+    product ``(i, j >= i)`` of the telescope's inputs gets the (conjugated, if ``feedconj``)
+    visibility of its unique baseline and unit weight; products of masked pairs
+    (``feedmap < 0``) stay zero with zero weight.
+    """
+
+    def setup(self, telescope):
+        self.telescope = io.get_telescope(telescope)
+
+    def process(self, sstream):
+        sstream.redistribute("freq")
+        tel = self.telescope
+        inputs = sstream.index_map.get("input")
+        ninput = len(inputs) if inputs is not None else tel.nfeed
+        ii, jj = np.triu_indices(ninput)
+        prod = np.zeros(len(ii), dtype=[("input_a", int), ("input_b", int)])
+        prod["input_a"], prod["input_b"] = ii, jj
+        nprod = len(prod)
+        fwd_stack = np.zeros(nprod, dtype=[("prod", "<u4"), ("conjugate", "u1")])
+        fwd_stack["prod"] = np.arange(nprod)
+        rev_stack = np.zeros(nprod, dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        rev_stack["stack"] = np.arange(nprod)
+        out = containers.SiderealStream(
+            freq=sstream.index_map["freq"], ra=np.asarray(sstream.index_map["ra"]), input=inputs if inputs is not None else ninput,
+            prod=prod, stack=fwd_stack, reverse_map_stack=rev_stack, attrs_from=sstream, comm=sstream.comm, allocate=False,
+        )
+        ctx = Context.get()
+        vis = _dev_dataset(sstream.vis, ctx, np.complex64)
+        nfreq, nstack, nra = vis.shape
+        src = ctx.to_device(np.asarray(tel.feedmap)[ii, jj].astype(np.int32))
+        cj = ctx.to_device(np.asarray(tel.feedconj)[ii, jj].astype(np.uint8))
+        out_v = ctx.empty((nfreq, nprod, nra), np.complex64)
+        out_w = ctx.empty((nfreq, nprod, nra), np.float32)
+        _lib.check(_lib.lib.dmm_expand_products(ctx.handle, ptr(vis), int(nfreq), int(nstack), int(nra), int(nprod), ptr(src), ptr(cj), ptr(out_v), ptr(out_w)))
+        ctx.sync()  # src / cj go out of scope below
+        out.attach("vis", out_v)
+        out.attach("vis_weight", out_w)
+        return out

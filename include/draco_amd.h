@@ -132,6 +132,13 @@ int dmm_collate_products(dmm_ctx* ctx, const void* ssv, const float* ssw, int nf
                          const int* csr_src, const unsigned char* csr_conj, const float* red,
                          void* out_vis, float* out_w);
 
+/* ExpandProducts.process (reference synthesis/stream.py:193-246): stacked stream -> full product triangle.
+ * vis_in [dev] complex64 [nfreq, nstack, nt]; src [dev] int [nprod] = unique-baseline index of each product
+ * (telescope.feedmap, < 0: masked pair, output 0 with weight 0); conj [dev] uint8 [nprod] (telescope.feedconj);
+ * outputs complex64 / float32 [nfreq, nprod, nt], weight 1 where the pair exists.                              */
+int dmm_expand_products(dmm_ctx* ctx, const void* vis_in, int nfreq, int nstack, int nt, int nprod,
+                        const int* src, const unsigned char* conj, void* out_vis, float* out_w);
+
 /* ------------------------------------------------------ map-maker solves (a5-a8)
  * A plan fixes the batch of (m, f) solves (the double loop at mapmaker.py:79-94)
  * and the shapes; it owns a device copy of the tile table.

@@ -810,6 +810,57 @@ def gen_svd(out):
     np.savez_compressed(os.path.join(out, "svdfilter.npz"), **cases)
 
 
+class FakeExpandStream(_FakeCont):
+    """SiderealStream duck type for ExpandProducts: also the constructor it calls for its output."""
+
+    last = None
+
+    def __init__(self, prod=None, stack=None, axes_from=None, vis=None, input=None):
+        if axes_from is not None:
+            nfreq, _, nra = axes_from.vis.shape
+            vis = np.zeros((nfreq, len(prod), nra), np.complex64)
+            input = axes_from.input
+        self.input = input
+        self.prod = prod
+        self.vis = _DS(vis)
+        self.weight = _DS(np.zeros(vis.shape, np.float32))
+        self.maps = {}
+
+    def create_index_map(self, name, arr):
+        self.maps[name] = arr
+
+    def create_reverse_map(self, name, arr):
+        self.maps["rev_" + name] = arr
+
+
+def gen_expand(out):
+    """ExpandProducts.process (synthesis/stream.py:193-246) on a duck-typed stacked stream."""
+    from draco.synthesis import stream
+
+    stream.containers = type("C", (), {"SiderealStream": FakeExpandStream})
+    stream.io.get_telescope = lambda t: t
+    rng = np.random.default_rng(9009)
+    cases = {}
+    idx = 0
+    for nfeed, mask in ((4, False), (5, True)):
+        tel = _CollateTel(nfeed, [400.0, 410.0, 420.0])
+        if mask:
+            tel.feedmap[1, 3] = tel.feedmap[3, 1] = -1
+        vis = crandn(rng, (3, tel.npairs, 6), np.complex64)
+        ss = FakeExpandStream(vis=vis.copy(), input=np.arange(nfeed))
+        t = stream.ExpandProducts.__new__(stream.ExpandProducts)
+        t.setup(tel)
+        res = t.process(ss)
+        cases[f"c{idx}_nfeed"] = np.int64(nfeed)
+        cases[f"c{idx}_mask"] = np.int64(mask)
+        cases[f"c{idx}_vis"] = vis
+        cases[f"c{idx}_out_vis"] = res.vis.arr.view(np.ndarray)
+        cases[f"c{idx}_out_w"] = res.weight.arr.view(np.ndarray)
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "stream_expand.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -830,6 +881,8 @@ def main():
         gen_ringmap(GOLDEN)
     if not only or "--only-collate" in only:
         gen_collate(transform, GOLDEN)
+    if not only or "--only-expand" in only:
+        gen_expand(GOLDEN)
     if not only or "--only-svd" in only:
         gen_svd(GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):

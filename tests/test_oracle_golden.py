@@ -231,3 +231,20 @@ def test_svd_em_and_tasks(golden_dir):
         np.testing.assert_allclose(spec, g[f"c{i}_spectrum"], rtol=1e-11, atol=1e-12 * spec.max())
         out = osvd.svd_filter(vis, w, niter=int(niter), global_threshold=gthr, local_threshold=lthr)
         np.testing.assert_allclose(out, g[f"c{i}_filtered"], rtol=0, atol=1e-11 * np.abs(vis).max())
+
+
+def test_expand_products(golden_dir):
+    """ExpandProducts.process (synthesis/stream.py:193-246): outputs of the reference class."""
+    from oracle import expand as oe
+
+    g = _load(golden_dir, "stream_expand.npz")
+    for i in range(int(g["ncase"])):
+        nfeed = int(g[f"c{i}_nfeed"])
+        feedmap, feedconj = _collate_tel(nfeed)
+        feedmap = feedmap.copy()
+        if int(g[f"c{i}_mask"]):
+            feedmap[1, 3] = feedmap[3, 1] = -1
+        v, w = oe.expand_products(g[f"c{i}_vis"], feedmap, feedconj, nfeed)
+        np.testing.assert_array_equal(v, g[f"c{i}_out_vis"])
+        np.testing.assert_array_equal(w, g[f"c{i}_out_w"])
+        assert np.abs(v).max() > 0
