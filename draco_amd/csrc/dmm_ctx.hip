@@ -29,12 +29,15 @@ int dmm_get_scratch(dmm_ctx* ctx, size_t bytes, void** out) {
   return DMM_OK;
 }
 
+// A ring of task counters: every launch takes the next one, so a launch still in flight on another stream of the
+// same context keeps its own counter (it would take kTickets newer launches to come round to it again).
 hipError_t dmm_ticket(dmm_ctx* ctx, unsigned long long** out) {
+  constexpr int kTickets = 256;
   if (!ctx->ticket) {
-    hipError_t e = hipMalloc((void**)&ctx->ticket, sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void**)&ctx->ticket, kTickets * sizeof(unsigned long long));
     if (e != hipSuccess) return e;
   }
-  *out = ctx->ticket;
+  *out = ctx->ticket + (ctx->ticket_seq++ % kTickets);
   return hipSuccess;
 }
 

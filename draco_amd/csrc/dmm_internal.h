@@ -33,14 +33,15 @@ struct dmm_ctx {
   int opt_sht_variant = 0;
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
-  unsigned long long* ticket = nullptr;    // task counter of the dirty kernel's dynamic hand-out
+  unsigned long long* ticket = nullptr;    // ring of task counters for the dirty kernel's dynamic hand-out
+  unsigned ticket_seq = 0;
   void* scratch = nullptr;                 // grow-only workspace (ring coefficients, Gram matrices ...)
   size_t scratch_bytes = 0;
 };
 
 // library-owned scratch of at least `bytes` (valid until the next call that asks for more)
 int dmm_get_scratch(dmm_ctx* ctx, size_t bytes, void** out);
-// the context's 8-byte device task counter (allocated on first use)
+// the next device task counter of the context's ring (allocated on first use)
 hipError_t dmm_ticket(dmm_ctx* ctx, unsigned long long** out);
 
 struct dmm_plan {
