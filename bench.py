@@ -56,6 +56,26 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_worker(args):
+    """One process of the multi-process CPU arm: Dirty solves (1 BLAS thread) on its own RAM pool of tiles."""
+    seed, npairs, lmax, ms, budget = args
+    from oracle import mapmaker as omm
+    from oracle import synth as osyn
+
+    rng = np.random.default_rng(seed)
+    tiles = [osyn.beam_tile(3000, int(m), seed % 7, npairs, 4, lmax) for m in ms]
+    v = rng.standard_normal((2, npairs)) + 1j * rng.standard_normal((2, npairs))
+    Ni = rng.uniform(0.5, 1.5, (2, npairs))
+    omm.dirty_solve(tiles[0], v, Ni)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        for bm in tiles:
+            omm.dirty_solve(bm, v, Ni)
+            n += 1
+    return n, time.perf_counter() - t0
+
+
 def cpu_baseline(cfg, seconds):
     """Oracle (NumPy restatement of the reference) timed on this box's host cores.
 
@@ -65,13 +85,16 @@ def cpu_baseline(cfg, seconds):
     reference runs) is excluded, as on the GPU side.  The final alm2map (healpy's C++ in the
     reference; the NumPy oracle would overstate it by orders of magnitude) is NOT charged to
     the CPU time, although the GPU step includes it: the CPU figure is an upper bound.
+
+    Three arms of the solve loop, the fastest one is reported with ITS core count: one process with one
+    BLAS thread; one process with every thread it may use; and P single-threaded processes each owning
+    its own tiles (the reference's MPI decomposition over frequency), P = this box's CPU share.
+    Runs BEFORE the GPU is touched (worker processes are spawned).
     """
     from oracle import mapmaker as omm
     from oracle import synth as osyn
     from oracle import transform as otr
 
-    # the BLAS behind np.dot is timed twice -- pinned to 1 thread and with every thread this process
-    # may use -- and the faster arm is reported with ITS thread count
     try:
         ncpu = len(os.sched_getaffinity(0))
     except Exception:
@@ -116,20 +139,43 @@ def cpu_baseline(cfg, seconds):
         # the reference multiplies the FULL tile (zeros included): cost is m-independent -> mean
         return float((per_m / np.maximum(cnt, 1)).mean()), n
 
-    t1, n1 = solve_arm(1, seconds / 2)
+    t1, n1 = solve_arm(1, seconds / 3)
     if threadpool_limits is not None and ncpu > 1:
-        tn, nn = solve_arm(ncpu, seconds / 2)
+        tn, nn = solve_arm(ncpu, seconds / 3)
     else:
         tn, nn = t1, 0
-    t_solve, nthreads, nsolve = (t1, 1, n1 + nn) if t1 <= tn else (tn, ncpu, n1 + nn)
-    arms = {"1_thread_ms": t1 * 1e3, f"{ncpu}_threads_ms": tn * 1e3}
-    t_job = t_fft_per_freq * nfreq + t_solve * (lmax + 1) * nfreq
+    # P single-threaded processes (a GPU box gives one GPU's job 16 cores' worth of CPU)
+    nproc = max(1, min(ncpu, 16))
+    tp, npr = float("inf"), 0
+    if nproc > 1:
+        import multiprocessing as mp
+
+        saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        os.environ.update({k: "1" for k in saved})
+        try:
+            with mp.get_context("spawn").Pool(nproc) as pool:
+                res = pool.map(_cpu_worker, [(100 + i, npairs, lmax, ms[i % len(ms) :: 3][:8], seconds / 3) for i in range(nproc)])
+            rate = sum(n / t for n, t in res)  # solves per second, all processes together
+            tp, npr = 1.0 / rate, sum(n for n, _ in res)
+        except Exception as e:  # the baseline must never break the bench line
+            tp, npr = float("inf"), 0
+            print(f"cpu_baseline: multi-process arm failed: {e!r}", file=sys.stderr)
+        finally:
+            for k, v_ in saved.items():
+                if v_ is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v_
+    t_solve, nthreads = min((t1, 1), (tn, ncpu), (tp, nproc))
+    nsolve = n1 + nn + npr
+    arms = {"1_thread_ms": t1 * 1e3, f"{ncpu}_threads_ms": tn * 1e3, f"{nproc}_processes_ms_per_solve": tp * 1e3 if np.isfinite(tp) else None}
+    t_job = t_fft_per_freq * nfreq / (nthreads if nthreads == nproc and nproc > 1 else 1) + t_solve * (lmax + 1) * nfreq
     return {
         "value": (lmax + 1) / t_job,
         "unit": "m-modes/s",
         "cores": int(nthreads),
         "kind": "port",
-        "sample": f"FFT+pack of {nf_s}/{nfreq} freqs; {nsolve} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from a {len(tiles)}-tile RAM pool) in {seconds:.0f}s; extrapolated linearly; alm2map not charged to the CPU time (GPU step includes it)",
+        "sample": f"FFT+pack of {nf_s}/{nfreq} freqs; {nsolve} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from RAM pools) in {seconds:.0f}s over three arms (1 thread / {ncpu} BLAS threads / {nproc} processes x 1 thread), fastest reported; extrapolated linearly; alm2map not charged to the CPU time (GPU step includes it)",
         "t_solve_ms": t_solve * 1e3,
         "t_solve_arms": arms,
         "t_fft_per_freq_ms": t_fft_per_freq * 1e3,
@@ -165,6 +211,7 @@ class Job:
         gen = torch.Generator(device=ctx.device).manual_seed(1000 + rank)
         self.vis = torch.randn((nfreq, npairs, nra), dtype=torch.complex64, device=ctx.device, generator=gen)
         self.weight = torch.rand((nfreq, npairs, nra), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
+        self.weight[torch.rand(self.weight.shape, dtype=torch.float32, device=ctx.device, generator=gen) < 0.01] = 0.0  # 1 % exact zeros
         self.n_m = lmax + 1
         self.alm = torch.empty((nfreq, 4, self.n_m, lmax + 1), dtype=torch.complex128, device=ctx.device)
         self.nside = cfg["nside"]
@@ -191,6 +238,22 @@ class Job:
         self.ncycle = nfreq // pool_freqs
         self._lib = _lib
         ctx.sync()
+
+    def stages_alone_ms(self):
+        """HIP-event times of the step's other two stages, each alone on the GPU (T_fft, T_sht)."""
+        from draco_amd.analysis.transform import mmode_forward
+        from draco_amd.device import ptr
+
+        ctx = self.ctx
+        ctx.sync()
+        self.torch.cuda.synchronize()
+        ctx.timer_start()
+        mmode_forward(ctx, self.vis, self.weight, self.lmax)
+        t_fft = ctx.timer_stop()
+        ctx.timer_start()
+        self._lib.check(self._lib.lib.dmm_alm2map(ctx.handle, ptr(self.alm), self.nfreq, 4, self.lmax, self.lmax, self.nside, ptr(self.maps)))
+        t_sht = ctx.timer_stop()
+        return {"fft": t_fft, "sht": t_sht}
 
     def dirty_alone_ms(self, reps=2):
         """Mean HIP-event time of one pool cycle's Dirty launch with nothing else on the GPU."""
@@ -249,12 +312,18 @@ class Job:
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import synth as _osyn
+
+        cpu = cpu_baseline(_osyn.CONFIGS[args.config], args.cpu_seconds)  # before any GPU work: it spawns processes
+
+    import torch
+    import torch.distributed as dist
+
     if world > 1:
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -277,6 +346,7 @@ def main():
     # reference point for the roofline object, outside the timed region: the Dirty kernel with the GPU to itself
     # (inside the step the side stream's alm2map shares CUs and HBM with it)
     alone_ms = job.dirty_alone_ms()
+    stage_ms = job.stages_alone_ms()
     barrier()
     t0 = time.perf_counter()
     dirty_ms = 0.0
@@ -323,6 +393,11 @@ def main():
             "parallelism": f"freq-sharded x{world} (no collective in the timed region)",
             "alm2map": "side stream, per solved cycle, beside the next cycle's solves" if job.side is not None else "main stream, after all solves",
         },
+        # SURVEY 8d asks for the stage times next to the metric; each measured alone on the GPU after warmup
+        # (in the step the SHT runs beside the solves).  value_to_alm = (mmax+1) / (T_fft + T_solve): the metric
+        # with T ending at "a_lm of all (m,f) resident", i.e. without DirtyMapMaker's final alm2map
+        "stages_alone_ms": {"T_fft": stage_ms["fft"], "T_solve": alone_ms * job.ncycle, "T_sht": stage_ms["sht"]},
+        "value_to_alm": world * (cfg["lmax"] + 1) / ((stage_ms["fft"] + alone_ms * job.ncycle) * 1e-3),
         "roofline": {
             "kernel": "k_dirty (a = B^H N^-1 v, batched over (m,f))",
             "bound": "hbm",
@@ -405,10 +480,8 @@ def main():
             extra["error"] = repr(e)
         out["extra"] = extra
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    if rank == 0:
+        out["cpu_baseline"] = cpu
 
     if rank == 0:
         print(json.dumps(out))
