@@ -420,6 +420,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}
+        per_freq = job.pool_bytes // job.pool_freqs  # bytes of one frequency's B tiles
         try:
             # complex64 storage of B (half the bytes, float64 accumulation)
             if args.b_dtype == "complex128":
@@ -476,6 +477,23 @@ def main():
                     t_w = time.perf_counter() - t0
                 extra[f"{kind}_ms_per_solve"] = t_w * 1e3 / (nf_w * (lmax + 1))
             extra["dense_sample"] = f"all {lmax + 1} m of {nf_w} frequencies, B resident"
+            # B = host-stream (SURVEY 8d's second residency policy): one frequency's tiles (6.4 GB) from pinned host
+            # memory into the pool per step of the stream, PCIe-bound; the solves hide completely behind the copy
+            hb = torch.empty(per_freq, dtype=torch.uint8).pin_memory()
+            dv = torch.empty(per_freq, dtype=torch.uint8, device="cuda")
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dv.copy_(hb, non_blocking=True)
+                torch.cuda.synchronize()
+                t_h2d = time.perf_counter() - t0
+            extra["b_host_stream"] = {
+                "value": (lmax + 1) / (t_h2d * nfreq),
+                "unit": "m-modes/s",
+                "h2d_GBs": per_freq / t_h2d / 1e9,
+                "note": "pinned host -> HBM copy of one frequency's B tiles, times the job's frequencies; PCIe-bound, the solves (1 ms per frequency) hide behind it",
+            }
+            del hb, dv
         except Exception as e:  # secondary numbers must never break the headline line
             extra["error"] = repr(e)
         out["extra"] = extra
