@@ -228,3 +228,32 @@ def test_wiener_cfg2_sized_tile_properties():
         lhs = a[:, m:].reshape(-1) / S + B.conj().T @ (Ni.reshape(-1) * (B @ a[:, m:].reshape(-1)))
         rhs = B.conj().T @ (Ni.reshape(-1) * v.reshape(-1))
         assert _rel(lhs, rhs) < 1e-10, m
+
+
+@pytest.mark.parametrize("kind", ["wiener", "ml"])
+def test_dense_full_layout_matches_packed(kind):
+    """B handed over in the FULL [.., lmax+1] layout (driftscan's on-disk shape) must give the packed layout's
+    alm for both dense solvers, on both the telescope-side (low m) and sky-side (high m) systems."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    lmax = 50
+    tel = _tel(2, lmax, 2, 4)  # ntel = 86: both sides of the nsky_m / ntel split occur
+    bt = SyntheticProvider(tel, seed=77)
+    gen = torch.Generator(device=ctx.device).manual_seed(3)
+    shape = (lmax + 1, 2, 2, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) * 20.0
+    kw = {"prior_amp": 1.5, "prior_tilt": 0.5} if kind == "wiener" else {}
+    outs = {}
+    for dt in (_lib.DMM_C128, _lib.DMM_C64):
+        for layout in (_lib.DMM_B_PACKED, _lib.DMM_B_FULL):
+            eng = SolveEngine(bt, ctx, dt, layout)
+            outs[dt, layout] = eng.solve(kind, mv, mw, [0, 1], lmax, **kw).cpu().numpy()
+    for dt in (_lib.DMM_C128, _lib.DMM_C64):
+        assert _rel(outs[dt, _lib.DMM_B_PACKED], outs[dt, _lib.DMM_B_FULL]) < 1e-12, dt
