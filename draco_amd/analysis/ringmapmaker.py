@@ -8,8 +8,8 @@ validation errors.  This is the production CHIME map-maker; it consumes the
 
 The per-frequency NumPy loop of the reference (``ringmapmaker.py:744-823``) runs as four
 kernels over all local frequencies at once (``csrc/ringmap.hip``).  Arithmetic is float64
-throughout.  Not built: the ``DeconvolveAnalyticalBeam`` variants (they need driftscan's
-analytic beam model [3P]).
+throughout.  The ``DeconvolveAnalyticalBeam`` variants (``ringmapmaker.py:968-1072, 1189-1190``) generate
+their beam m-modes on the device (``dmm_analytic_beam_mmodes``) and then run the same kernels.
 """
 
 from __future__ import annotations
@@ -228,6 +228,58 @@ class WienerRingMapMaker(DeconvolveHybridMBase):
         for cyl in self.exclude_cyl:
             keep[cyl] = 0.0
         return 2, keep
+
+
+class DeconvolveAnalyticalBeam(DeconvolveHybridMBase):
+    """Deconvolve the analytic (Gaussian-on-the-circle) transit beam model (``ringmapmaker.py:968-1072``);
+    non-functional on its own, like the reference's."""
+
+    # EW voltage-beam widths: sigma = coef / freq[MHz] / cos(dec), per feed polarisation (:1009-1017)
+    _beam_coef = {"X": 14.87857614, "Y": 9.95746878}
+
+    def setup(self, telescope):
+        self.telescope = io.get_telescope(telescope)
+        excl = list(self.exclude_cyl or [])
+        if self.exclude_intracyl:
+            excl.append(0)
+        self.exclude_cyl = sorted(set(excl))
+
+    def process(self, hybrid_vis_m):
+        return super().process(hybrid_vis_m, self._get_beam_mmodes(hybrid_vis_m))
+
+    def _get_beam_mmodes(self, hybrid_vis_m):
+        """Beam m-modes on the axes of ``hybrid_vis_m`` (``ringmapmaker.py:1004-1072``), device resident."""
+        ctx = Context.get()
+        mmax = hybrid_vis_m.mmax
+        nra = 2 * mmax + int(hybrid_vis_m.oddra)
+        dec = np.arcsin(np.asarray(hybrid_vis_m.index_map["el"], dtype=np.float64)) + np.radians(self.telescope.latitude)
+        pol = [str(x) for x in hybrid_vis_m.index_map["pol"]]
+        try:
+            ca = np.array([self._beam_coef[x[0]] for x in pol], dtype=np.float64)
+            cb = np.array([self._beam_coef[x[1]] for x in pol], dtype=np.float64)
+        except (KeyError, IndexError):
+            raise KeyError(f"polarisations must be pairs of 'X'/'Y' feeds, got {pol}") from None
+        freq = np.asarray(hybrid_vis_m.freq, dtype=np.float64)
+        ew = np.asarray(hybrid_vis_m.index_map["ew"], dtype=np.float64)
+        out = ctx.empty((mmax + 1, 2, len(pol), len(freq), len(ew), len(dec)), np.complex64)
+        tabs = [ctx.to_device(x, np.float64) for x in (freq, ew, dec, ca, cb)]  # held until the launch is queued
+        _lib.check(
+            _lib.lib.dmm_analytic_beam_mmodes(
+                ctx.handle, len(pol), len(freq), len(ew), len(dec), int(nra), int(mmax), *(ptr(t) for t in tabs), ptr(out)
+            )
+        )
+        beam = containers.HybridVisMModes(mmax=mmax, oddra=hybrid_vis_m.oddra, axes_from=hybrid_vis_m, attrs_from=hybrid_vis_m,
+                                          comm=hybrid_vis_m.comm, allocate=False)
+        beam.attach("vis", out)
+        return beam
+
+
+class TikhonovRingMapMakerAnalytical(DeconvolveAnalyticalBeam, TikhonovRingMapMaker):
+    """Tikhonov deconvolution of the analytical beam model (``ringmapmaker.py:1189``)."""
+
+
+class WienerRingMapMakerAnalytical(DeconvolveAnalyticalBeam, WienerRingMapMaker):
+    """Wiener deconvolution of the analytical beam model (``ringmapmaker.py:1190``)."""
 
 
 # Aliases to support old names (ringmapmaker.py:1193-1194)

@@ -139,6 +139,107 @@ __global__ __launch_bounds__(kThreads) void k_mfft_pack(MfftParams p) {
   }
 }
 
+struct BeamParams {
+  int npol, nfreq, n_ew, nel;
+  int64_t nrow;
+  int N, M, logM, RB, P;
+  const double2* tw;
+  const double2* chirp;
+  const double2* bfilt;
+  const double* freq;    // [nfreq] MHz
+  const double* ew;      // [n_ew] m
+  const double* dec;     // [nel] rad
+  const double* coef_a;  // [npol] beam-width coefficient of the first / second feed of the pol pair
+  const double* coef_b;
+  float2* out;  // [mmax+1, 2, nrow]
+  int mmax, mlim, mlim_neg;
+};
+
+// Analytic transit beam (ringmapmaker.py:1019-1025,1046-1064), conjugated (:1066), generated straight into the LDS
+// image of a double-precision forward transform and packed like k_mfft_pack; rows are (pol, freq, ew, el).
+template <bool BLUESTEIN>
+__global__ __launch_bounds__(kThreads) void k_beam_mfft(BeamParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  C<double>* buf = reinterpret_cast<C<double>*>(smem);
+  C<double>* tw = buf + (size_t)p.RB * p.P;
+  __shared__ double s_u[16], s_is2[16];
+  const int N = p.N, M = p.M, RB = p.RB, P = p.P;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+
+  for (int k = threadIdx.x; k < (M >> 1); k += kThreads) {
+    const double2 w = p.tw[k];
+    tw[k] = {w.x, w.y};
+  }
+  if (threadIdx.x < RB && r0 + threadIdx.x < p.nrow) {
+    int64_t r = r0 + threadIdx.x;
+    const int el = (int)(r % p.nel);
+    r /= p.nel;
+    const int e = (int)(r % p.n_ew);
+    r /= p.n_ew;
+    const int f = (int)(r % p.nfreq);
+    const int pol = (int)(r / p.nfreq);
+    const double fr = p.freq[f], cd = cos(p.dec[el]);
+    const double wv = 299792458.0 * 1e-6 / fr;  // scipy.constants.c * 1e-6 / freq (:1047)
+    s_u[threadIdx.x] = p.ew[e] / wv * cd;
+    const double sa = p.coef_a[pol] / fr / cd, sb = p.coef_b[pol] / fr / cd;
+    const double sig = sa * sb / sqrt(sa * sa + sb * sb);
+    s_is2[threadIdx.x] = 1.0 / (2.0 * sig * sig);
+  }
+  __syncthreads();
+  const double step = 360.0 / (double)N;  // np.linspace(0, 360, nra, endpoint=False) then np.radians
+  for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
+    const int r = idx / M, k = idx - r * M;
+    C<double> v = {0.0, 0.0};
+    if (k < N && r0 + r < p.nrow) {
+      const double phi = ((double)k * step) * (M_PI / 180.0);
+      const double t = 2.0 * tan(0.5 * phi);
+      const double amp = exp(-(t * t) * s_is2[r]);
+      double sn, cs;
+      sincos(2.0 * M_PI * s_u[r] * sin(phi), &sn, &cs);
+      v = {amp * cs, -amp * sn};
+      if (BLUESTEIN) {
+        const double2 c = p.chirp[k];
+        v = cmul<double>(v, {c.x, c.y});
+      }
+    }
+    buf[r * P + k] = v;
+  }
+  __syncthreads();
+  fft_dif<double>(buf, tw, RB, M, p.logM, P);
+  if (BLUESTEIN) {
+    for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
+      const int r = idx / M, k = idx - r * M;
+      const double2 f = p.bfilt[k];
+      buf[r * P + k] = cmul<double>(buf[r * P + k], {f.x, f.y});
+    }
+    __syncthreads();
+    fft_dit<double, true>(buf, tw, RB, M, p.logM, P);
+  }
+  const double inv_n = 1.0 / (double)N;
+  const int nslot = (p.mmax + 1) * 2;
+  for (int idx = threadIdx.x; idx < nslot * RB; idx += kThreads) {
+    const int r = idx % RB, ms = idx / RB;
+    const int s = ms & 1, m = ms >> 1;
+    if (r0 + r >= p.nrow) continue;
+    double re = 0.0, im = 0.0;
+    int k = -1;
+    if (s == 0 && m <= p.mlim) k = m;
+    if (s == 1 && m >= 1 && m <= p.mlim_neg) k = N - m;
+    if (k >= 0) {
+      C<double> v;
+      if (BLUESTEIN) {
+        const double2 c = p.chirp[k];
+        v = cmul<double>(buf[r * P + k], {c.x, c.y});
+      } else {
+        v = buf[r * P + bitrev(k, p.logM)];
+      }
+      re = v.x * inv_n;
+      im = (s ? -v.y : v.y) * inv_n;
+    }
+    p.out[(int64_t)ms * p.nrow + r0 + r] = make_float2((float)re, (float)im);
+  }
+}
+
 struct MifftParams {
   const double2* mvis;  // [n_m, 2, nrow]
   int64_t nrow;
@@ -408,6 +509,45 @@ int dmm_mfft_pack(dmm_ctx* ctx, const void* ts, int64_t nrow, int nra, void* out
   DMM_REQUIRE(nblk <= 0x7fffffff, "dmm_mfft_pack: too many rows");
   const bool blue = t->chirp != nullptr;
   auto kern = blue ? k_mfft_pack<true> : k_mfft_pack<false>;
+  DMM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, ctx->stream, p);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+int dmm_analytic_beam_mmodes(dmm_ctx* ctx, int npol, int nfreq, int new_, int nel, int nra, int mmax, const double* freq,
+                             const double* ew, const double* dec, const double* coef_a, const double* coef_b, void* out) {
+  DMM_REQUIRE(ctx != nullptr, "dmm_analytic_beam_mmodes: ctx is NULL");
+  DMM_REQUIRE(npol >= 0 && nfreq >= 0 && new_ >= 0 && nel >= 0 && nra >= 1 && mmax >= 0,
+              "dmm_analytic_beam_mmodes: bad sizes npol=%d nfreq=%d new=%d nel=%d nra=%d mmax=%d", npol, nfreq, new_, nel, nra, mmax);
+  const int64_t nrow = (int64_t)npol * nfreq * new_ * nel;
+  if (nrow == 0) return DMM_OK;
+  DMM_REQUIRE(freq && ew && dec && coef_a && coef_b && out, "dmm_analytic_beam_mmodes: NULL argument");
+  if (nra > DMM_MAX_NRA) return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_analytic_beam_mmodes: nra=%d > %d", nra, DMM_MAX_NRA);
+  DMM_HIP(hipSetDevice(ctx->device));
+  dmm_fft_tables* t = nullptr;
+  int rc = get_tables<double2, double>(ctx->ifft, nra, &t);
+  if (rc) return rc;
+  BeamParams p;
+  p.npol = npol, p.nfreq = nfreq, p.n_ew = new_, p.nel = nel;
+  p.nrow = nrow;
+  p.N = nra;
+  p.M = t->M;
+  p.logM = ilog2(t->M);
+  size_t lds = 0;
+  if (!choose_rb(p.M, sizeof(double2), nrow, &p.RB, &p.P, &lds))
+    return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_analytic_beam_mmodes: nra=%d needs %zu B of LDS", nra, lds);
+  p.tw = (const double2*)t->tw;
+  p.chirp = (const double2*)t->chirp;
+  p.bfilt = (const double2*)t->bfilt;
+  p.freq = freq, p.ew = ew, p.dec = dec, p.coef_a = coef_a, p.coef_b = coef_b;
+  p.out = (float2*)out;
+  p.mmax = mmax;
+  p.mlim = nra / 2 < mmax ? nra / 2 : mmax;
+  p.mlim_neg = (mmax >= nra / 2) ? nra / 2 - 1 + nra % 2 : mmax;
+  const int64_t nblk = (nrow + p.RB - 1) / p.RB;
+  DMM_REQUIRE(nblk <= 0x7fffffff, "dmm_analytic_beam_mmodes: too many rows");
+  auto kern = t->chirp ? k_beam_mfft<true> : k_beam_mfft<false>;
   DMM_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), lds, ctx->stream, p);
   DMM_HIP(hipGetLastError());

@@ -211,6 +211,18 @@ int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npol, int nfre
                            const float* window, double* map, double* weight, double* dirty_beam_power,
                            double* dirty_beam);
 
+/* dmm_analytic_beam_mmodes replaces DeconvolveAnalyticalBeam._get_beam_mmodes (reference
+ * ringmapmaker.py:1004-1072): for every (pol, freq, ew, el) the conjugated transit of the analytic
+ * beam  exp(2 pi i u cos(dec) sin(phi)) * exp(-(2 tan(phi/2))^2 / (2 sigma^2)),  phi = 2 pi k / nra,
+ * u = ew / wavelength, sigma = sa*sb/sqrt(sa^2+sb^2) with s = coef / freq / cos(dec) per feed of the pol
+ * pair (:1009-1017,1057-1060), is generated in float64 and m-transformed (double-precision FFT, the
+ * _make_marray packing of dmm_mfft_pack) into
+ *   out [dev] complex64 [mmax+1, 2, npol, nfreq, new, nel]            (HybridVisMModes.vis layout).
+ * freq [nfreq] MHz, ew [new] metres, dec [nel] radians, coef_a/coef_b [npol]: all [dev] double.   */
+int dmm_analytic_beam_mmodes(dmm_ctx* ctx, int npol, int nfreq, int new_, int nel, int nra, int mmax,
+                             const double* freq, const double* ew, const double* dec, const double* coef_a,
+                             const double* coef_b, void* out);
+
 /* ------------------------------------------------ synthetic beam-transfer tiles
  * Fill tiles with the counter-hash generator shared with oracle/synth.py
  * (bit-identical in float64): value(seed, m, f, row, pol, l) with l<m -> 0.

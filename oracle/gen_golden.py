@@ -565,6 +565,78 @@ def gen_ringmap(out):
     np.savez_compressed(os.path.join(out, "ringmap_deconvolve.npz"), **cases)
 
 
+class _HybEnumArr(_Arr):
+    def enumerate(self, axis):
+        return [(i, i) for i in range(self.shape[axis])]
+
+
+class _HybEnumDS(_ShapeDS):
+    def __init__(self, arr):
+        self.arr = arr.view(_HybEnumArr)
+
+
+def gen_ringmap_analytic(out):
+    """DeconvolveAnalyticalBeam._get_beam_mmodes (ringmapmaker.py:1001-1072) and the two ...Analytical makers
+    (:1189-1194) end to end.  caput's pyfftw wrapper [3P] is absent: `transform.fft.fftw.fft` is served by
+    np.fft.fft (the same complex128 DFT)."""
+    import types
+
+    from draco.analysis import ringmapmaker as rmk
+    from draco.analysis import transform
+
+    transform.fft = types.SimpleNamespace(fftw=types.SimpleNamespace(fft=lambda x, axes=-1: np.fft.fft(x, axis=axes)))
+    rmk.containers = type("NS", (), {"RingMap": FakeRingMap, "HybridVisMModes": FakeHybridM})
+
+    def _empty_like(c):
+        o = FakeHybridM(np.zeros(c.vis.shape, np.complex64), np.zeros(c.weight.shape, np.float32), c.freq, c.index_map["ew"], c.index_map["el"], c.oddra)
+        o.index_map = dict(c.index_map)
+        return o
+
+    rmk.empty_like = _empty_like
+
+    class _T:
+        latitude = 49.3
+
+    rng = np.random.default_rng(6106)
+    pol = np.array(["XX", "XY", "YX", "YY"])
+    freq = np.array([410.0, 600.0, 790.0])
+    ew = np.array([0.0, 22.0, 44.0, 66.0])
+    cases = {"pol": pol, "freq": freq, "ew": ew, "latitude": np.float64(_T.latitude)}
+    idx = 0
+    for nm, oddra, nel, kind in ((9, False, 5, "tikhonov"), (8, True, 6, "wiener"), (17, False, 3, "tikhonov")):
+        el = np.linspace(-0.7, 0.9, nel)
+        hv = crandn(rng, (nm, 2, 4, len(freq), len(ew), nel), np.complex64)
+        hw = rng.uniform(0.5, 1.5, (nm, 2, 4, len(freq), len(ew))).astype(np.float32)
+        hw[rng.uniform(size=hw.shape) < 0.1] = 0.0
+        cls = rmk.TikhonovRingMapMakerAnalytical if kind == "tikhonov" else rmk.WienerRingMapMakerAnalytical
+        t = cls.__new__(cls)
+        t.log = _Log()
+        t.exclude_cyl, t.exclude_intracyl, t.skip_deconvolution = [], False, False
+        t.reference_declination, t.save_dirty_beam = None, True
+        t.window_type, t.window_size, t.window_scaled = "none", 1.0, False
+        t.telescope = _T()
+        if kind == "tikhonov":
+            t.weight_ew, t.inv_SN = "natural", 1e-3
+        else:
+            t.gal_amp, t.gal_alpha, t.gal_beta, t.psrc_amp, t.psrc_alpha = 1.41, -1.75, -0.75, 0.045, -1.0
+        hvm = FakeHybridM(hv.copy(), hw.copy(), freq, ew, el, oddra)
+        hvm.vis = _HybEnumDS(hv.copy())
+        hvm.index_map["pol"] = pol
+        bm = t._get_beam_mmodes(hvm)
+        rm = t.process(hvm)
+        cases[f"c{idx}_kind"] = np.array(kind)
+        cases[f"c{idx}_hv"], cases[f"c{idx}_hw"], cases[f"c{idx}_el"] = hv, hw, el
+        cases[f"c{idx}_oddra"] = np.int64(oddra)
+        cases[f"c{idx}_beam_m"] = bm.vis.arr.view(np.ndarray)
+        cases[f"c{idx}_map"] = rm.map.arr.view(np.ndarray)
+        cases[f"c{idx}_wgt"] = rm.weight.arr.view(np.ndarray)
+        cases[f"c{idx}_dbp"] = rm.dirty_beam_power.arr.view(np.ndarray)
+        cases[f"c{idx}_db"] = rm.dirty_beam.arr.view(np.ndarray)
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "ringmap_analytic.npz"), **cases)
+
+
 class _LA(np.ndarray):
     @property
     def local_array(self):
@@ -879,6 +951,8 @@ def main():
         gen_mask(GOLDEN)
     if not only or "--only-ringmap" in only:
         gen_ringmap(GOLDEN)
+    if not only or "--only-ringmap-analytic" in only:
+        gen_ringmap_analytic(GOLDEN)
     if not only or "--only-collate" in only:
         gen_collate(transform, GOLDEN)
     if not only or "--only-expand" in only:

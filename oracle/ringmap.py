@@ -147,3 +147,38 @@ def deconvolve(kind, hv, hw, bv, freq, el, ew, oddra, exclude_cyl=(), skip_decon
         sum_var_map_m = 0.5 * np.sum((sigma * winf * norm[np.newaxis, :, 0] * invert_no_zero((mmax + 1) * C_inv)) ** 2, axis=0)[:, np.newaxis, :]
         rmw[:, lfi] = invert_no_zero(sum_var_map_m)
     return rmm, rmw, rmbp, rmb
+
+
+# EW voltage-beam widths (sigma, radians) per feed polarisation: sigma = coef / freq[MHz] / cos(dec)
+# (ringmapmaker.py:1009-1017)
+_BEAM_COEF = {"X": 14.87857614, "Y": 9.95746878}
+
+
+def analytic_beam_mmodes(freq, ew, el, pol, latitude, mmax, oddra):
+    """``DeconvolveAnalyticalBeam._get_beam_mmodes`` (ringmapmaker.py:1004-1072) on plain arrays.
+
+    Returns the beam m-modes ``[mmax+1, 2, npol, nfreq, new, nel]`` complex64: for every (pol, freq, ew, el) the
+    transit ``conj(exp(2 pi i u cos(dec) sin(phi)) * exp(-(2 tan(phi/2))^2 / (2 sigma^2)))`` over
+    ``phi = 2 pi k / nra``, ``nra = 2 mmax + oddra``, transformed with ``_make_marray`` (complex128 FFT, stored
+    complex64).  Pinned by ``tests/golden/ringmap_analytic.npz``.
+    """
+    from .transform import make_marray
+
+    freq = np.asarray(freq, dtype=np.float64)
+    ew = np.asarray(ew, dtype=np.float64)
+    nra = 2 * int(mmax) + int(oddra)
+    dec = np.arcsin(np.asarray(el, dtype=np.float64)) + np.radians(latitude)
+    phi = np.radians(np.linspace(0.0, 360.0, nra, endpoint=False))
+    out = np.zeros((mmax + 1, 2, len(pol), len(freq), len(ew), len(dec)), dtype=np.complex64)
+    for fi, f in enumerate(freq):
+        u = ew / (scipy.constants.c * 1e-6 / f)
+        u_dec = u[:, None] * np.cos(dec)[None, :]
+        sig = np.zeros((len(pol), len(dec)))
+        for pi, (pa, pb) in enumerate(pol):
+            sa = _BEAM_COEF[pa] / f / np.cos(dec)
+            sb = _BEAM_COEF[pb] / f / np.cos(dec)
+            sig[pi] = sa * sb / (sa**2 + sb**2) ** 0.5
+        amp = np.exp(-((2 * np.tan(phi / 2)) ** 2) / (2 * sig[:, None, :, None] ** 2))
+        b = np.exp(2.0j * np.pi * u_dec[None, :, :, None] * np.sin(phi)) * amp
+        out[:, :, :, fi] = make_marray(b.conj(), mmax=mmax, dtype=np.complex64)
+    return out

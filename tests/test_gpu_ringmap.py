@@ -124,3 +124,65 @@ def test_validation_errors():
     tw = TikhonovRingMapMaker(window_type="hann")
     with pytest.raises(RuntimeError, match="Must provide manager"):
         tw.setup()
+
+
+_POL = np.array(["XX", "XY", "YX", "YY"])
+
+
+class _Tel:
+    lmax = mmax = 1
+    frequencies = np.array([600.0])
+
+    def __init__(self, latitude):
+        self.latitude = latitude
+
+
+def test_analytic_beam_reference_golden(golden_dir):
+    """``...RingMapMakerAnalytical`` against the reference's own ``_get_beam_mmodes`` + ``process`` outputs.
+
+    Beam m-modes are complex64 built from a float64 FFT on both sides: agreement is the rounding of the complex64
+    store (a last-bit flip where device and host libm differ by an ulp), stated as 2e-7 of the largest mode."""
+    from draco_amd.analysis.ringmapmaker import TikhonovRingMapMakerAnalytical, WienerRingMapMakerAnalytical
+    from draco_amd.core import containers
+
+    g = np.load(os.path.join(golden_dir, "ringmap_analytic.npz"))
+    for i in range(int(g["ncase"])):
+        hv, hw, el = g[f"c{i}_hv"], g[f"c{i}_hw"], g[f"c{i}_el"]
+        kind = str(g[f"c{i}_kind"])
+        cls = TikhonovRingMapMakerAnalytical if kind == "tikhonov" else WienerRingMapMakerAnalytical
+        t = cls(save_dirty_beam=True, **({"inv_SN": 1e-3} if kind == "tikhonov" else {}))
+        t.setup(_Tel(float(g["latitude"])))
+        v = containers.HybridVisMModes(mmax=hv.shape[0] - 1, oddra=bool(g[f"c{i}_oddra"]), pol=_POL, freq=g["freq"], ew=g["ew"], el=el)
+        v.vis[:] = hv
+        v.weight[:] = hw
+        bm = t._get_beam_mmodes(v)
+        ref = g[f"c{i}_beam_m"]
+        got = bm.vis[:]
+        assert got.shape == ref.shape and got.dtype == np.complex64
+        assert np.abs(got - ref).max() < 2e-7 * np.abs(ref).max(), i
+        rm = t.process(v)
+        for ds, name in ((rm.map, "map"), (rm.weight, "wgt"), (rm.dirty_beam_power, "dbp"), (rm.dirty_beam, "db")):
+            r = g[f"c{i}_{name}"]
+            assert np.abs(ds[:] - r).max() < 5e-6 * np.abs(r).max(), (i, name)
+
+
+@pytest.mark.parametrize("mmax,oddra,nel,nfreq", [(64, False, 33, 2), (100, True, 7, 3), (512, False, 5, 1), (300, False, 4, 2)])
+def test_analytic_beam_vs_oracle(mmax, oddra, nel, nfreq):
+    """nra = 128 / 1024 (radix-2) and 201 / 600 (Bluestein) against the float64 oracle."""
+    from draco_amd.analysis.ringmapmaker import TikhonovRingMapMakerAnalytical
+    from draco_amd.core import containers
+
+    freq = np.linspace(400.0, 800.0, nfreq, endpoint=False)
+    ew = np.array([0.0, 22.0, 44.0, 66.0])
+    el = np.linspace(-0.95, 0.95, nel)
+    t = TikhonovRingMapMakerAnalytical()
+    t.setup(_Tel(49.32))
+    v = containers.HybridVisMModes(mmax=mmax, oddra=oddra, pol=_POL, freq=freq, ew=ew, el=el)
+    got = t._get_beam_mmodes(v).vis[:]
+    ref = orm.analytic_beam_mmodes(freq, ew, el, _POL, 49.32, mmax, oddra)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-7 * np.abs(ref).max()
+    # structure: the -m half of m = 0 and (even nra) of the Nyquist row stays zero like _make_marray's
+    assert np.all(got[0, 1] == 0)
+    if not oddra:
+        assert np.all(got[mmax, 1] == 0)

@@ -175,6 +175,21 @@ def test_ringmap_deconvolve(golden_dir):
             np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max(), err_msg=f"case {i} {name}")
 
 
+def test_ringmap_analytic_beam(golden_dir):
+    """Analytic beam m-modes + the ...Analytical makers' outputs (reference ringmapmaker.py:1004-1072, 1189-1190)."""
+    from oracle import ringmap as orm
+
+    g = _load(golden_dir, "ringmap_analytic.npz")
+    for i in range(int(g["ncase"])):
+        hv, el, odd = g[f"c{i}_hv"], g[f"c{i}_el"], int(g[f"c{i}_oddra"])
+        bm = orm.analytic_beam_mmodes(g["freq"], g["ew"], el, g["pol"], float(g["latitude"]), hv.shape[0] - 1, odd)
+        assert bm.dtype == np.complex64 and np.array_equal(bm, g[f"c{i}_beam_m"]), i
+        out = orm.deconvolve(str(g[f"c{i}_kind"]), hv, g[f"c{i}_hw"], bm, g["freq"], el, g["ew"], odd, weight_ew="natural", inv_SN=1e-3)
+        for got, name in zip(out, ("map", "wgt", "dbp", "db")):
+            ref = g[f"c{i}_{name}"]
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max(), err_msg=f"case {i} {name}")
+
+
 def _collate_tel(nfeed):
     feedmap = np.abs(np.arange(nfeed)[None, :] - np.arange(nfeed)[:, None])
     feedconj = np.arange(nfeed)[:, None] > np.arange(nfeed)[None, :]

@@ -57,7 +57,8 @@ def main():
     alm[:, :, 0, :] = alm[:, :, 0, :].real.to(torch.complex128)  # m = 0 is real
     alm[:, 1:3, :, :2] = 0
     sky = ctx.empty((tel.nfreq, 4, 12 * nside * nside), np.float64)
-    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm.contiguous()), tel.nfreq, 4, lmax, lmax, nside, ptr(sky)))
+    alm = alm.contiguous()
+    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), tel.nfreq, 4, lmax, lmax, nside, ptr(sky)))
     mp = containers.Map(nside=nside, freq=tel.frequencies, allocate=False)
     mp.attach("map", sky)
 
