@@ -523,7 +523,10 @@ __global__ __launch_bounds__(kThreads) void k_bj_init(BjParams bp) {  // V = I, 
 
 // Solve one 64x64 Hermitian sub-problem per block entirely in LDS (cyclic Jacobi, parallel
 // ordering: 63 rounds of 32 disjoint rotations per sweep), emit W^H.
-__global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
+// 16 waves per block: the rotations are chains of dependent LDS accesses, four waves per SIMD hide their latency
+// (the LDS image allows one block per CU only).
+constexpr int kSubThreads = 1024;
+__global__ __launch_bounds__(kSubThreads) void k_bj_sub(BjParams bp) {
   extern __shared__ __align__(16) unsigned char smem_bj[];
   constexpr int M = 2 * JB, MP = M + 1;
   double2(*s)[MP] = reinterpret_cast<double2(*)[MP]>(smem_bj);
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
   if (threadIdx.x == 0) need = work = 0;
   __syncthreads();
   int my_need = 0, my_work = 0;
-  for (int idx = threadIdx.x; idx < M * M; idx += kThreads) {
+  for (int idx = threadIdx.x; idx < M * M; idx += kSubThreads) {
     const int i = idx / M, j = idx % M;
     const int gi = i < JB ? P0 + i : Q0 + i - JB, gj = j < JB ? P0 + j : Q0 + j - JB;
     const double2 v = A[(int64_t)gi * n + gj];
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
       }
       __syncthreads();
       // columns of S and W:  new_p = c col_p - conj(s) col_q ; new_q = s col_p + c col_q
-      for (int idx = threadIdx.x; idx < M * (M / 2); idx += kThreads) {
+      for (int idx = threadIdx.x; idx < M * (M / 2); idx += kSubThreads) {
         const int row = idx / (M / 2), k = idx % (M / 2);
         const double2 sn = rs[k];
         if (sn.x == 0.0 && sn.y == 0.0) continue;
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
       }
       __syncthreads();
       // rows of S:  new_p = c row_p - s row_q ; new_q = conj(s) row_p + c row_q
-      for (int idx = threadIdx.x; idx < (M / 2) * M; idx += kThreads) {
+      for (int idx = threadIdx.x; idx < (M / 2) * M; idx += kSubThreads) {
         const int k = idx / M, col = idx % M;
         const double2 sn = rs[k];
         if (sn.x == 0.0 && sn.y == 0.0) continue;
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void k_bj_sub(BjParams bp) {
     __syncthreads();
   }
   double2* Wh = bp.Wh + ((int64_t)mat * (bp.nb / 2) + pr) * M * M;
-  for (int idx = threadIdx.x; idx < M * M; idx += kThreads) {
+  for (int idx = threadIdx.x; idx < M * M; idx += kSubThreads) {
     const int j = idx / M, k = idx % M;
     const double2 v = w[k][j];
     Wh[idx] = make_double2(v.x, -v.y);  // W^H[j][k] = conj(W[k][j])

@@ -106,6 +106,7 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_outer_sweeps")) c->opt_ml_outer_sweeps = (int)value;
   else if (!strcmp(name, "sht_variant")) c->opt_sht_variant = (int)value;
   else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
+  else if (!strcmp(name, "ml_eigen")) c->opt_ml_eigen = (int)value;
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_set_option: unknown option '%s'", name);
   return DMM_OK;
 }

@@ -1,0 +1,479 @@
+// Direct Hermitian pseudo-inverse for the maximum-likelihood map-maker's rejected tiles:
+//   x = U_r diag(1/lambda_r) U_r^H b   with the reference's cut on sigma = sqrt(lambda)
+// (pinv_svd, reference draco/analysis/mapmaker.py:287-300, applied to the Gram matrix of the tile).
+//
+// Instead of an eigenvector matrix the decomposition is kept in factored form,
+//   G = Q T Q^H   (Householder tridiagonalisation, reflectors stored in the dead rows of G)
+//   T = S L S^T   (implicit-shift QL on the real tridiagonal matrix, plane rotations logged),
+// and applied to the ONE right-hand side each tile has:  x = Q S f(L) S^T Q^H b.  Work per matrix is
+// O(n^3) flops once (the blocked Jacobi of dense_kernels.h spends ~50 n^3 per sweep) and O(n^2) memory traffic for
+// everything after the reduction.
+//
+// Kernels (all batched over the selected matrices of a sub-batch):
+//   k_td_col    one block per matrix, per column j: finish w_{j-1}, form column j with the pending rank-2
+//               update, generate the Householder reflector (the zlarfg rule)
+//   k_td_trail  one pass over the trailing matrix per column: apply the pending rank-2 update of step j-1
+//               and form A v_j in the same sweep (HBM bound: 32 bytes per trailing element and column)
+//   k_td_solve  one block per matrix: b, Q^H b, QL with the rotations applied forward to the vector and logged,
+//               the cut, the logged rotations backwards, Q y, output
+#ifndef DMM_HERM_TRIDIAG_H
+#define DMM_HERM_TRIDIAG_H
+
+namespace {
+
+constexpr int kTdRows = 32;       // rows of the trailing matrix per block of k_td_trail (4 waves x 8)
+constexpr int kTdVecSlots = 6;    // per matrix: vprev, wprev, vcur, praw, tau, (d | e)
+constexpr int kTdMaxIter = 60;    // QL iterations per eigenvalue before giving up
+
+struct TdParams {
+  DenseParams d;
+  double2* vec;        // [slot][kTdVecSlots][Np]
+  double2* log_cs;     // rotation log of matrix slot s: log_cs + s * log_stride, then its chase headers
+  int64_t log_stride;  // double2 units per matrix slot
+  int log_cap;         // rotations per matrix
+  int run_cap;         // chases (QL iterations) per matrix: 3 ints each behind the rotations
+  int j;               // current column
+  double acond, rcond;
+  int* fail;           // [nsel] set when QL does not converge or the log overflows
+};
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // a * conj(b)
+  return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// sum of a complex value over the 256 threads of a block (red: >= 8 doubles of LDS)
+__device__ __forceinline__ double2 block_sum2(double2 v, double* red) {
+  v.x = wave_sum(v.x);
+  v.y = wave_sum(v.y);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * w] = v.x;
+    red[2 * w + 1] = v.y;
+  }
+  __syncthreads();
+  return make_double2(red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7]);
+}
+
+__global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
+  extern __shared__ __align__(16) unsigned char smem_td[];
+  __shared__ double red[8];
+  __shared__ double2 s_tau, s_scale;
+  const DenseParams& p = tp.d;
+  const int n = p.Np, j = tp.j;
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  double2* A = p.A + (int64_t)mat * n * n;
+  double2* vb = tp.vec + (int64_t)mat * kTdVecSlots * n;
+  double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n, *praw = vb + 3 * n, *tau = vb + 4 * n;
+  double* dd = reinterpret_cast<double*>(vb + 5 * n);
+  double* ee = dd + n;
+  double2* sv = reinterpret_cast<double2*>(smem_td);
+  double2* sw = sv + n;
+  double2* sa = sw + n;
+
+  // ---- finish step j-1: w = p - (conj(tau)/2) (v^H p) v,  p = tau A v
+  if (j >= 1) {
+    const double2 t = tau[j - 1];
+    double2 g = make_double2(0.0, 0.0);
+    for (int i = j + threadIdx.x; i < n; i += kThreads) {
+      const double2 v = vcur[i], pi = cmul(t, praw[i]);
+      sv[i] = v;
+      sw[i] = pi;
+      const double2 q = cmulc(pi, v);  // conj(v) p
+      g.x += q.x;
+      g.y += q.y;
+    }
+    g = block_sum2(g, red);
+    const double2 coef = cmul(make_double2(0.5 * t.x, -0.5 * t.y), g);
+    for (int i = j + threadIdx.x; i < n; i += kThreads) {
+      const double2 v = sv[i], c = cmul(coef, v);
+      const double2 w = make_double2(sw[i].x - c.x, sw[i].y - c.y);
+      sw[i] = w;
+      vprev[i] = v;
+      wprev[i] = w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+      sv[i] = sw[i] = make_double2(0.0, 0.0);
+      vprev[i] = wprev[i] = make_double2(0.0, 0.0);
+    }
+  }
+  __syncthreads();
+  // ---- column j with the pending update: a_i = conj(A[j][i]) - v_i conj(w_j) - w_i conj(v_j)
+  const double2 wj = sw[j], vj = sv[j];
+  double2 xn = make_double2(0.0, 0.0);
+  for (int i = j + threadIdx.x; i < n; i += kThreads) {
+    const double2 r = A[(int64_t)j * n + i];
+    const double2 u1 = cmulc(sv[i], wj), u2 = cmulc(sw[i], vj);
+    const double2 a = make_double2(r.x - u1.x - u2.x, -r.y - u1.y - u2.y);
+    sa[i] = a;
+    if (i >= j + 2) xn.x += a.x * a.x + a.y * a.y;
+  }
+  xn = block_sum2(xn, red);  // (also orders the sa[] writes before the reads below)
+  if (threadIdx.x == 0) dd[j] = sa[j].x;
+  if (j >= n - 1) return;
+  if (threadIdx.x == 0) {
+    const double2 alpha = sa[j + 1];
+    double2 t = make_double2(0.0, 0.0), sc = make_double2(0.0, 0.0);
+    double beta = alpha.x;
+    if (xn.x != 0.0 || alpha.y != 0.0) {
+      const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn.x);
+      beta = alpha.x >= 0.0 ? -nrm : nrm;
+      t = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
+      const double2 dn = make_double2(alpha.x - beta, alpha.y);  // v = x / (alpha - beta)
+      const double q = 1.0 / (dn.x * dn.x + dn.y * dn.y);
+      sc = make_double2(dn.x * q, -dn.y * q);
+    }
+    s_tau = t;
+    s_scale = sc;
+    tau[j] = t;
+    ee[j] = beta;
+  }
+  __syncthreads();
+  const double2 sc = s_scale;
+  for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) {
+    double2 v = make_double2(1.0, 0.0);
+    if (i >= j + 2) {
+      v = cmul(sa[i], sc);
+      A[(int64_t)j * n + i] = v;  // row j is dead from here on: it keeps the reflector
+    }
+    vcur[i] = v;
+  }
+}
+
+// rows [j+1, n) x columns [j+1, n):  A -= vp wp^H + wp vp^H (step j-1),  praw = A v (step j)
+__global__ __launch_bounds__(kThreads) void k_td_trail(TdParams tp) {
+  extern __shared__ __align__(16) unsigned char smem_td[];
+  const DenseParams& p = tp.d;
+  const int n = p.Np, c0 = tp.j + 1, L = n - c0;
+  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
+  double2* A = p.A + (int64_t)mat * n * n;
+  double2* vb = tp.vec + (int64_t)mat * kTdVecSlots * n;
+  const double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n;
+  double2* praw = vb + 3 * n;
+  double2* cvp = reinterpret_cast<double2*>(smem_td);  // conj(vprev), conj(wprev), vcur on the trailing columns
+  double2* cwp = cvp + L;
+  double2* vv = cwp + L;
+  for (int c = threadIdx.x; c < L; c += kThreads) {
+    const double2 a = vprev[c0 + c], b = wprev[c0 + c];
+    cvp[c] = make_double2(a.x, -a.y);
+    cwp[c] = make_double2(b.x, -b.y);
+    vv[c] = vcur[c0 + c];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rbase = c0 + blockIdx.x * kTdRows + wave * (kTdRows / 4);
+#pragma unroll 1
+  for (int g = 0; g < kTdRows / 4; g += 4) {
+    const int r0 = rbase + g;
+    if (r0 >= n) break;
+    double2 vpi[4], wpi[4], acc[4];
+    double2* row[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + k < n ? r0 + k : n - 1;  // (clamped duplicates are not stored)
+      vpi[k] = vprev[r];
+      wpi[k] = wprev[r];
+      row[k] = A + (int64_t)r * n + c0;
+      acc[k] = make_double2(0.0, 0.0);
+    }
+    for (int c = lane; c < L; c += 64) {
+      const double2 cw = cwp[c], cv = cvp[c], v = vv[c];
+      double2 a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = row[k][c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k].x -= vpi[k].x * cw.x - vpi[k].y * cw.y + wpi[k].x * cv.x - wpi[k].y * cv.y;
+        a[k].y -= vpi[k].x * cw.y + vpi[k].y * cw.x + wpi[k].x * cv.y + wpi[k].y * cv.x;
+        acc[k].x += a[k].x * v.x - a[k].y * v.y;
+        acc[k].y += a[k].x * v.y + a[k].y * v.x;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r0 + k < n) row[k][c] = a[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double sx = wave_sum(acc[k].x), sy = wave_sum(acc[k].y);
+      if (lane == 0 && r0 + k < n) praw[r0 + k] = make_double2(sx, sy);
+    }
+  }
+}
+
+// Apply the logged chases of one matrix to the vector b (LDS) with wave 0.  Chase r: rotations on the index pairs
+// (i, i+1), i = m-1 down to m-len, at log positions pos .. pos+len-1.  BACKWARD = false: generation order (row
+// vector times S); true: reverse order (S times column vector).
+template <bool BACKWARD>
+__device__ __forceinline__ void td_replay(double2* b, const double2* lcs, const int* lrun, int nrun) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  constexpr int P = 8;  // log entries in flight per lane
+  for (int g0 = 0; g0 < nrun; g0 += 64) {
+    // forward: lane t <-> chase g0 + t; backward: the groups and the lanes within a group run last chase first
+    const int r = BACKWARD ? nrun - 1 - g0 - lane : g0 + lane;
+    const bool have = BACKWARD ? r >= 0 : r < nrun;
+    int m = 0, len = 0, pos = 0;
+    if (have) {
+      m = lrun[3 * r];
+      len = lrun[3 * r + 1];
+      pos = lrun[3 * r + 2];
+    }
+    const int lo = m - len;  // indices lo .. m-1
+    int top = have ? m - 1 : -1, bot = have ? lo : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      top = max(top, __shfl_xor(top, o));
+      bot = min(bot, __shfl_xor(bot, o));
+    }
+    const int nstep = top - bot + 1 + 2 * 63;
+    // step tau: forward  i = top - tau + 2 lane (descending);  backward  i = bot + tau - 2 lane (ascending)
+    auto index_at = [&](int tau) { return BACKWARD ? bot + tau - 2 * lane : top - tau + 2 * lane; };
+    auto fetch = [&](int tau) {
+      const int i = index_at(tau);
+      double2 cs = make_double2(1.0, 0.0);
+      if (have && i >= lo && i < m) cs = lcs[pos + (m - 1 - i)];
+      return cs;
+    };
+    double2 ring[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) ring[u] = fetch(u);
+    for (int t0 = 0; t0 < nstep; t0 += P) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int tau = t0 + u;
+        const double2 cs = ring[u];
+        ring[u] = fetch(tau + P);
+        const int i = index_at(tau);
+        if (have && i >= lo && i < m && tau < nstep) {
+          const double2 x = b[i], y = b[i + 1];
+          if (BACKWARD) {
+            b[i] = make_double2(cs.x * x.x + cs.y * y.x, cs.x * x.y + cs.y * y.y);
+            b[i + 1] = make_double2(cs.x * y.x - cs.y * x.x, cs.x * y.y - cs.y * x.y);
+          } else {
+            b[i + 1] = make_double2(cs.y * x.x + cs.x * y.x, cs.y * x.y + cs.x * y.y);
+            b[i] = make_double2(cs.x * x.x - cs.y * y.x, cs.x * x.y - cs.y * y.y);
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
+  extern __shared__ __align__(16) unsigned char smem_td[];
+  __shared__ double red[8];
+  __shared__ int s_nrot, s_fail;
+  const DenseParams& p = tp.d;
+  const int n = p.Np;
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  const double2* A = p.A + (int64_t)mat * n * n;
+  const double2* vb = tp.vec + (int64_t)mat * kTdVecSlots * n;
+  const double2* tau = vb + 4 * n;
+  const double* dd = reinterpret_cast<const double*>(vb + 5 * n);
+  const double* ee = dd + n;
+  double2* lcs = tp.log_cs + (int64_t)mat * tp.log_stride;
+  int* lrun = reinterpret_cast<int*>(lcs + tp.log_cap);
+  double2* b = reinterpret_cast<double2*>(smem_td);       // [n] the vector, transformed in place
+  double* dl = reinterpret_cast<double*>(b + n);          // [n]
+  double* el = dl + n;                                    // [n]
+  const int Lsky = p.lmax + 1 - tile.m, N = order_of(p, tile);
+
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    double2 v = make_double2(0.0, 0.0);
+    if (i < N) {
+      if (p.sky) {
+        const int pol = i / Lsky, lrel = i - pol * Lsky;
+        v = p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel];
+      } else {
+        const int s = i >= p.npairs, pp = i - s * p.npairs;
+        const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
+        const double d = sqrt(p.mweight[o]);
+        const double2 x = p.mvis[o];
+        v = make_double2(d * x.x, d * x.y);
+      }
+    }
+    b[i] = v;
+    dl[i] = dd[i];
+    el[i] = i < n - 1 ? ee[i] : 0.0;
+  }
+  if (threadIdx.x == 0) s_nrot = s_fail = 0;
+  __syncthreads();
+  // ---- z = Q^H b = H_{n-2}^H ... H_0^H b,  H_j = I - tau_j v_j v_j^H,  v_j = (0.., 1 at j+1, row j of A beyond)
+  for (int j = 0; j < n - 1; ++j) {
+    const double2 t = tau[j];
+    if (t.x == 0.0 && t.y == 0.0) continue;  // (uniform over the block)
+    double2 s = make_double2(0.0, 0.0);
+    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) {
+      const double2 v = i == j + 1 ? make_double2(1.0, 0.0) : A[(int64_t)j * n + i];
+      const double2 q = cmulc(b[i], v);  // conj(v) b
+      s.x += q.x;
+      s.y += q.y;
+    }
+    s = block_sum2(s, red);
+    const double2 f = cmul(make_double2(t.x, -t.y), s);
+    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) {
+      const double2 v = i == j + 1 ? make_double2(1.0, 0.0) : A[(int64_t)j * n + i];
+      const double2 u = cmul(f, v);
+      b[i] = make_double2(b[i].x - u.x, b[i].y - u.y);
+    }
+    __syncthreads();
+  }
+  // ---- implicit-shift QL on (dl, el).  One lane runs the (inherently serial) bulge chases and logs every rotation
+  // (c, s) plus one header (l, m, first log position) per chase; the vector is not touched here.
+  if (threadIdx.x < 64) {  // wave 0: all lanes search for the split point, lane 0 chases the bulge
+    const int lane = threadIdx.x;
+    int nrot = 0, nrun = 0, fail = 0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n && !fail; ++l) {
+      int iter = 0;
+      while (true) {
+        int m = n - 1;  // first m >= l whose sub-diagonal is negligible
+        for (int base = l; base < n - 1; base += 64) {
+          const int k = base + lane;
+          const bool small = k < n - 1 && fabs(el[k]) <= eps * (fabs(dl[k]) + fabs(dl[k + 1]));
+          const unsigned long long mask = __ballot(small);
+          if (mask) {
+            m = base + __ffsll((long long)mask) - 1;
+            break;
+          }
+        }
+        if (m == l) break;
+        if (++iter > kTdMaxIter || nrot + (m - l) > tp.log_cap || nrun >= tp.run_cap) {
+          fail = 1;
+          break;
+        }
+        int done = 0, under = 0;
+        if (lane == 0) {
+          double g = (dl[l + 1] - dl[l]) / (2.0 * el[l]);
+          double r = sqrt(g * g + 1.0);
+          g = dl[m] - dl[l] + el[l] / (g + (g >= 0.0 ? r : -r));
+          double s = 1.0, c = 1.0, pp = 0.0;
+          int i = m - 1;
+          // operands of the chase are fetched one step ahead of the dependent chain
+          double e_n = el[i], d_n = dl[i], d_hi = dl[i + 1];
+          double2* out = lcs + nrot;
+          for (; i >= l; --i) {
+            const double e_i = e_n, d_i = d_n;
+            const int ip = i > 0 ? i - 1 : 0;
+            e_n = el[ip];
+            d_n = dl[ip];
+            const double f = s * e_i, bb = c * e_i;
+            const double h = f * f + g * g;
+            if (h == 0.0) {  // recover from underflow
+              el[i + 1] = 0.0;
+              dl[i + 1] = d_hi - pp;
+              el[m] = 0.0;
+              under = 1;
+              break;
+            }
+            double ri = __builtin_amdgcn_rsq(h);  // ~2^-26 seed, two Newton steps
+            ri = ri * (1.5 - 0.5 * h * ri * ri);
+            ri = ri * (1.5 - 0.5 * h * ri * ri);
+            el[i + 1] = h * ri;
+            s = f * ri;
+            c = g * ri;
+            g = d_hi - pp;
+            r = (d_i - g) * s + 2.0 * c * bb;
+            pp = s * r;
+            dl[i + 1] = g + pp;
+            g = c * r - bb;
+            d_hi = d_i;
+            out[done++] = make_double2(c, s);
+          }
+          if (!under) {
+            dl[l] -= pp;
+            el[l] = g;
+            el[m] = 0.0;
+          }
+          if (done) {  // rotations i = m-1 .. m-done of this chase
+            lrun[3 * nrun] = m;
+            lrun[3 * nrun + 1] = done;
+            lrun[3 * nrun + 2] = nrot;
+          }
+        }
+        done = __shfl(done, 0);
+        nrot += done;
+        nrun += done ? 1 : 0;
+      }
+    }
+    if (lane == 0) {
+      s_nrot = nrun;
+      s_fail = fail;
+    }
+  }
+  __syncthreads();
+  if (s_fail) {
+    if (threadIdx.x == 0) tp.fail[blockIdx.x] = 1;
+    return;
+  }
+  // ---- t = S^T z: the chases in order, each a chain of rotations on descending index pairs (i, i+1).  A chase may
+  // start index i once its predecessor is done with i-1, so 64 chases run as a systolic pipeline over the lanes of
+  // wave 0, lane t two indices behind lane t-1:  (q R)_{i+1} = s q_i + c q_{i+1},  (q R)_i = c q_i - s q_{i+1}.
+  td_replay<false>(b, lcs, lrun, s_nrot);
+  __syncthreads();
+  // ---- the reference's cut on sigma = sqrt(lambda) (mapmaker.py:296), g = f(L) S^T z
+  {
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) mx = fmax(mx, dl[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const double smax = sqrt(fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), 0.0));
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+      const double lam = dl[i], sig = sqrt(fmax(lam, 0.0));
+      double2 v = make_double2(0.0, 0.0);
+      if (sig > tp.rcond * smax && sig > tp.acond) v = make_double2(b[i].x / lam, b[i].y / lam);
+      b[i] = v;
+    }
+  }
+  __syncthreads();
+  // ---- y = S g: the chases in reverse order, ascending index pairs, same pipeline:
+  // (R y)_i = c y_i + s y_{i+1},  (R y)_{i+1} = -s y_i + c y_{i+1}
+  td_replay<true>(b, lcs, lrun, s_nrot);
+  __syncthreads();
+  // ---- x = Q y = H_0 (H_1 (... H_{n-2} y))
+  for (int j = n - 2; j >= 0; --j) {
+    const double2 t = tau[j];
+    if (t.x == 0.0 && t.y == 0.0) continue;
+    double2 s = make_double2(0.0, 0.0);
+    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) {
+      const double2 v = i == j + 1 ? make_double2(1.0, 0.0) : A[(int64_t)j * n + i];
+      const double2 q = cmulc(b[i], v);
+      s.x += q.x;
+      s.y += q.y;
+    }
+    s = block_sum2(s, red);
+    const double2 f = cmul(t, s);
+    for (int i = j + 1 + threadIdx.x; i < n; i += kThreads) {
+      const double2 v = i == j + 1 ? make_double2(1.0, 0.0) : A[(int64_t)j * n + i];
+      const double2 u = cmul(f, v);
+      b[i] = make_double2(b[i].x - u.x, b[i].y - u.y);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    const double2 acc = b[i];
+    if (p.sky) {
+      const int pol = i / Lsky, lrel = i - pol * Lsky;
+      p.alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * (p.lmax + 1) + tile.m + lrel] = acc;
+    } else {
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+      p.wbuf[(int64_t)mat * p.N + i] = make_double2(d * acc.x, d * acc.y);
+    }
+  }
+}
+
+}  // namespace
+#endif

@@ -35,6 +35,7 @@
 // The complex products run on v_mfma_f64_16x16x4_f64 through the real embedding
 //   Re = [Xr Xi].[Yr Yi]^T,  Im = [Xr Xi].[-Yi Yr]^T   (4 real k per 2 complex k).
 #include "dense_kernels.h"
+#include "herm_tridiag.h"
 
 namespace {
 
@@ -211,13 +212,16 @@ struct Layout {
   size_t header;    // Sl table
 };
 
-Layout layout_of(const dmm_plan* pl, bool ml) {
+// aux_slots: matrix-sized regions behind A: 1 = Wiener (X / Cholesky copy), 2 = ML (also the rotation log of the
+// tridiagonal eigen path, herm_tridiag.h); 0 = only the inverted diagonal blocks
+Layout layout_of(const dmm_plan* pl, int aux_slots) {
+  const bool ml = aux_slots > 0;
   Layout L;
   L.N = 2 * pl->npairs;
   L.Np = (L.N + TB - 1) / TB * TB;
   L.T = L.Np / TB;
   const size_t a = (size_t)L.Np * L.Np * sizeof(double2);
-  const size_t aux = ml ? a : (size_t)L.T * TB * TB * sizeof(double2);
+  const size_t aux = ml ? (size_t)aux_slots * a : (size_t)L.T * TB * TB * sizeof(double2);
   L.per_mat = a + aux + (size_t)L.N * sizeof(double2);
   L.per_mat_extra = ml ? (size_t)(L.Np / 64) * TB * TB * sizeof(double2) + (size_t)(L.Np / 64) * sizeof(int) + 32 + 64 : 0;  // + theta, tile, work, fail, msel
   L.header = ((size_t)(pl->lmax + 1) * sizeof(double) + 255) / 256 * 256;
@@ -226,9 +230,9 @@ Layout layout_of(const dmm_plan* pl, bool ml) {
 
 constexpr size_t kTargetWs = (size_t)6 << 30;  // ~6 GiB of matrices in flight per sub-batch
 
-int64_t workspace_bytes(const dmm_plan* pl, bool ml) {
+int64_t workspace_bytes(const dmm_plan* pl, int aux_slots) {
   if (!pl) return 0;
-  const Layout L = layout_of(pl, ml);
+  const Layout L = layout_of(pl, aux_slots);
   size_t nmat = kTargetWs / (L.per_mat + L.per_mat_extra);
   if (nmat < 1) nmat = 1;
   if (nmat > (size_t)pl->ntile) nmat = pl->ntile > 0 ? pl->ntile : 1;
@@ -284,8 +288,8 @@ int dmm_dirty_w_launch_list(dmm_plan* pl, const void* B, const double2* wbuf, co
 extern "C" {
 
 // (the Wiener solve stages the sky-side operand like ML does: same workspace layout)
-int64_t dmm_wiener_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, true); }
-int64_t dmm_ml_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, true); }
+int64_t dmm_wiener_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, 1); }
+int64_t dmm_ml_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, 2); }
 
 int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, double prior_amp,
                    double prior_tilt, void* workspace, void* alm) {
@@ -294,7 +298,7 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   if (pl->ntile == 0) return DMM_OK;
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
-  const Layout L = layout_of(pl, true);
+  const Layout L = layout_of(pl, 1);
   const int64_t wsb = dmm_wiener_workspace_bytes(pl);
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
@@ -398,7 +402,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   if (pl->ntile == 0) return DMM_OK;
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
-  const Layout L = layout_of(pl, true);  // telescope-side order: the largest any batch uses
+  const Layout L = layout_of(pl, 2);  // telescope-side order: the largest any batch uses
   const int64_t wsb = dmm_ml_workspace_bytes(pl);
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
@@ -451,10 +455,18 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
   DMM_HIP(hipFuncSetAttribute((const void*)k_bj_sub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sub_lds));
   DMM_HIP(hipFuncSetAttribute((const void*)k_ml_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fil_lds));
+  {
+    const size_t td_vec = (size_t)3 * L.Np * sizeof(double2);
+    const size_t td_sol = (size_t)L.Np * (sizeof(double2) + 2 * sizeof(double));
+    DMM_REQUIRE(td_vec <= 160 * 1024 && td_sol <= 160 * 1024, "dmm_ml_run: matrix order %d too large for the LDS", L.Np);
+    DMM_HIP(hipFuncSetAttribute((const void*)k_td_col, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_vec));
+    DMM_HIP(hipFuncSetAttribute((const void*)k_td_trail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_vec));
+    DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
+  }
 
   std::vector<dmm_tile> tiles_c;
   std::vector<int32_t> work_c;
-  std::vector<int> fail_h, msel_h;
+  std::vector<int> fail_h, msel_h, td_fail_h;
   // tiles whose certificate failed, collected over all batches so that the (launch-latency bound)
   // eigen path runs on well filled batches at the end
   std::vector<int64_t> tel_deferred;
@@ -485,12 +497,17 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     if (sky) {
       p.ldx = ntel;
       p.X = Vbuf;
-      hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf);
-      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
-    } else {
-      hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
     }
-    hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
+    auto form_gram = [&]() {
+      if (sky) {
+        hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf);
+        hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+      } else {
+        hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+      }
+      hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
+    };
+    form_gram();
     DMM_HIP(hipGetLastError());
     fail_h.assign(nmat, 1);
     if (shortcut && !eigen_only) {
@@ -532,6 +549,42 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       const int nsel = (int)msel_h.size();
       DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
+      bool solved = false;
+      if (ctx->opt_ml_eigen == 0) {  // tridiagonalisation + QL in factored form (herm_tridiag.h)
+        const int n = p.Np;
+        TdParams tp;
+        tp.d = p;
+        tp.d.msel = msel_d;
+        tp.vec = Whbuf;
+        tp.log_cs = Vbuf;
+        tp.log_stride = (int64_t)2 * L.Np * L.Np;
+        tp.run_cap = 16 * n;  // (a chase per QL iteration: ~1.7 n in practice)
+        tp.log_cap = (int)std::min<int64_t>(tp.log_stride - ((int64_t)3 * tp.run_cap * sizeof(int) + 15) / 16, 0x7fffffff);
+        tp.acond = acond;
+        tp.rcond = rcond;
+        tp.fail = fail_d;
+        DMM_HIP(hipMemsetAsync(fail_d, 0, nsel * sizeof(int), ctx->stream));
+        const size_t col_lds = (size_t)3 * n * sizeof(double2);
+        const size_t sol_lds = (size_t)n * (sizeof(double2) + 2 * sizeof(double));
+        for (int j = 0; j < n; ++j) {
+          tp.j = j;
+          hipLaunchKernelGGL(k_td_col, dim3(nsel), dim3(kThreads), col_lds, ctx->stream, tp);
+          if (j < n - 1)
+            hipLaunchKernelGGL(k_td_trail, dim3((n - j - 1 + kTdRows - 1) / kTdRows, nsel), dim3(kThreads),
+                               (size_t)3 * (n - j - 1) * sizeof(double2), ctx->stream, tp);
+        }
+        hipLaunchKernelGGL(k_td_solve, dim3(nsel), dim3(kThreads), sol_lds, ctx->stream, tp);
+        DMM_HIP(hipGetLastError());
+        td_fail_h.assign(nsel, 0);
+        DMM_HIP(hipMemcpyAsync(td_fail_h.data(), fail_d, nsel * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DMM_HIP(hipStreamSynchronize(ctx->stream));
+        solved = true;
+        for (int f : td_fail_h) solved = solved && !f;
+        if (!solved) form_gram();  // QL stalled or its log overflowed (not seen in practice): Jacobi on the batch
+      }
+      if (solved) {
+        // nothing left to do
+      } else {
       JacobiParams jp;
       jp.d = p;
       jp.d.msel = msel_d;
@@ -556,7 +609,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         DMM_HIP(hipMemsetAsync(any_rot_d, 0, sizeof(int), ctx->stream));
         for (int round = 0; round < bp.nb - 1; ++round) {
           bp.round = round;
-          hipLaunchKernelGGL(k_bj_sub, dim3(npr, nsel), dim3(kThreads), sub_lds, ctx->stream, bp);
+          hipLaunchKernelGGL(k_bj_sub, dim3(npr, nsel), dim3(kSubThreads), sub_lds, ctx->stream, bp);
           bp.target = 0;
           hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nsel), dim3(kThreads), 0, ctx->stream, bp);
           bp.target = 2;
@@ -574,6 +627,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       }
       hipLaunchKernelGGL(k_ml_filter, dim3(nsel), dim3(kThreads), fil_lds, ctx->stream, jp);
       DMM_HIP(hipGetLastError());
+      }
     }
     if (!sky) {
       int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_d, work_d, nmat, work_c[nmat], alm);

@@ -218,7 +218,7 @@ int dmm_mmode_svd(dmm_ctx* ctx, void* mvis, const double* mweight, int n_m, int 
         DMM_HIP(hipMemsetAsync(any_rot_d, 0, sizeof(int), ctx->stream));
         for (int round = 0; round < bp.nb - 1; ++round) {
           bp.round = round;
-          hipLaunchKernelGGL(k_bj_sub, dim3(npr, nmat), dim3(kThreads), sub_lds, ctx->stream, bp);
+          hipLaunchKernelGGL(k_bj_sub, dim3(npr, nmat), dim3(kSubThreads), sub_lds, ctx->stream, bp);
           bp.target = 0;
           hipLaunchKernelGGL(k_bj_apply, dim3(T, npr, nmat), dim3(kThreads), 0, ctx->stream, bp);
           bp.target = 2;
