@@ -22,17 +22,20 @@
 namespace {
 
 constexpr int kTdRows = 32;       // rows of the trailing matrix per block of k_td_trail (4 waves x 8)
-constexpr int kTdVecSlots = 6;    // per matrix: vprev, wprev, vcur, praw, tau, (d | e)
+constexpr int kTdVecSlots = 6;    // per matrix: vprev, wprev, vcur, praw, tau, (d | e); then one column-partial vector per row block
 constexpr int kTdMaxIter = 60;    // QL iterations per eigenvalue before giving up
+
+__host__ __device__ constexpr int td_slots(int n) { return kTdVecSlots + n / kTdRows; }
 
 struct TdParams {
   DenseParams d;
-  double2* vec;        // [slot][kTdVecSlots][Np]
+  double2* vec;        // [slot][kTdVecSlots + Np / kTdRows][Np]
   double2* log_cs;     // rotation log of matrix slot s: log_cs + s * log_stride, then its chase headers
   int64_t log_stride;  // double2 units per matrix slot
   int log_cap;         // rotations per matrix
   int run_cap;         // chases (QL iterations) per matrix: 3 ints each behind the rotations
   int j;               // current column
+  int tri;             // 1: the trailing matrix lives in its upper triangle only (k_td_trail_tri)
   double acond, rcond;
   int* fail;           // [nsel] set when QL does not converge or the log overflows
 };
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
   const int n = p.Np, j = tp.j;
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
   double2* A = p.A + (int64_t)mat * n * n;
-  double2* vb = tp.vec + (int64_t)mat * kTdVecSlots * n;
+  double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
   double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n, *praw = vb + 3 * n, *tau = vb + 4 * n;
   double* dd = reinterpret_cast<double*>(vb + 5 * n);
   double* ee = dd + n;
@@ -83,7 +86,17 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
     const double2 t = tau[j - 1];
     double2 g = make_double2(0.0, 0.0);
     for (int i = j + threadIdx.x; i < n; i += kThreads) {
-      const double2 v = vcur[i], pi = cmul(t, praw[i]);
+      double2 pr = praw[i];
+      if (tp.tri) {  // + the transposed contributions conj(a_ri) v_r of the rows r < i, one partial per row block
+        const double2* cp = vb + (int64_t)kTdVecSlots * n + i;
+        const int nblk = (i - j) / kTdRows;
+        for (int blk = 0; blk <= nblk; ++blk) {
+          const double2 q = cp[(int64_t)blk * n];
+          pr.x += q.x;
+          pr.y += q.y;
+        }
+      }
+      const double2 v = vcur[i], pi = cmul(t, pr);
       sv[i] = v;
       sw[i] = pi;
       const double2 q = cmulc(pi, v);  // conj(v) p
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_td_trail(TdParams tp) {
   const int n = p.Np, c0 = tp.j + 1, L = n - c0;
   const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
   double2* A = p.A + (int64_t)mat * n * n;
-  double2* vb = tp.vec + (int64_t)mat * kTdVecSlots * n;
+  double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
   const double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n;
   double2* praw = vb + 3 * n;
   double2* cvp = reinterpret_cast<double2*>(smem_td);  // conj(vprev), conj(wprev), vcur on the trailing columns
@@ -205,6 +218,97 @@ __global__ __launch_bounds__(kThreads) void k_td_trail(TdParams tp) {
       const double sx = wave_sum(acc[k].x), sy = wave_sum(acc[k].y);
       if (lane == 0 && r0 + k < n) praw[r0 + k] = make_double2(sx, sy);
     }
+  }
+}
+
+// Upper-triangle variant of k_td_trail: only A[r][c], c >= r, is kept (half the traffic).  Each element serves the
+// row product a_rc v_c and, for c > r, the transposed one conj(a_rc) v_r.  Wave w owns the 64-column chunks
+// w, w+4, ... of the block's column range for ALL of its rows: the per-column operands and the transposed sums
+// stay in that wave's registers (no cross-wave reduction, this row block's partial vector is written straight from
+// them); the four waves' pieces of a row sum meet in LDS.
+template <int KK, int RI = (KK <= 3 ? 4 : 2)>  // RI rows in flight per wave
+__global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
+  __shared__ double2 s_vp[kTdRows], s_wp[kTdRows], s_vr[kTdRows];
+  __shared__ double2 s_row[4][kTdRows];
+  const DenseParams& p = tp.d;
+  const int n = p.Np, c0 = tp.j + 1;
+  const int r0 = c0 + blockIdx.x * kTdRows, Lb = n - r0;
+  const int nrows = Lb < kTdRows ? Lb : kTdRows;
+  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
+  double2* A = p.A + (int64_t)mat * n * n;
+  double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
+  const double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n;
+  double2* praw = vb + 3 * n;
+  double2* colpart = vb + (int64_t)(kTdVecSlots + blockIdx.x) * n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < nrows) {
+    s_vp[threadIdx.x] = vprev[r0 + threadIdx.x];
+    s_wp[threadIdx.x] = wprev[r0 + threadIdx.x];
+    s_vr[threadIdx.x] = vcur[r0 + threadIdx.x];
+  }
+  double2 cw[KK], cv[KK], v[KK], col[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int cb = (wave + 4 * kk) * 64 + lane;
+    cw[kk] = cv[kk] = v[kk] = col[kk] = make_double2(0.0, 0.0);
+    if (cb < Lb) {
+      const double2 a = vprev[r0 + cb], b = wprev[r0 + cb];
+      cv[kk] = make_double2(a.x, -a.y);
+      cw[kk] = make_double2(b.x, -b.y);
+      v[kk] = vcur[r0 + cb];
+    }
+  }
+  __syncthreads();
+  for (int d0 = 0; d0 < nrows; d0 += RI) {
+    double2 a[RI][KK], acc[RI];
+    double2* row[RI];
+#pragma unroll
+    for (int q = 0; q < RI; ++q) {
+      const int d = d0 + q < nrows ? d0 + q : nrows - 1;
+      row[q] = A + (int64_t)(r0 + d) * n + r0;
+      acc[q] = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const int cb = (wave + 4 * kk) * 64 + lane;
+        if (d0 + q < nrows && cb < Lb && cb >= d0 + q) a[q][kk] = row[q][cb];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RI; ++q) {
+      const int d = d0 + q;
+      if (d < nrows) {
+        const double2 vpi = s_vp[d], wpi = s_wp[d], vr = s_vr[d];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          const int cb = (wave + 4 * kk) * 64 + lane;
+          if (cb < Lb && cb >= d) {
+            double2 x = a[q][kk];
+            x.x -= vpi.x * cw[kk].x - vpi.y * cw[kk].y + wpi.x * cv[kk].x - wpi.y * cv[kk].y;
+            x.y -= vpi.x * cw[kk].y + vpi.y * cw[kk].x + wpi.x * cv[kk].y + wpi.y * cv[kk].x;
+            row[q][cb] = x;
+            acc[q].x += x.x * v[kk].x - x.y * v[kk].y;
+            acc[q].y += x.x * v[kk].y + x.y * v[kk].x;
+            if (cb > d) {  // conj(a) v_r
+              col[kk].x += x.x * vr.x + x.y * vr.y;
+              col[kk].y += x.x * vr.y - x.y * vr.x;
+            }
+          }
+        }
+        const double sx = wave_sum(acc[q].x), sy = wave_sum(acc[q].y);
+        if (lane == 0) s_row[wave][d] = make_double2(sx, sy);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nrows) {
+    const int t = threadIdx.x;
+    praw[r0 + t] = make_double2(s_row[0][t].x + s_row[1][t].x + s_row[2][t].x + s_row[3][t].x,
+                                s_row[0][t].y + s_row[1][t].y + s_row[2][t].y + s_row[3][t].y);
+  }
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int cb = (wave + 4 * kk) * 64 + lane;
+    if (cb < Lb) colpart[r0 + cb] = col[kk];
   }
 }
 
@@ -276,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   const double2* A = p.A + (int64_t)mat * n * n;
-  const double2* vb = tp.vec + (int64_t)mat * kTdVecSlots * n;
+  const double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
   const double2* tau = vb + 4 * n;
   const double* dd = reinterpret_cast<const double*>(vb + 5 * n);
   const double* ee = dd + n;

@@ -228,12 +228,14 @@ Layout layout_of(const dmm_plan* pl, int aux_slots) {
   return L;
 }
 
-constexpr size_t kTargetWs = (size_t)6 << 30;  // ~6 GiB of matrices in flight per sub-batch
+// matrices in flight per sub-batch: ~6 GiB for the Wiener solve; the ML eigen path has a per-batch latency floor (the
+// serial QL chases, ~0.1 s at order 768 whatever the batch size), so its batches are made larger
+constexpr size_t kTargetWs = (size_t)6 << 30, kTargetWsMl = (size_t)20 << 30;
 
 int64_t workspace_bytes(const dmm_plan* pl, int aux_slots) {
   if (!pl) return 0;
   const Layout L = layout_of(pl, aux_slots);
-  size_t nmat = kTargetWs / (L.per_mat + L.per_mat_extra);
+  size_t nmat = (aux_slots >= 2 ? kTargetWsMl : kTargetWs) / (L.per_mat + L.per_mat_extra);
   if (nmat < 1) nmat = 1;
   if (nmat > (size_t)pl->ntile) nmat = pl->ntile > 0 ? pl->ntile : 1;
   return (int64_t)(L.header + nmat * (L.per_mat + L.per_mat_extra) + 1024);
@@ -550,7 +552,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
       bool solved = false;
-      if (ctx->opt_ml_eigen == 0) {  // tridiagonalisation + QL in factored form (herm_tridiag.h)
+      if (ctx->opt_ml_eigen != 1) {  // tridiagonalisation + QL in factored form (herm_tridiag.h)
         const int n = p.Np;
         TdParams tp;
         tp.d = p;
@@ -558,20 +560,30 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.vec = Whbuf;
         tp.log_cs = Vbuf;
         tp.log_stride = (int64_t)2 * L.Np * L.Np;
-        tp.run_cap = 16 * n;  // (a chase per QL iteration: ~1.7 n in practice)
+        tp.run_cap = ctx->opt_ml_eigen == 3 ? 0 : 16 * n;  // (a chase per QL iteration: ~1.7 n in practice; 3: force the fallback, tests)
         tp.log_cap = (int)std::min<int64_t>(tp.log_stride - ((int64_t)3 * tp.run_cap * sizeof(int) + 15) / 16, 0x7fffffff);
         tp.acond = acond;
         tp.rcond = rcond;
         tp.fail = fail_d;
+        tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         DMM_HIP(hipMemsetAsync(fail_d, 0, nsel * sizeof(int), ctx->stream));
         const size_t col_lds = (size_t)3 * n * sizeof(double2);
         const size_t sol_lds = (size_t)n * (sizeof(double2) + 2 * sizeof(double));
         for (int j = 0; j < n; ++j) {
           tp.j = j;
           hipLaunchKernelGGL(k_td_col, dim3(nsel), dim3(kThreads), col_lds, ctx->stream, tp);
-          if (j < n - 1)
-            hipLaunchKernelGGL(k_td_trail, dim3((n - j - 1 + kTdRows - 1) / kTdRows, nsel), dim3(kThreads),
-                               (size_t)3 * (n - j - 1) * sizeof(double2), ctx->stream, tp);
+          if (j < n - 1) {
+            const dim3 grid((n - j - 1 + kTdRows - 1) / kTdRows, nsel);
+            const size_t tri_lds = 0;
+            if (!tp.tri)
+              hipLaunchKernelGGL(k_td_trail, grid, dim3(kThreads), (size_t)3 * (n - j - 1) * sizeof(double2), ctx->stream, tp);
+            else if (n <= 768)
+              hipLaunchKernelGGL(k_td_trail_tri<3>, grid, dim3(kThreads), tri_lds, ctx->stream, tp);
+            else if (n <= 1536)
+              hipLaunchKernelGGL(k_td_trail_tri<6>, grid, dim3(kThreads), tri_lds, ctx->stream, tp);
+            else
+              hipLaunchKernelGGL(k_td_trail_tri<8>, grid, dim3(kThreads), tri_lds, ctx->stream, tp);
+          }
         }
         hipLaunchKernelGGL(k_td_solve, dim3(nsel), dim3(kThreads), sol_lds, ctx->stream, tp);
         DMM_HIP(hipGetLastError());

@@ -257,3 +257,51 @@ def test_dense_full_layout_matches_packed(kind):
             outs[dt, layout] = eng.solve(kind, mv, mw, [0, 1], lmax, **kw).cpu().numpy()
     for dt in (_lib.DMM_C128, _lib.DMM_C64):
         assert _rel(outs[dt, _lib.DMM_B_PACKED], outs[dt, _lib.DMM_B_FULL]) < 1e-12, dt
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_ml_eigen_path_variants(variant):
+    """The eigen path of ML (`ml_shortcut` = 2 sends every tile there) in all its implementations:
+    0 Householder tridiagonalisation (upper-triangle trailing updates) + QL in factored form, 1 blocked Jacobi,
+    2 as 0 with full-matrix trailing updates, 3 QL forced to give up -> Jacobi fallback on the re-formed Gram matrices.
+    Rank-deficient tiles, zero weights, telescope- and sky-side orders (64 ... 192) against the oracle's SVD."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import ArrayProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    nfreq, lmax = 2, 70
+    tel = _tel(nfreq, lmax, 2, 6)  # ntel = 134: padded order 192; sky side from m = 38
+    seed = 515
+
+    def beam(m, f):
+        b = osyn.beam_tile(seed, m, f, tel.npairs, 4, lmax).copy()
+        if f == 0 and m in (2, 45, 69):
+            b[0, 3] = b[0, 1]
+            b[:, :, 1, min(m + 1, lmax)] = 0.0
+        return b
+
+    bt = ArrayProvider(tel, beam)
+    rng = np.random.default_rng(10 + variant)
+    shape = (lmax + 1, 2, nfreq, tel.npairs)
+    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    mw = rng.uniform(0.5, 1.5, shape) * 10.0
+    mw[rng.uniform(size=shape) < 0.1] = 0.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    ref = omm.solve_alm("ml", beam, mv, mw, lmax, tel.mmax, list(range(nfreq)))
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", variant))
+        e0 = _counter(ctx, b"ml_tiles_eigen")
+        task = MaximumLikelihoodMapMaker()
+        task.setup(bt)
+        out = task.alm_square(task.make_alm(mm))
+        assert _counter(ctx, b"ml_tiles_eigen") - e0 == nfreq * (lmax + 1)
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+    assert _rel(out, ref) < 1e-8, variant
