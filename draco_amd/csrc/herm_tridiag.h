@@ -51,6 +51,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Sums of NV per-lane values over the 64 lanes with a reduce-scatter butterfly: every stage halves the number of
+// values a lane still carries, so NV sums cost NV - 1 + (6 - log2 NV) shuffles instead of 6 NV.  On return lane l < NV
+// holds in x[0] the total of value number bitrev_{log2 NV}(l).
+template <int NV>
+__device__ __forceinline__ void wave_sums(double (&x)[NV], int lane) {
+  int bit = 0;
+#pragma unroll
+  for (int h = NV / 2; h >= 1; h >>= 1, ++bit) {
+    const bool up = (lane >> bit) & 1;
+#pragma unroll
+    for (int k = 0; k < h; ++k) {
+      const double keep = up ? x[h + k] : x[k], send = up ? x[k] : x[h + k];
+      x[k] = keep + __shfl_xor(send, 1 << bit);
+    }
+  }
+#pragma unroll
+  for (int o = NV; o < 64; o <<= 1) x[0] += __shfl_xor(x[0], o);
+}
+
 // sum of a complex value over the 256 threads of a block (red: >= 8 doubles of LDS)
 __device__ __forceinline__ double2 block_sum2(double2 v, double* red) {
   v.x = wave_sum(v.x);
@@ -259,14 +278,25 @@ __global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
     }
   }
   __syncthreads();
+  // this wave's chunks that exist at all; rows whose diagonal lies right of all of them are skipped too
+  int nk = 0;
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+    if ((wave + 4 * kk) * 64 < Lb) nk = kk + 1;
+  const int last_col = nk ? (wave + 4 * (nk - 1)) * 64 + 63 : -1;
   for (int d0 = 0; d0 < nrows; d0 += RI) {
-    double2 a[RI][KK], acc[RI];
+    if (d0 > last_col) {  // (uniform over the wave)
+      if (lane < RI && d0 + lane < nrows) s_row[wave][d0 + lane] = make_double2(0.0, 0.0);
+      continue;
+    }
+    double2 a[RI][KK];
+    double acc[2 * RI];
     double2* row[RI];
 #pragma unroll
     for (int q = 0; q < RI; ++q) {
       const int d = d0 + q < nrows ? d0 + q : nrows - 1;
       row[q] = A + (int64_t)(r0 + d) * n + r0;
-      acc[q] = make_double2(0.0, 0.0);
+      acc[2 * q] = acc[2 * q + 1] = 0.0;
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         const int cb = (wave + 4 * kk) * 64 + lane;
@@ -286,17 +316,23 @@ __global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
             x.x -= vpi.x * cw[kk].x - vpi.y * cw[kk].y + wpi.x * cv[kk].x - wpi.y * cv[kk].y;
             x.y -= vpi.x * cw[kk].y + vpi.y * cw[kk].x + wpi.x * cv[kk].y + wpi.y * cv[kk].x;
             row[q][cb] = x;
-            acc[q].x += x.x * v[kk].x - x.y * v[kk].y;
-            acc[q].y += x.x * v[kk].y + x.y * v[kk].x;
+            acc[2 * q] += x.x * v[kk].x - x.y * v[kk].y;
+            acc[2 * q + 1] += x.x * v[kk].y + x.y * v[kk].x;
             if (cb > d) {  // conj(a) v_r
               col[kk].x += x.x * vr.x + x.y * vr.y;
               col[kk].y += x.x * vr.y - x.y * vr.x;
             }
           }
         }
-        const double sx = wave_sum(acc[q].x), sy = wave_sum(acc[q].y);
-        if (lane == 0) s_row[wave][d] = make_double2(sx, sy);
       }
+    }
+    wave_sums<2 * RI>(acc, lane);
+    if (lane < 2 * RI) {  // lane holds value number bitrev(lane) = 2 q + (0: re, 1: im)
+      int idx = 0;
+#pragma unroll
+      for (int bq = 0, nb = (RI == 4 ? 3 : 2); bq < nb; ++bq) idx |= ((lane >> bq) & 1) << (nb - 1 - bq);
+      const int d = d0 + (idx >> 1);
+      if (d < nrows) reinterpret_cast<double*>(&s_row[wave][d])[idx & 1] = acc[0];
     }
   }
   __syncthreads();

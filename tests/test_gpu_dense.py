@@ -259,6 +259,9 @@ def test_dense_full_layout_matches_packed(kind):
         assert _rel(outs[dt, _lib.DMM_B_PACKED], outs[dt, _lib.DMM_B_FULL]) < 1e-12, dt
 
 
+_VARIANT_REF = {}
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_ml_eigen_path_variants(variant):
     """The eigen path of ML (`ml_shortcut` = 2 sends every tile there) in all its implementations:
@@ -284,7 +287,7 @@ def test_ml_eigen_path_variants(variant):
         return b
 
     bt = ArrayProvider(tel, beam)
-    rng = np.random.default_rng(10 + variant)
+    rng = np.random.default_rng(10)
     shape = (lmax + 1, 2, nfreq, tel.npairs)
     mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
     mw = rng.uniform(0.5, 1.5, shape) * 10.0
@@ -292,7 +295,9 @@ def test_ml_eigen_path_variants(variant):
     mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
     mm.vis[:] = mv
     mm.weight[:] = mw
-    ref = omm.solve_alm("ml", beam, mv, mw, lmax, tel.mmax, list(range(nfreq)))
+    if "ref" not in _VARIANT_REF:  # the oracle's SVDs take most of the time: same inputs for every variant
+        _VARIANT_REF["ref"] = omm.solve_alm("ml", beam, mv, mw, lmax, tel.mmax, list(range(nfreq)))
+    ref = _VARIANT_REF["ref"]
     try:
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", variant))
