@@ -310,3 +310,63 @@ def test_ml_eigen_path_variants(variant):
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
     assert _rel(out, ref) < 1e-8, variant
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_ml_eigen_path_degenerate_tiles(variant):
+    """Degenerate Gram matrices through the eigen path: a tile whose weights are all zero (G = 0, the answer is 0),
+    a tile with orthogonal rows of equal norm (G = c I: every eigenvalue equal, nothing to rotate), a tile with one
+    non-zero row (rank 1) and a tile scaled by 1e-3 so that the absolute cut `acond` removes modes the relative one
+    keeps.  All against the oracle's SVD."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import ArrayProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    nfreq, lmax = 1, 12
+    tel = _tel(nfreq, lmax, 1, 3)
+    npairs, ntel = tel.npairs, 2 * tel.npairs
+    seed = 99
+
+    def beam(m, f):
+        b = osyn.beam_tile(seed, m, f, npairs, 4, lmax).copy()
+        if m == 1:  # orthogonal rows of equal norm: row i of the (ntel, nsky) matrix = unit vector i
+            b[:] = 0.0
+            flat = b.reshape(ntel, 4 * (lmax + 1))
+            for i in range(ntel):
+                flat[i, (i % 4) * (lmax + 1) + 1 + i // 4] = 2.0  # columns with l >= m = 1
+        if m == 2:
+            b[:] = 0.0
+            b[0, 0, :, 2:] = osyn.beam_tile(seed, 2, f, npairs, 4, lmax)[0, 0, :, 2:]
+        if m == 3:
+            b *= 1e-3
+        return b
+
+    assert ntel <= 4 * lmax  # room for the unit vectors of m = 1
+    bt = ArrayProvider(tel, beam)
+    rng = np.random.default_rng(3)
+    shape = (lmax + 1, 2, nfreq, npairs)
+    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    mw = rng.uniform(0.5, 1.5, shape)
+    mw[0] = 0.0  # m = 0: no data at all
+    mw[1] = 0.7  # equal weights keep G = c I
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    ref = omm.solve_alm("ml", beam, mv, mw, lmax, tel.mmax, [0])
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", variant))
+        task = MaximumLikelihoodMapMaker()
+        task.setup(bt)
+        out = task.alm_square(task.make_alm(mm))
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+    assert np.all(np.isfinite(out))
+    assert np.all(out[..., 0] == 0)  # [freq, pol, l, m]
+    for m in range(lmax + 1):
+        scale = max(np.abs(ref[..., m]).max(), 1e-300)
+        assert np.abs(out[..., m] - ref[..., m]).max() / scale < 1e-8, m
