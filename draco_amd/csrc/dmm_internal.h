@@ -31,7 +31,7 @@ struct dmm_ctx {
   int opt_project_variant = 0;
   int opt_ml_inner_sweeps = 0, opt_ml_outer_sweeps = 0;
   int opt_sht_variant = 0;
-  int opt_ml_eigen = 0;                    // 0: Householder tridiagonalisation + QL (factored); 1: blocked Jacobi; 2: as 0 with full-matrix trailing updates; 3: as 0 with QL made to give up (exercises the Jacobi fallback)
+  int opt_ml_eigen = 0;                    // 0: by batch size (tridiagonalisation + QL for large batches, blocked Jacobi for a few matrices); 1: Jacobi; 4: tridiagonal; 2: tridiagonal with full-matrix trailing updates; 3: tridiagonal with QL made to give up (Jacobi fallback)
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
   unsigned long long* ticket = nullptr;    // ring of task counters for the dirty kernel's dynamic hand-out

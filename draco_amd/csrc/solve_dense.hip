@@ -552,7 +552,10 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
       bool solved = false;
-      if (ctx->opt_ml_eigen != 1) {  // tridiagonalisation + QL in factored form (herm_tridiag.h)
+      // tridiagonalisation + QL in factored form (herm_tridiag.h) has a latency floor per launch (the serial QL
+      // chases, ~0.12 s at order 768, ~ n^2); a handful of matrices is through the blocked Jacobi sooner
+      const bool use_td = ctx->opt_ml_eigen == 0 ? (double)nsel * p.Np >= 12000.0 : ctx->opt_ml_eigen != 1;
+      if (use_td) {
         const int n = p.Np;
         TdParams tp;
         tp.d = p;

@@ -262,11 +262,12 @@ def test_dense_full_layout_matches_packed(kind):
 _VARIANT_REF = {}
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [4, 1, 2, 3, 0])
 def test_ml_eigen_path_variants(variant):
     """The eigen path of ML (`ml_shortcut` = 2 sends every tile there) in all its implementations:
-    0 Householder tridiagonalisation (upper-triangle trailing updates) + QL in factored form, 1 blocked Jacobi,
-    2 as 0 with full-matrix trailing updates, 3 QL forced to give up -> Jacobi fallback on the re-formed Gram matrices.
+    4 Householder tridiagonalisation (upper-triangle trailing updates) + QL in factored form, 1 blocked Jacobi,
+    2 as 4 with full-matrix trailing updates, 3 QL forced to give up -> Jacobi fallback on the re-formed Gram matrices,
+    0 the default (by batch size).
     Rank-deficient tiles, zero weights, telescope- and sky-side orders (64 ... 192) against the oracle's SVD."""
     from draco_amd import _lib
     from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
@@ -312,7 +313,7 @@ def test_ml_eigen_path_variants(variant):
     assert _rel(out, ref) < 1e-8, variant
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [4, 1])
 def test_ml_eigen_path_degenerate_tiles(variant):
     """Degenerate Gram matrices through the eigen path: a tile whose weights are all zero (G = 0, the answer is 0),
     a tile with orthogonal rows of equal norm (G = c I: every eigenvalue equal, nothing to rotate), a tile with one

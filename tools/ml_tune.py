@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """ML timing and accuracy vs the oracle SVD on sampled tiles: all m of one frequency.
 
-    python tools/ml_tune.py [config]      modes: certified shortcut (default), eigen path always, telescope side only
+    python tools/ml_tune.py [config [nfreq [modes [ml_eigen]]]]
+    modes (ml_shortcut): 0 certified shortcut (default), 2 eigen path always, 3 telescope side only;
+    ml_eigen: 0 by batch size (default), 4 tridiagonalisation + QL, 1 blocked Jacobi
 """
 import json
 import os
@@ -28,8 +30,10 @@ def main():
     cfgn = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     modes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 3, 2]
+    eig = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     cfg = osyn.CONFIGS[cfgn]
     ctx = Context.get()
+    _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", eig))
     lmax = cfg["lmax"]
     tel = TransitTelescope(osyn.frequencies(nf), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
     eng = SolveEngine(SyntheticProvider(tel, seed=5), ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=True)
@@ -60,7 +64,7 @@ def main():
         ctx.sync()
         dt = time.perf_counter() - t0
         err = max(np.abs(alm[0, :, m, :].cpu().numpy() - refs[m]).max() / np.abs(refs[m]).max() for m in ms)
-        print(json.dumps({"cfg": cfgn, "mode": label, "nfreq": nf, "ms_per_tile": dt * 1e3 / (nf * (lmax + 1)), "total_s": dt, "max_rel_err": err,
+        print(json.dumps({"cfg": cfgn, "mode": label, "ml_eigen": eig, "nfreq": nf, "ms_per_tile": dt * 1e3 / (nf * (lmax + 1)), "total_s": dt, "max_rel_err": err,
                           "tiles_direct": counter(b"ml_tiles_direct") - d0, "tiles_eigen": counter(b"ml_tiles_eigen") - e0}), flush=True)
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
 
