@@ -407,7 +407,15 @@ __device__ __forceinline__ void td_replay(double2* b, const double2* lcs, const 
   }
 }
 
+#ifdef TD_TIMING
+#define TD_T(k) td_t[k] = wall_clock64()
+#else
+#define TD_T(k)
+#endif
 __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
+#ifdef TD_TIMING
+  long long td_t[6];
+#endif
   extern __shared__ __align__(16) unsigned char smem_td[];
   __shared__ double red[8];
   __shared__ int s_nrot, s_fail;
@@ -445,6 +453,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     dl[i] = dd[i];
     el[i] = i < n - 1 ? ee[i] : 0.0;
   }
+  TD_T(0);
   if (threadIdx.x == 0) s_nrot = s_fail = 0;
   __syncthreads();
   // ---- z = Q^H b = H_{n-2}^H ... H_0^H b,  H_j = I - tau_j v_j v_j^H,  v_j = (0.., 1 at j+1, row j of A beyond)
@@ -467,6 +476,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     }
     __syncthreads();
   }
+  TD_T(1);
   // ---- implicit-shift QL on (dl, el).  One lane runs the (inherently serial) bulge chases and logs every rotation
   // (c, s) plus one header (l, m, first log position) per chase; the vector is not touched here.
   if (threadIdx.x < 64) {  // wave 0: all lanes search for the split point, lane 0 chases the bulge
@@ -491,49 +501,56 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
           fail = 1;
           break;
         }
-        int done = 0, under = 0;
+        int done = 0;
         if (lane == 0) {
           double g = (dl[l + 1] - dl[l]) / (2.0 * el[l]);
           double r = sqrt(g * g + 1.0);
           g = dl[m] - dl[l] + el[l] / (g + (g >= 0.0 ? r : -r));
           double s = 1.0, c = 1.0, pp = 0.0;
           int i = m - 1;
-          // operands of the chase are fetched one step ahead of the dependent chain
+          // The chase is one long dependent chain; everything off it is arranged not to stall it: operands are
+          // fetched one step ahead, the results of a step are stored at the top of the next one (so the wait for the
+          // prefetched operands never waits for a younger store), and the exact-zero case (f = g = 0, the
+          // "underflow" exit of the textbook loop) is an identity rotation chosen by selects instead of a branch --
+          // every step stays a plane rotation, so the product is an orthogonal similarity whatever the data.
           double e_n = el[i], d_n = dl[i], d_hi = dl[i + 1];
+          double e_n2 = el[i > 0 ? i - 1 : 0], d_n2 = dl[i > 0 ? i - 1 : 0];  // two steps ahead
+          double pend_e = el[i + 1], pend_d = d_hi;  // (first store rewrites what is there)
           double2* out = lcs + nrot;
           for (; i >= l; --i) {
+            el[i + 2 <= m ? i + 2 : m] = pend_e;  // results of the previous step (i + 1): e[i+2], d[i+2]
+            dl[i + 2 <= m ? i + 2 : m] = pend_d;
             const double e_i = e_n, d_i = d_n;
-            const int ip = i > 0 ? i - 1 : 0;
-            e_n = el[ip];
-            d_n = dl[ip];
+            const int ip = i > 1 ? i - 2 : 0;
+            e_n = e_n2;
+            d_n = d_n2;
+            e_n2 = el[ip];
+            d_n2 = dl[ip];
             const double f = s * e_i, bb = c * e_i;
             const double h = f * f + g * g;
-            if (h == 0.0) {  // recover from underflow
-              el[i + 1] = 0.0;
-              dl[i + 1] = d_hi - pp;
-              el[m] = 0.0;
-              under = 1;
-              break;
-            }
-            double ri = __builtin_amdgcn_rsq(h);  // ~2^-26 seed, two Newton steps
-            ri = ri * (1.5 - 0.5 * h * ri * ri);
-            ri = ri * (1.5 - 0.5 * h * ri * ri);
-            el[i + 1] = h * ri;
+            // 1/sqrt(h): hardware seed (~2^-26), one cubically convergent correction
+            double y = __builtin_amdgcn_rsq(h);
+            const double ee = __builtin_fma(-h * y, y, 1.0);
+            y = __builtin_fma(y * ee, __builtin_fma(ee, 0.375, 0.5), y);
+            const bool zero = h == 0.0;
+            const double ri = zero ? 0.0 : y;
+            pend_e = h * ri;  // e[i+1]
             s = f * ri;
-            c = g * ri;
+            c = zero ? 1.0 : g * ri;
             g = d_hi - pp;
-            r = (d_i - g) * s + 2.0 * c * bb;
+            const double r = (d_i - g) * s + 2.0 * c * bb;
             pp = s * r;
-            dl[i + 1] = g + pp;
+            pend_d = g + pp;  // d[i+1]
             g = c * r - bb;
             d_hi = d_i;
             out[done++] = make_double2(c, s);
           }
-          if (!under) {
-            dl[l] -= pp;
-            el[l] = g;
-            el[m] = 0.0;
-          }
+          // the last step's results: e[l+1], d[l+1]  (i == l - 1 here)
+          el[l + 1] = pend_e;
+          dl[l + 1] = pend_d;
+          dl[l] -= pp;
+          el[l] = g;
+          el[m] = 0.0;
           if (done) {  // rotations i = m-1 .. m-done of this chase
             lrun[3 * nrun] = m;
             lrun[3 * nrun + 1] = done;
@@ -551,6 +568,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     }
   }
   __syncthreads();
+  TD_T(2);
   if (s_fail) {
     if (threadIdx.x == 0) tp.fail[blockIdx.x] = 1;
     return;
@@ -560,6 +578,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   // wave 0, lane t two indices behind lane t-1:  (q R)_{i+1} = s q_i + c q_{i+1},  (q R)_i = c q_i - s q_{i+1}.
   td_replay<false>(b, lcs, lrun, s_nrot);
   __syncthreads();
+  TD_T(3);
   // ---- the reference's cut on sigma = sqrt(lambda) (mapmaker.py:296), g = f(L) S^T z
   {
     double mx = 0.0;
@@ -582,6 +601,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   // (R y)_i = c y_i + s y_{i+1},  (R y)_{i+1} = -s y_i + c y_{i+1}
   td_replay<true>(b, lcs, lrun, s_nrot);
   __syncthreads();
+  TD_T(4);
   // ---- x = Q y = H_0 (H_1 (... H_{n-2} y))
   for (int j = n - 2; j >= 0; --j) {
     const double2 t = tau[j];
@@ -602,6 +622,12 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     }
     __syncthreads();
   }
+  TD_T(5);
+#ifdef TD_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("td_solve n=%d runs=%d: Qhb %.3f ms, QL %.3f, fwd %.3f, cut+bwd %.3f, Qy %.3f\n", n, s_nrot, (td_t[1] - td_t[0]) * 1e-5,
+           (td_t[2] - td_t[1]) * 1e-5, (td_t[3] - td_t[2]) * 1e-5, (td_t[4] - td_t[3]) * 1e-5, (td_t[5] - td_t[4]) * 1e-5);
+#endif
   for (int i = threadIdx.x; i < N; i += kThreads) {
     const double2 acc = b[i];
     if (p.sky) {
