@@ -157,12 +157,15 @@ def test_cfg4_tile_wiener_and_ml_properties():
             assert np.abs(Bt.conj().T @ y - x).max() < 1e-9 * np.abs(x).max(), m
         else:  # overdetermined: normal equations
             assert np.abs(Bt.conj().T @ r).max() < 1e-9 * np.abs(Bt.conj().T @ (np.sqrt(nv) * vv)).max(), m
-        try:
-            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
-            a_eig = ml._solve_m(m, 0, v, Ni)
-        finally:
-            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
-        assert _rel(a, a_eig) < 1e-9, m
+        for eig in (1, 4):  # blocked Jacobi; Householder tridiagonalisation + QL (order 1536: six column chunks per wave)
+            try:
+                _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+                _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", eig))
+                a_eig = ml._solve_m(m, 0, v, Ni)
+            finally:
+                _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+                _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+            assert _rel(a, a_eig) < 1e-9, (m, eig)
 
 
 def test_cfg4_sht_roundtrip_nside512():
