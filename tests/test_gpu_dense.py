@@ -371,3 +371,57 @@ def test_ml_eigen_path_degenerate_tiles(variant):
     for m in range(lmax + 1):
         scale = max(np.abs(ref[..., m]).max(), 1e-300)
         assert np.abs(out[..., m] - ref[..., m]).max() / scale < 1e-8, m
+
+
+@pytest.mark.parametrize("variant", [4, 1])
+def test_ml_ill_conditioned_tiles(variant):
+    """Beam transfers with a geometric singular spectrum (1 ... 1e-8, the regime of real telescopes): about a third of
+    the modes survive pinv_svd's relative cut at 1e-3.  The Gram route squares the condition number, so a kept mode
+    sigma carries a relative error ~ eps (sigma_max / sigma)^2 <= 1e-10; agreement with the oracle's SVD of D B itself
+    is asserted at 1e-7 of the solution's scale (far inside the 1e-5 map tolerance of the task)."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import ArrayProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    nfreq, lmax = 1, 40
+    tel = _tel(nfreq, lmax, 2, 4)
+    npairs, ntel = tel.npairs, 2 * tel.npairs
+    rng = np.random.default_rng(77)
+    tiles = {}
+
+    def beam(m, f):
+        if m not in tiles:
+            nsky = 4 * (lmax + 1 - m)
+            k = min(ntel, nsky)
+            u, _ = np.linalg.qr(rng.standard_normal((ntel, k)) + 1j * rng.standard_normal((ntel, k)))
+            v, _ = np.linalg.qr(rng.standard_normal((nsky, k)) + 1j * rng.standard_normal((nsky, k)))
+            sig = np.logspace(0, -8, k)
+            b = np.zeros((2, npairs, 4, lmax + 1), dtype=np.complex128)
+            b[..., m:] = ((u * sig) @ v.conj().T).reshape(2, npairs, 4, lmax + 1 - m)
+            tiles[m] = b
+        return tiles[m]
+
+    bt = ArrayProvider(tel, beam)
+    shape = (lmax + 1, 2, nfreq, npairs)
+    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    mw = np.ones(shape)  # unit weights keep the singular values those of B; acond = 1e-4 then cuts below the relative rule
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    ref = omm.solve_alm("ml", beam, mv, mw, lmax, tel.mmax, [0])
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", variant))
+        d0, e0 = _counter(ctx, b"ml_tiles_direct"), _counter(ctx, b"ml_tiles_eigen")
+        task = MaximumLikelihoodMapMaker()
+        task.setup(bt)
+        out = task.alm_square(task.make_alm(mm))
+        assert _counter(ctx, b"ml_tiles_direct") == d0  # no tile passes the full-rank certificate
+        assert _counter(ctx, b"ml_tiles_eigen") - e0 == lmax + 1
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+    for m in range(lmax + 1):
+        err = np.abs(out[..., m] - ref[..., m]).max() / np.abs(ref[..., m]).max()
+        assert err < 1e-7, (m, err)
