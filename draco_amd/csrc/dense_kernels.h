@@ -269,7 +269,24 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
       }
 }
 
+// 1/x and 1/sqrt(x) in double from the hardware seeds (~2^-26) and one cubically convergent correction (full precision
+// for normal x > 0; NaN / inf / zero behave like the slow forms closely enough for a pivot that is flagged anyway)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, __builtin_fma(e, e, e), y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-x * y, y, 1.0);
+  return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+}
+
 // Factor the 64x64 diagonal block J of every matrix in LDS and invert the factor.
+// Right-looking, one barrier per column: step k divides by a_kk on the fly (a_ij -= a_ik conj(a_jk) / a_kk), the
+// scaling of column k itself is postponed to step k+1, when nobody reads that column any more.  Thread t updates row
+// t/4, columns k+1 + t%4, +4, ...  The inverse of the factor is a forward substitution per column, four adjacent lanes
+// per column sharing the inner sum (no barrier: a column's lanes sit in one wave).
 __global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
   extern __shared__ __align__(16) unsigned char smem_cd[];
   double2(*a)[TB + 1] = reinterpret_cast<double2(*)[TB + 1]>(smem_cd);
@@ -282,44 +299,59 @@ __global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
     a[i][j] = j <= i ? Ablk[(int64_t)i * p.Np + j] : make_double2(0.0, 0.0);
   }
   __syncthreads();
+  const int ri = threadIdx.x >> 2, rc = threadIdx.x & 3;
+  bool bad = false;
   for (int k = 0; k < TB; ++k) {
-    const double akk = a[k][k].x;
-    if (p.fail && threadIdx.x == 0 && !(akk > 0.0)) p.fail[mat] = 1;  // not positive definite (NaN included)
-    const double d = sqrt(akk);
-    const double inv = 1.0 / d;
-    __syncthreads();
-    if (threadIdx.x == 0) a[k][k] = make_double2(d, 0.0);
-    for (int i = k + 1 + threadIdx.x; i < TB; i += kThreads) {
-      a[i][k].x *= inv;
-      a[i][k].y *= inv;
+    const double akk = a[k][k].x;  // still the unscaled pivot
+    bad = bad || !(akk > 0.0);     // not positive definite (NaN included)
+    if (k > 0 && threadIdx.x < TB) {  // finish column k-1: l_i,k-1 = a_i,k-1 / sqrt(pivot)
+      const int i = threadIdx.x;
+      const double inv = fast_rsqrt(a[k - 1][k - 1].x);
+      if (i > k - 1) {
+        a[i][k - 1].x *= inv;
+        a[i][k - 1].y *= inv;
+      }
     }
-    __syncthreads();
-    // trailing update of the lower triangle: a[i][j] -= a[i][k] conj(a[j][k]),  k < j <= i
-    const int n = TB - 1 - k;
-    for (int idx = threadIdx.x; idx < n * n; idx += kThreads) {
-      const int i = k + 1 + idx / n, j = k + 1 + idx % n;
-      if (j <= i) {
-        const double2 x = a[i][k], y = a[j][k];
-        a[i][j].x -= x.x * y.x + x.y * y.y;
-        a[i][j].y -= x.y * y.x - x.x * y.y;
+    const double rinv = fast_rcp(akk);
+    if (ri > k) {
+      const double2 x = a[ri][k];
+      const double2 xs = make_double2(x.x * rinv, x.y * rinv);
+      for (int j = k + 1 + rc; j <= ri; j += 4) {
+        const double2 y = a[j][k];
+        a[ri][j].x -= xs.x * y.x + xs.y * y.y;
+        a[ri][j].y -= xs.y * y.x - xs.x * y.y;
       }
     }
     __syncthreads();
+    if (k > 0 && threadIdx.x == 0) a[k - 1][k - 1] = make_double2(sqrt(a[k - 1][k - 1].x), 0.0);
   }
-  // inverse of the lower-triangular factor: column j by forward substitution (one thread per column)
-  if (threadIdx.x < TB) {
-    const int j = threadIdx.x;
-    for (int i = 0; i < TB; ++i) li[i][j] = make_double2(0.0, 0.0);
-    li[j][j] = make_double2(1.0 / a[j][j].x, 0.0);
+  if (threadIdx.x == 0) {
+    a[TB - 1][TB - 1] = make_double2(sqrt(a[TB - 1][TB - 1].x), 0.0);
+    if (p.fail && bad) p.fail[mat] = 1;
+  }
+  __syncthreads();
+  // inverse of the lower-triangular factor: column j = threadIdx / 4 by forward substitution
+  __shared__ double dinv[TB];
+  if (threadIdx.x < TB) dinv[threadIdx.x] = fast_rcp(a[threadIdx.x][threadIdx.x].x);
+  __syncthreads();
+  {
+    const int j = threadIdx.x >> 2, g = threadIdx.x & 3;
+    for (int i = g; i < j; i += 4) li[i][j] = make_double2(0.0, 0.0);
+    if (g == 0) li[j][j] = make_double2(dinv[j], 0.0);
     for (int i = j + 1; i < TB; ++i) {
       double sx = 0.0, sy = 0.0;
-      for (int q = j; q < i; ++q) {
+      for (int q = j + g; q < i; q += 4) {
         const double2 l = a[i][q], x = li[q][j];
         sx += l.x * x.x - l.y * x.y;
         sy += l.x * x.y + l.y * x.x;
       }
-      const double inv = 1.0 / a[i][i].x;
-      li[i][j] = make_double2(-sx * inv, -sy * inv);
+      sx += __shfl_xor(sx, 1);
+      sy += __shfl_xor(sy, 1);
+      sx += __shfl_xor(sx, 2);
+      sy += __shfl_xor(sy, 2);
+      const double inv = dinv[i];
+      if (g == 0) li[i][j] = make_double2(-sx * inv, -sy * inv);
+      __builtin_amdgcn_wave_barrier();  // (compiler only: the other lanes of the column read it next round)
     }
   }
   __syncthreads();
