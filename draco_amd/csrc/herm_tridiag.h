@@ -33,7 +33,8 @@ struct TdParams {
   double2* log_cs;     // rotation log of matrix slot s: log_cs + s * log_stride, then its chase headers
   int64_t log_stride;  // double2 units per matrix slot
   int log_cap;         // rotations per matrix
-  int run_cap;         // chases (QL iterations) per matrix: 3 ints each behind the rotations
+  int run_cap;         // chases (QL iterations) per matrix: 3 ints each behind the rotations; negative: |run_cap|, and every
+                       // other matrix of the launch is made to give up at its first chase (exercises the fallback)
   int j;               // current column
   int tri;             // 1: the trailing matrix lives in its upper triangle only (k_td_trail_tri)
   double acond, rcond;
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   if (threadIdx.x < 64) {  // wave 0: all lanes search for the split point, lane 0 chases the bulge
     const int lane = threadIdx.x;
     int nrot = 0, nrun = 0, fail = 0;
+    const int run_cap = tp.run_cap >= 0 ? tp.run_cap : ((blockIdx.x & 1) ? 0 : -tp.run_cap);
     const double eps = 2.220446049250313e-16;
     for (int l = 0; l < n && !fail; ++l) {
       int iter = 0;
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
           }
         }
         if (m == l) break;
-        if (++iter > kTdMaxIter || nrot + (m - l) > tp.log_cap || nrun >= tp.run_cap) {
+        if (++iter > kTdMaxIter || nrot + (m - l) > tp.log_cap || nrun >= run_cap) {
           fail = 1;
           break;
         }

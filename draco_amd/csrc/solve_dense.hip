@@ -548,7 +548,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     }
     ctx->ml_tiles_eigen += (int64_t)msel_h.size();
     if (!msel_h.empty()) {  // eigen-decomposition of the Gram matrices, reference's cut applied
-      const int nsel = (int)msel_h.size();
+      int nsel = (int)msel_h.size();
       DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
       bool solved = false;
@@ -563,8 +563,9 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.vec = Whbuf;
         tp.log_cs = Vbuf;
         tp.log_stride = (int64_t)2 * L.Np * L.Np;
-        tp.run_cap = ctx->opt_ml_eigen == 3 ? 0 : 16 * n;  // (a chase per QL iteration: ~1.7 n in practice; 3: force the fallback, tests)
-        tp.log_cap = (int)std::min<int64_t>(tp.log_stride - ((int64_t)3 * tp.run_cap * sizeof(int) + 15) / 16, 0x7fffffff);
+        const int runs = 16 * n;  // a chase per QL iteration: ~1.7 n in practice
+        tp.run_cap = ctx->opt_ml_eigen == 3 ? -runs : runs;  // negative: every other matrix is made to give up (tests)
+        tp.log_cap = (int)std::min<int64_t>(tp.log_stride - ((int64_t)3 * runs * sizeof(int) + 15) / 16, 0x7fffffff);
         tp.acond = acond;
         tp.rcond = rcond;
         tp.fail = fail_d;
@@ -593,9 +594,19 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         td_fail_h.assign(nsel, 0);
         DMM_HIP(hipMemcpyAsync(td_fail_h.data(), fail_d, nsel * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         DMM_HIP(hipStreamSynchronize(ctx->stream));
-        solved = true;
-        for (int f : td_fail_h) solved = solved && !f;
-        if (!solved) form_gram();  // QL stalled or its log overflowed (not seen in practice): Jacobi on the batch
+        // QL stalled or its log overflowed (not seen in practice): those matrices -- and only those, the others have
+        // already replaced their right-hand side by the solution -- go through Jacobi on re-formed Gram matrices
+        std::vector<int> redo;
+        for (int k = 0; k < nsel; ++k)
+          if (td_fail_h[k]) redo.push_back(msel_h[k]);
+        solved = redo.empty();
+        if (!solved) {
+          msel_h = redo;
+          nsel = (int)msel_h.size();
+          DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+          DMM_HIP(hipStreamSynchronize(ctx->stream));
+          form_gram();
+        }
       }
       if (solved) {
         // nothing left to do

@@ -266,7 +266,7 @@ _VARIANT_REF = {}
 def test_ml_eigen_path_variants(variant):
     """The eigen path of ML (`ml_shortcut` = 2 sends every tile there) in all its implementations:
     4 Householder tridiagonalisation (upper-triangle trailing updates) + QL in factored form, 1 blocked Jacobi,
-    2 as 4 with full-matrix trailing updates, 3 QL forced to give up -> Jacobi fallback on the re-formed Gram matrices,
+    2 as 4 with full-matrix trailing updates, 3 QL forced to give up on every other matrix -> Jacobi fallback on the re-formed Gram matrices of those,
     0 the default (by batch size).
     Rank-deficient tiles, zero weights, telescope- and sky-side orders (64 ... 192) against the oracle's SVD."""
     from draco_amd import _lib

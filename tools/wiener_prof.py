@@ -25,7 +25,8 @@ def main():
     cfg = osyn.CONFIGS[cfgn]
     ctx = Context.get()
     tel = TransitTelescope(osyn.frequencies(nf), lmax=cfg["lmax"], ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
-    eng = SolveEngine(SyntheticProvider(tel, seed=5), ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=True)
+    bdt = _lib.DMM_C64 if (len(sys.argv) > 5 and sys.argv[5] == "c64") else _lib.DMM_C128
+    eng = SolveEngine(SyntheticProvider(tel, seed=5), ctx, bdt, _lib.DMM_B_PACKED, cache=True)
     gen = torch.Generator(device=ctx.device).manual_seed(7)
     vis = torch.randn((nf, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
     w = torch.rand((nf, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
