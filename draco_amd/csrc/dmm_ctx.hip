@@ -85,6 +85,10 @@ int dmm_ctx_destroy(dmm_ctx* c) {
   if (c->ticket) (void)hipFree(c->ticket);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->aux_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+  if (c->aux_pinned) (void)hipHostFree(c->aux_pinned);
   delete c;
   return DMM_OK;
 }

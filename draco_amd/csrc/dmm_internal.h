@@ -20,6 +20,10 @@ struct dmm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t aux_stream = nullptr;        // library-owned second stream (ML eigen path: QL of one half-batch under the reduction of the next)
+  hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* aux_pinned = nullptr;               // pinned host words for flags read back on the second stream
+  size_t aux_pinned_n = 0;
   int num_cu = 256;
   std::map<int, dmm_fft_tables> fft;       // forward tables by nra
   std::map<int, dmm_fft_tables> ifft;      // inverse tables by nra

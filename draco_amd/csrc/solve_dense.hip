@@ -663,21 +663,203 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     return DMM_OK;
   };
 
-  for (int pass = 0; pass < 2; ++pass) {  // 0: every tile, certificate first; 1: the tiles it rejected
-    const bool eigen_only = pass == 1;
-    const std::vector<int64_t>& tl = eigen_only ? tel_deferred : tel_list;
-    for (size_t i0 = 0; i0 < tl.size(); i0 += cap) {
-      int rc = run_batch(tl, i0, (int)std::min<size_t>(cap, tl.size() - i0), false, 0, eigen_only);
+  // ---- pipelined eigen pass (tridiagonal path).  The workspace is used as two halves: while the serial QL chases of
+  // one half-batch run on the library's second stream (one wave per matrix, a latency floor that leaves the GPU
+  // empty), the Gram matrices and the HBM-bound reduction of the next half-batch run on the caller's stream.
+  const int capE = cap / 2;
+  struct Half {
+    std::vector<dmm_tile> tiles;
+    std::vector<int32_t> work;
+    std::vector<int64_t> ids;
+    int nmat = 0;
+    bool busy = false;
+  } half[2];
+  std::vector<int64_t> redo_tel;
+  std::map<int, std::vector<int64_t>> redo_sky;
+  bool redo_is_sky[2] = {false, false};
+  int redo_np[2] = {0, 0};
+  auto pipe_ready = [&]() -> int {
+    if (!ctx->aux_stream) DMM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : ctx->aux_ev)
+      if (!e) DMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (ctx->aux_pinned_n < (size_t)2 * capE) {
+      if (ctx->aux_pinned) DMM_HIP(hipHostFree(ctx->aux_pinned));
+      ctx->aux_pinned = nullptr;
+      DMM_HIP(hipHostMalloc((void**)&ctx->aux_pinned, (size_t)2 * capE * sizeof(int), hipHostMallocDefault));
+      ctx->aux_pinned_n = (size_t)2 * capE;
+    }
+    return DMM_OK;
+  };
+  auto retire = [&](int h) -> int {  // wait for the half's solve and collect the matrices whose QL gave up
+    Half& H = half[h];
+    if (!H.busy) return DMM_OK;
+    DMM_HIP(hipEventSynchronize(ctx->aux_ev[2 + h]));
+    const int* fl = ctx->aux_pinned + (size_t)h * capE;
+    for (int k = 0; k < H.nmat; ++k)
+      if (fl[k]) (redo_is_sky[h] ? redo_sky[redo_np[h]] : redo_tel).push_back(H.ids[k]);
+    H.busy = false;
+    return DMM_OK;
+  };
+  auto launch_chunk = [&](int h, const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky) -> int {
+    int rc = retire(h);
+    if (rc) return rc;
+    Half& H = half[h];
+    const size_t off = (size_t)h * capE;
+    hipStream_t S1 = ctx->stream, S2 = ctx->aux_stream;
+    DenseParams p = base;
+    p.A = base.A + off * L.Np * L.Np;
+    p.wbuf = base.wbuf + off * L.N;
+    dmm_tile* const tiles_h = tiles_d + off;
+    int32_t* const work_h = work_d + off + h;
+    int* const fail_hd = fail_d + off;
+    double2* const Vb = Vbuf + off * 2 * L.Np * L.Np;
+    double2* const Wv = Whbuf + off * (L.Np / 64) * TB * TB;
+    p.tiles = tiles_h;
+    p.tile0 = 0;
+    p.nmat = nmat;
+    p.sky = sky ? 1 : 0;
+    p.N = sky ? np_sky : ntel;
+    p.Np = (p.N + TB - 1) / TB * TB;
+    p.T = p.Np / TB;
+    p.alm = (double2*)alm;
+    H.nmat = nmat;
+    H.tiles.resize(nmat);
+    H.work.assign(nmat + 1, 0);
+    H.ids.assign(list.begin() + i0, list.begin() + i0 + nmat);
+    for (int i = 0; i < nmat; ++i) {
+      H.tiles[i] = pl->tiles_h[list[i0 + i]];
+      const int ncol = pl->npol * (pl->lmax + 1 - H.tiles[i].m);
+      H.work[i + 1] = H.work[i] + (ncol + pl->cols_per_block - 1) / pl->cols_per_block;
+    }
+    redo_is_sky[h] = sky;
+    redo_np[h] = np_sky;
+    DMM_HIP(hipMemcpyAsync(tiles_h, H.tiles.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, S1));
+    DMM_HIP(hipMemcpyAsync(work_h, H.work.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, S1));
+    const int T = p.T, n = p.Np;
+    if (sky) {
+      p.ldx = ntel;
+      p.X = Vb;
+      hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, S1, p, Vb);
+      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+    } else {
+      hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+    }
+    hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, S1, p);
+    TdParams tp;
+    tp.d = p;
+    tp.d.msel = nullptr;
+    tp.vec = Wv;
+    tp.log_cs = Vb;
+    tp.log_stride = (int64_t)2 * L.Np * L.Np;
+    const int runs = 16 * n;
+    tp.run_cap = ctx->opt_ml_eigen == 3 ? -runs : runs;
+    tp.log_cap = (int)std::min<int64_t>(tp.log_stride - ((int64_t)3 * runs * sizeof(int) + 15) / 16, 0x7fffffff);
+    tp.acond = acond;
+    tp.rcond = rcond;
+    tp.fail = fail_hd;
+    tp.tri = n <= 2048 ? 1 : 0;
+    DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
+    const size_t col_lds = (size_t)3 * n * sizeof(double2);
+    const size_t sol_lds = (size_t)n * (sizeof(double2) + 2 * sizeof(double));
+    for (int j = 0; j < n; ++j) {
+      tp.j = j;
+      hipLaunchKernelGGL(k_td_col, dim3(nmat), dim3(kThreads), col_lds, S1, tp);
+      if (j < n - 1) {
+        const dim3 grid((n - j - 1 + kTdRows - 1) / kTdRows, nmat);
+        if (!tp.tri)
+          hipLaunchKernelGGL(k_td_trail, grid, dim3(kThreads), (size_t)3 * (n - j - 1) * sizeof(double2), S1, tp);
+        else if (n <= 768)
+          hipLaunchKernelGGL(k_td_trail_tri<3>, grid, dim3(kThreads), 0, S1, tp);
+        else if (n <= 1536)
+          hipLaunchKernelGGL(k_td_trail_tri<6>, grid, dim3(kThreads), 0, S1, tp);
+        else
+          hipLaunchKernelGGL(k_td_trail_tri<8>, grid, dim3(kThreads), 0, S1, tp);
+      }
+    }
+    DMM_HIP(hipGetLastError());
+    DMM_HIP(hipEventRecord(ctx->aux_ev[h], S1));
+    DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
+    hipLaunchKernelGGL(k_td_solve, dim3(nmat), dim3(kThreads), sol_lds, S2, tp);
+    DMM_HIP(hipGetLastError());
+    if (!sky) {  // back-projection a = B^H w of the half's tiles, behind its solve on the second stream
+      ctx->stream = S2;
+      rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_h, work_h, nmat, H.work[nmat], alm);
+      ctx->stream = S1;
       if (rc) return rc;
     }
-    for (auto& kv : eigen_only ? sky_deferred : sky_lists)
-      for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
-        int rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first, eigen_only);
+    DMM_HIP(hipMemcpyAsync(ctx->aux_pinned + off, fail_hd, nmat * sizeof(int), hipMemcpyDeviceToHost, S2));
+    DMM_HIP(hipEventRecord(ctx->aux_ev[2 + h], S2));
+    H.busy = true;
+    ctx->ml_tiles_eigen += nmat;
+    return DMM_OK;
+  };
+  // one list of same-order matrices through the eigen path: pipelined tridiagonal chunks, or (few matrices, or the
+  // Jacobi / full-matrix variants asked for) the synchronous batches above
+  int chunk_no = 0;
+  auto eigen_list = [&](const std::vector<int64_t>& list, bool sky, int np_sky) -> int {
+    if (list.empty()) return DMM_OK;
+    const int np = ((sky ? np_sky : ntel) + TB - 1) / TB * TB;
+    const int eig = ctx->opt_ml_eigen;
+    const bool pipelined = capE >= 1 && (eig == 4 || eig == 3 || (eig == 0 && (double)std::min<size_t>(capE, list.size()) * np >= 12000.0));
+    if (!pipelined) {
+      for (size_t i0 = 0; i0 < list.size(); i0 += cap) {
+        int rc = run_batch(list, i0, (int)std::min<size_t>(cap, list.size() - i0), sky, np_sky, true);
         if (rc) return rc;
       }
-    if (!shortcut) break;  // everything went through the eigen path already
+      return DMM_OK;
+    }
+    int rc = pipe_ready();
+    if (rc) return rc;
+    for (size_t i0 = 0; i0 < list.size(); i0 += capE, ++chunk_no) {
+      rc = launch_chunk(chunk_no & 1, list, i0, (int)std::min<size_t>(capE, list.size() - i0), sky, np_sky);
+      if (rc) return rc;
+    }
+    return DMM_OK;
+  };
+  auto drain = [&]() -> int {
+    int rc = retire(0);
+    if (rc) return rc;
+    rc = retire(1);
+    if (rc) return rc;
+    // matrices whose QL gave up (not seen in practice): synchronous Jacobi batches
+    const int saved = ctx->opt_ml_eigen;
+    ctx->opt_ml_eigen = 1;
+    for (size_t i0 = 0; i0 < redo_tel.size() && !rc; i0 += cap) {
+      ctx->ml_tiles_eigen -= (int64_t)std::min<size_t>(cap, redo_tel.size() - i0);  // (counted once already)
+      rc = run_batch(redo_tel, i0, (int)std::min<size_t>(cap, redo_tel.size() - i0), false, 0, true);
+    }
+    for (auto& kv : redo_sky)
+      for (size_t i0 = 0; i0 < kv.second.size() && !rc; i0 += cap) {
+        ctx->ml_tiles_eigen -= (int64_t)std::min<size_t>(cap, kv.second.size() - i0);
+        rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first, true);
+      }
+    ctx->opt_ml_eigen = saved;
+    redo_tel.clear();
+    redo_sky.clear();
+    return rc;
+  };
+
+  if (!shortcut) {  // every tile through the eigen path
+    int rc = eigen_list(tel_list, false, 0);
+    for (auto& kv : sky_lists)
+      if (!rc) rc = eigen_list(kv.second, true, kv.first);
+    const int rc2 = drain();
+    return rc ? rc : rc2;
   }
-  return DMM_OK;
+  for (size_t i0 = 0; i0 < tel_list.size(); i0 += cap) {  // certificate first; rejected tiles are deferred
+    int rc = run_batch(tel_list, i0, (int)std::min<size_t>(cap, tel_list.size() - i0), false, 0, false);
+    if (rc) return rc;
+  }
+  for (auto& kv : sky_lists)
+    for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
+      int rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first, false);
+      if (rc) return rc;
+    }
+  int rc = eigen_list(tel_deferred, false, 0);
+  for (auto& kv : sky_deferred)
+    if (!rc) rc = eigen_list(kv.second, true, kv.first);
+  const int rc2 = drain();
+  return rc ? rc : rc2;
 }
 
 }  // extern "C"
