@@ -22,8 +22,9 @@
 namespace {
 
 constexpr int kTdRows = 32;       // rows of the trailing matrix per block of k_td_trail (4 waves x 8)
-constexpr int kTdVecSlots = 6;    // per matrix: vprev, wprev, vcur, praw, tau, (d | e); then one column-partial vector per row block
+constexpr int kTdVecSlots = 6;    // per matrix: (2 unused), vcur, praw, tau, (d | e); then one column-partial vector per row block
 constexpr int kTdMaxIter = 60;    // QL iterations per eigenvalue before giving up
+constexpr int kTdPend = 4;        // most rank-2 updates left pending before a sweep applies them (all at once)
 
 __host__ __device__ constexpr int td_slots(int n) { return kTdVecSlots + n / kTdRows; }
 
@@ -37,9 +38,14 @@ struct TdParams {
                        // other matrix of the launch is made to give up at its first chase (exercises the fallback)
   int j;               // current column
   int tri;             // 1: the trailing matrix lives in its upper triangle only (k_td_trail_tri)
+  int np;              // pending rank-2 updates (pairs v_q, w_q not yet applied to the stored matrix) at this launch
   double acond, rcond;
   int* fail;           // [nsel] set when QL does not converge or the log overflows
 };
+
+// pending pair q of a matrix: v at pend + q n, w at pend + (kTdPend + q) n; the arrays live at the head of the
+// matrix's rotation-log region, which is free during the reduction
+__device__ __forceinline__ double2* td_pend(const TdParams& tp, int mat) { return tp.log_cs + (int64_t)mat * tp.log_stride; }
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // a * conj(b)
@@ -94,17 +100,23 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
   double2* A = p.A + (int64_t)mat * n * n;
   double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
-  double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n, *praw = vb + 3 * n, *tau = vb + 4 * n;
+  double2 *vcur = vb + 2 * n, *praw = vb + 3 * n, *tau = vb + 4 * n;
   double* dd = reinterpret_cast<double*>(vb + 5 * n);
   double* ee = dd + n;
+  double2* pv = td_pend(tp, mat);
+  double2* pw = pv + (int64_t)kTdPend * n;
   double2* sv = reinterpret_cast<double2*>(smem_td);
   double2* sw = sv + n;
   double2* sa = sw + n;
+  int np = tp.np;  // complete pending pairs; the stored matrix lacks their updates
 
-  // ---- finish step j-1: w = p - (conj(tau)/2) (v^H p) v,  p = tau A v
+  // ---- finish step j-1: w = p - (conj(tau)/2) (v^H p) v,  p = tau A v with A = stored matrix - pending updates:
+  // A v = (stored) v - sum_q [ v_q (w_q^H v) + w_q (v_q^H v) ]
   if (j >= 1) {
     const double2 t = tau[j - 1];
-    double2 g = make_double2(0.0, 0.0);
+    double2 cq[kTdPend], dq[kTdPend];
+#pragma unroll
+    for (int q = 0; q < kTdPend; ++q) cq[q] = dq[q] = make_double2(0.0, 0.0);
     for (int i = j + threadIdx.x; i < n; i += kThreads) {
       double2 pr = praw[i];
       if (tp.tri) {  // + the transposed contributions conj(a_ri) v_r of the rows r < i, one partial per row block
@@ -116,12 +128,40 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
           pr.y += q.y;
         }
       }
-      const double2 v = vcur[i], pi = cmul(t, pr);
+      const double2 v = vcur[i];
       sv[i] = v;
+      sw[i] = pr;
+#pragma unroll
+      for (int q = 0; q < kTdPend; ++q)
+        if (q < np) {
+          const double2 a = cmulc(v, pw[(int64_t)q * n + i]), b = cmulc(v, pv[(int64_t)q * n + i]);  // conj(w_q) v, conj(v_q) v
+          cq[q].x += a.x;
+          cq[q].y += a.y;
+          dq[q].x += b.x;
+          dq[q].y += b.y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kTdPend; ++q)
+      if (q < np) {  // (uniform)
+        cq[q] = block_sum2(cq[q], red);
+        dq[q] = block_sum2(dq[q], red);
+      }
+    double2 g = make_double2(0.0, 0.0);
+    for (int i = j + threadIdx.x; i < n; i += kThreads) {
+      double2 pr = sw[i];
+#pragma unroll
+      for (int q = 0; q < kTdPend; ++q)
+        if (q < np) {
+          const double2 a = cmul(pv[(int64_t)q * n + i], cq[q]), b = cmul(pw[(int64_t)q * n + i], dq[q]);
+          pr.x -= a.x + b.x;
+          pr.y -= a.y + b.y;
+        }
+      const double2 pi = cmul(t, pr);
       sw[i] = pi;
-      const double2 q = cmulc(pi, v);  // conj(v) p
-      g.x += q.x;
-      g.y += q.y;
+      const double2 qq = cmulc(pi, sv[i]);  // conj(v) p
+      g.x += qq.x;
+      g.y += qq.y;
     }
     g = block_sum2(g, red);
     const double2 coef = cmul(make_double2(0.5 * t.x, -0.5 * t.y), g);
@@ -129,23 +169,29 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
       const double2 v = sv[i], c = cmul(coef, v);
       const double2 w = make_double2(sw[i].x - c.x, sw[i].y - c.y);
       sw[i] = w;
-      vprev[i] = v;
-      wprev[i] = w;
+      pv[(int64_t)np * n + i] = v;  // the new pending pair
+      pw[(int64_t)np * n + i] = w;
     }
-  } else {
-    for (int i = threadIdx.x; i < n; i += kThreads) {
-      sv[i] = sw[i] = make_double2(0.0, 0.0);
-      vprev[i] = wprev[i] = make_double2(0.0, 0.0);
-    }
+    __syncthreads();
   }
-  __syncthreads();
-  // ---- column j with the pending update: a_i = conj(A[j][i]) - v_i conj(w_j) - w_i conj(v_j)
-  const double2 wj = sw[j], vj = sv[j];
+  // ---- column j with the pending updates: a_i = conj(A[j][i]) - sum_q [ v_q,i conj(w_q,j) + w_q,i conj(v_q,j) ]
+  // (the newest pair from LDS, the older ones from memory)
   double2 xn = make_double2(0.0, 0.0);
   for (int i = j + threadIdx.x; i < n; i += kThreads) {
     const double2 r = A[(int64_t)j * n + i];
-    const double2 u1 = cmulc(sv[i], wj), u2 = cmulc(sw[i], vj);
-    const double2 a = make_double2(r.x - u1.x - u2.x, -r.y - u1.y - u2.y);
+    double2 a = make_double2(r.x, -r.y);
+    if (j >= 1) {
+      const double2 u1 = cmulc(sv[i], sw[j]), u2 = cmulc(sw[i], sv[j]);
+      a.x -= u1.x + u2.x;
+      a.y -= u1.y + u2.y;
+    }
+#pragma unroll
+    for (int q = 0; q < kTdPend; ++q)
+      if (q < np) {
+        const double2 u1 = cmulc(pv[(int64_t)q * n + i], pw[(int64_t)q * n + j]), u2 = cmulc(pw[(int64_t)q * n + i], pv[(int64_t)q * n + j]);
+        a.x -= u1.x + u2.x;
+        a.y -= u1.y + u2.y;
+      }
     sa[i] = a;
     if (i >= j + 2) xn.x += a.x * a.x + a.y * a.y;
   }
@@ -189,13 +235,17 @@ __global__ __launch_bounds__(kThreads) void k_td_trail(TdParams tp) {
   const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
   double2* A = p.A + (int64_t)mat * n * n;
   double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
-  const double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n;
+  const double2* vcur = vb + 2 * n;
+  const double2* vprev = td_pend(tp, mat);  // this kernel applies one pending pair per sweep (tp.np = 0 or 1)
+  const double2* wprev = vprev + (int64_t)kTdPend * n;
+  const bool pend = tp.np > 0;
   double2* praw = vb + 3 * n;
   double2* cvp = reinterpret_cast<double2*>(smem_td);  // conj(vprev), conj(wprev), vcur on the trailing columns
   double2* cwp = cvp + L;
   double2* vv = cwp + L;
   for (int c = threadIdx.x; c < L; c += kThreads) {
-    const double2 a = vprev[c0 + c], b = wprev[c0 + c];
+    const double2 z = make_double2(0.0, 0.0);
+    const double2 a = pend ? vprev[c0 + c] : z, b = pend ? wprev[c0 + c] : z;
     cvp[c] = make_double2(a.x, -a.y);
     cwp[c] = make_double2(b.x, -b.y);
     vv[c] = vcur[c0 + c];
@@ -212,8 +262,8 @@ __global__ __launch_bounds__(kThreads) void k_td_trail(TdParams tp) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = r0 + k < n ? r0 + k : n - 1;  // (clamped duplicates are not stored)
-      vpi[k] = vprev[r];
-      wpi[k] = wprev[r];
+      vpi[k] = pend ? vprev[r] : make_double2(0.0, 0.0);
+      wpi[k] = pend ? wprev[r] : make_double2(0.0, 0.0);
       row[k] = A + (int64_t)r * n + c0;
       acc[k] = make_double2(0.0, 0.0);
     }
@@ -246,9 +296,10 @@ __global__ __launch_bounds__(kThreads) void k_td_trail(TdParams tp) {
 // w, w+4, ... of the block's column range for ALL of its rows: the per-column operands and the transposed sums
 // stay in that wave's registers (no cross-wave reduction, this row block's partial vector is written straight from
 // them); the four waves' pieces of a row sum meet in LDS.
-template <int KK, int RI = (KK <= 3 ? 4 : 2)>  // RI rows in flight per wave
+template <int KK, int NP, int RI = (KK <= 3 && NP == 0 ? 4 : 2)>  // NP pending pairs applied by this sweep (0: read only); RI rows in flight
 __global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
-  __shared__ double2 s_vp[kTdRows], s_wp[kTdRows], s_vr[kTdRows];
+  constexpr int NPA = NP > 0 ? NP : 1;
+  __shared__ double2 s_vp[NPA][kTdRows], s_wp[NPA][kTdRows], s_vr[kTdRows];
   __shared__ double2 s_row[4][kTdRows];
   const DenseParams& p = tp.d;
   const int n = p.Np, c0 = tp.j + 1;
@@ -257,25 +308,34 @@ __global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
   const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
   double2* A = p.A + (int64_t)mat * n * n;
   double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
-  const double2 *vprev = vb, *wprev = vb + n, *vcur = vb + 2 * n;
+  const double2* vcur = vb + 2 * n;
+  const double2* pv = td_pend(tp, mat);
+  const double2* pw = pv + (int64_t)kTdPend * n;
   double2* praw = vb + 3 * n;
   double2* colpart = vb + (int64_t)(kTdVecSlots + blockIdx.x) * n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < nrows) {
-    s_vp[threadIdx.x] = vprev[r0 + threadIdx.x];
-    s_wp[threadIdx.x] = wprev[r0 + threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      s_vp[q][threadIdx.x] = pv[(int64_t)q * n + r0 + threadIdx.x];
+      s_wp[q][threadIdx.x] = pw[(int64_t)q * n + r0 + threadIdx.x];
+    }
     s_vr[threadIdx.x] = vcur[r0 + threadIdx.x];
   }
-  double2 cw[KK], cv[KK], v[KK], col[KK];
+  double2 cw[NPA][KK], cv[NPA][KK], v[KK], col[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
     const int cb = (wave + 4 * kk) * 64 + lane;
-    cw[kk] = cv[kk] = v[kk] = col[kk] = make_double2(0.0, 0.0);
-    if (cb < Lb) {
-      const double2 a = vprev[r0 + cb], b = wprev[r0 + cb];
-      cv[kk] = make_double2(a.x, -a.y);
-      cw[kk] = make_double2(b.x, -b.y);
-      v[kk] = vcur[r0 + cb];
+    v[kk] = col[kk] = make_double2(0.0, 0.0);
+    if (cb < Lb) v[kk] = vcur[r0 + cb];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      cw[q][kk] = cv[q][kk] = make_double2(0.0, 0.0);
+      if (cb < Lb) {
+        const double2 a = pv[(int64_t)q * n + r0 + cb], b = pw[(int64_t)q * n + r0 + cb];
+        cv[q][kk] = make_double2(a.x, -a.y);
+        cw[q][kk] = make_double2(b.x, -b.y);
+      }
     }
   }
   __syncthreads();
@@ -308,15 +368,21 @@ __global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
     for (int q = 0; q < RI; ++q) {
       const int d = d0 + q;
       if (d < nrows) {
-        const double2 vpi = s_vp[d], wpi = s_wp[d], vr = s_vr[d];
+        const double2 vr = s_vr[d];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
           const int cb = (wave + 4 * kk) * 64 + lane;
           if (cb < Lb && cb >= d) {
             double2 x = a[q][kk];
-            x.x -= vpi.x * cw[kk].x - vpi.y * cw[kk].y + wpi.x * cv[kk].x - wpi.y * cv[kk].y;
-            x.y -= vpi.x * cw[kk].y + vpi.y * cw[kk].x + wpi.x * cv[kk].y + wpi.y * cv[kk].x;
-            row[q][cb] = x;
+            if (NP > 0) {
+#pragma unroll
+              for (int u = 0; u < NP; ++u) {
+                const double2 vpi = s_vp[u][d], wpi = s_wp[u][d];
+                x.x -= vpi.x * cw[u][kk].x - vpi.y * cw[u][kk].y + wpi.x * cv[u][kk].x - wpi.y * cv[u][kk].y;
+                x.y -= vpi.x * cw[u][kk].y + vpi.y * cw[u][kk].x + wpi.x * cv[u][kk].y + wpi.y * cv[u][kk].x;
+              }
+              row[q][cb] = x;
+            }
             acc[2 * q] += x.x * v[kk].x - x.y * v[kk].y;
             acc[2 * q + 1] += x.x * v[kk].y + x.y * v[kk].x;
             if (cb > d) {  // conj(a) v_r

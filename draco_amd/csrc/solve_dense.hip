@@ -39,6 +39,41 @@
 
 namespace {
 
+// One sweep over the trailing matrix of column tp.j.  np_pend = rank-2 updates pending at this point; the sweep
+// applies them all once their number reaches what the kernel variant keeps in registers (4 pairs at three column
+// chunks per wave, 2 at six, 1 at eight or with full-matrix storage), otherwise it only reads.  Returns through
+// np_pend the number still pending afterwards.
+template <int KK, int NB>
+void td_launch_tri(TdParams& tp, int& np_pend, dim3 grid, hipStream_t st) {
+  tp.np = np_pend;
+  if (np_pend < NB) {
+    hipLaunchKernelGGL((k_td_trail_tri<KK, 0>), grid, dim3(kThreads), 0, st, tp);
+  } else {
+    hipLaunchKernelGGL((k_td_trail_tri<KK, NB>), grid, dim3(kThreads), 0, st, tp);
+    np_pend = 0;
+  }
+}
+
+void td_launch_trail(TdParams& tp, int& np_pend, int nmat, hipStream_t st) {
+  const int n = tp.d.Np, j = tp.j;
+  const dim3 grid((n - j - 1 + kTdRows - 1) / kTdRows, nmat);
+  if (!tp.tri) {
+    tp.np = np_pend;  // 0 (first column) or 1
+    hipLaunchKernelGGL(k_td_trail, grid, dim3(kThreads), (size_t)3 * (n - j - 1) * sizeof(double2), st, tp);
+    np_pend = 0;
+  } else if (n <= 768) {
+    td_launch_tri<3, 4>(tp, np_pend, grid, st);
+  } else if (n <= 1536) {
+    td_launch_tri<6, 2>(tp, np_pend, grid, st);
+  } else {
+    td_launch_tri<8, 1>(tp, np_pend, grid, st);
+  }
+}
+
+}  // namespace
+
+namespace {
+
 // ---------------------------------------------------------------- ML: certificate of "nothing cut"
 // X[mat][k][i] = d_i conj(B[i][k]): the rows of (D B)^H, so that the NT tile product gives B^H Ni B
 __global__ __launch_bounds__(kThreads) void k_xpose(DenseParams p, double2* X) {
@@ -573,21 +608,13 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         DMM_HIP(hipMemsetAsync(fail_d, 0, nsel * sizeof(int), ctx->stream));
         const size_t col_lds = (size_t)3 * n * sizeof(double2);
         const size_t sol_lds = (size_t)n * (sizeof(double2) + 2 * sizeof(double));
+        int np_pend = 0;
         for (int j = 0; j < n; ++j) {
           tp.j = j;
+          tp.np = np_pend;
           hipLaunchKernelGGL(k_td_col, dim3(nsel), dim3(kThreads), col_lds, ctx->stream, tp);
-          if (j < n - 1) {
-            const dim3 grid((n - j - 1 + kTdRows - 1) / kTdRows, nsel);
-            const size_t tri_lds = 0;
-            if (!tp.tri)
-              hipLaunchKernelGGL(k_td_trail, grid, dim3(kThreads), (size_t)3 * (n - j - 1) * sizeof(double2), ctx->stream, tp);
-            else if (n <= 768)
-              hipLaunchKernelGGL(k_td_trail_tri<3>, grid, dim3(kThreads), tri_lds, ctx->stream, tp);
-            else if (n <= 1536)
-              hipLaunchKernelGGL(k_td_trail_tri<6>, grid, dim3(kThreads), tri_lds, ctx->stream, tp);
-            else
-              hipLaunchKernelGGL(k_td_trail_tri<8>, grid, dim3(kThreads), tri_lds, ctx->stream, tp);
-          }
+          if (j >= 1) ++np_pend;  // k_td_col has completed the pair of column j-1
+          if (j < n - 1) td_launch_trail(tp, np_pend, nsel, ctx->stream);
         }
         hipLaunchKernelGGL(k_td_solve, dim3(nsel), dim3(kThreads), sol_lds, ctx->stream, tp);
         DMM_HIP(hipGetLastError());
@@ -761,20 +788,13 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
     const size_t col_lds = (size_t)3 * n * sizeof(double2);
     const size_t sol_lds = (size_t)n * (sizeof(double2) + 2 * sizeof(double));
+    int np_pend = 0;
     for (int j = 0; j < n; ++j) {
       tp.j = j;
+      tp.np = np_pend;
       hipLaunchKernelGGL(k_td_col, dim3(nmat), dim3(kThreads), col_lds, S1, tp);
-      if (j < n - 1) {
-        const dim3 grid((n - j - 1 + kTdRows - 1) / kTdRows, nmat);
-        if (!tp.tri)
-          hipLaunchKernelGGL(k_td_trail, grid, dim3(kThreads), (size_t)3 * (n - j - 1) * sizeof(double2), S1, tp);
-        else if (n <= 768)
-          hipLaunchKernelGGL(k_td_trail_tri<3>, grid, dim3(kThreads), 0, S1, tp);
-        else if (n <= 1536)
-          hipLaunchKernelGGL(k_td_trail_tri<6>, grid, dim3(kThreads), 0, S1, tp);
-        else
-          hipLaunchKernelGGL(k_td_trail_tri<8>, grid, dim3(kThreads), 0, S1, tp);
-      }
+      if (j >= 1) ++np_pend;
+      if (j < n - 1) td_launch_trail(tp, np_pend, nmat, S1);
     }
     DMM_HIP(hipGetLastError());
     DMM_HIP(hipEventRecord(ctx->aux_ev[h], S1));
