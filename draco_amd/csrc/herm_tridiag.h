@@ -10,12 +10,17 @@
 // everything after the reduction.
 //
 // Kernels (all batched over the selected matrices of a sub-batch):
-//   k_td_col    one block per matrix, per column j: finish w_{j-1}, form column j with the pending rank-2
-//               update, generate the Householder reflector (the zlarfg rule)
-//   k_td_trail  one pass over the trailing matrix per column: apply the pending rank-2 update of step j-1
-//               and form A v_j in the same sweep (HBM bound: 32 bytes per trailing element and column)
-//   k_td_solve  one block per matrix: b, Q^H b, QL with the rotations applied forward to the vector and logged,
-//               the cut, the logged rotations backwards, Q y, output
+//   k_td_col        one block per matrix, per column j: finish w_{j-1} (the product A v comes from the sweep over
+//                   the STORED matrix and is corrected for the rank-2 updates still pending), form column j with the
+//                   pending updates, generate the Householder reflector (the zlarfg rule)
+//   k_td_trail_tri  one sweep over the upper triangle of the trailing matrix per column: A v_j (row and transposed
+//                   contributions of every element); every fourth sweep also applies the pending updates
+//                   (HBM bound: 16 bytes per trailing element when it only reads, 32 when it applies)
+//   k_td_trail      the same on full-matrix storage, one pending update per sweep (orders above 2048, tests)
+//   k_td_solve      one block per matrix: b, Q^H b, QL (serial chases, every rotation logged), the logged chases
+//                   replayed on the vector as a systolic pipeline over a wave's lanes (forwards: S^T z), the cut,
+//                   backwards (S g), Q y, output.  The host runs it on a second stream under the next half-batch's
+//                   sweeps (solve_dense.hip).
 #ifndef DMM_HERM_TRIDIAG_H
 #define DMM_HERM_TRIDIAG_H
 
