@@ -192,7 +192,7 @@ class Job:
         from draco_amd.analysis._solve import Slab
         from draco_amd.core.products import SyntheticProvider, TransitTelescope
         from draco_amd.device import Context
-        from oracle import synth as osyn  # shapes only (CONFIGS); no oracle compute here
+        from draco_amd import workloads as osyn
 
         self.torch = torch
         self.ctx = ctx = Context.get()
@@ -317,9 +317,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import synth as _osyn
+        from draco_amd import workloads as _wl  # (the oracle is imported inside cpu_baseline only)
 
-        cpu = cpu_baseline(_osyn.CONFIGS[args.config], args.cpu_seconds)  # before any GPU work: it spawns processes
+        cpu = cpu_baseline(_wl.CONFIGS[args.config], args.cpu_seconds)  # before any GPU work: it spawns processes
 
     import torch
     import torch.distributed as dist
@@ -330,7 +330,7 @@ def main():
     else:
         torch.cuda.set_device(0)
 
-    from oracle import synth as osyn
+    from draco_amd import workloads as osyn
 
     cfg = osyn.CONFIGS[args.config]
     job = Job(cfg, rank, args.b_dtype, args.pool_freqs, overlap=not args.no_overlap)

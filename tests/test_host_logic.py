@@ -100,3 +100,46 @@ def test_task_config():
     assert w.prior_amp == 2.0 and isinstance(w.prior_amp, float) and w.prior_tilt == 0.5 and w.nside == 64
     with pytest.raises(AttributeError):
         WienerMapMaker(bogus=1)
+
+
+def test_workloads_match_the_oracles_table():
+    """bench.py / tools take the BASELINE workloads from the package; the checker keeps its own copy."""
+    from draco_amd import workloads
+    from oracle import synth as osyn
+
+    assert workloads.CONFIGS == osyn.CONFIGS
+    assert np.array_equal(workloads.frequencies(64), osyn.frequencies(64))
+
+
+def test_oracle_is_imported_only_where_it_may_be():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/ (test infrastructure)."""
+    import ast
+    import pathlib
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+
+    def oracle_imports(path):
+        tree = ast.parse(path.read_text())
+        hits = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] == "oracle":
+                hits.append(node.lineno)
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                hits.append(node.lineno)
+        return hits
+
+    for path in list((root / "draco_amd").rglob("*.py")) + list((root / "tools").rglob("*.py")):
+        assert not oracle_imports(path), path
+    # bench.py: inside cpu_baseline and its worker only
+    tree = ast.parse((root / "bench.py").read_text())
+    allowed = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("cpu_baseline", "_cpu_worker"):
+            allowed.update(range(node.lineno, node.end_lineno + 1))
+    assert all(ln in allowed for ln in oracle_imports(root / "bench.py"))
+    tree = ast.parse((root / "__graft_entry__.py").read_text())
+    allowed = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "smoke":
+            allowed.update(range(node.lineno, node.end_lineno + 1))
+    assert all(ln in allowed for ln in oracle_imports(root / "__graft_entry__.py"))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""ML timing and accuracy vs the oracle SVD on sampled tiles: all m of one frequency.
+"""ML timing over all m of a few frequencies (accuracy against the oracle's SVD is the tests' job: tests/test_gpu_dense.py).
 
     python tools/ml_tune.py [config [nfreq [modes [ml_eigen]]]]
     modes (ml_shortcut): 0 certified shortcut (default), 2 eigen path always, 3 telescope side only;
@@ -24,8 +24,7 @@ def main():
     from draco_amd.analysis.transform import mmode_forward
     from draco_amd.core.products import SyntheticProvider, TransitTelescope
     from draco_amd.device import Context
-    from oracle import mapmaker as omm
-    from oracle import synth as osyn
+    from draco_amd import workloads as osyn
 
     cfgn = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -41,9 +40,6 @@ def main():
     vis = torch.randn((nf, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
     w = torch.rand((nf, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) * 40 + 10
     mv, mw = mmode_forward(ctx, vis, w, lmax)
-    mvh, mwh = mv.cpu().numpy(), mw.cpu().numpy()
-    ms = [0, lmax // 3, (2 * lmax) // 3, lmax - 2]
-    refs = {m: omm.ml_solve(osyn.beam_tile(5, m, 0, tel.npairs, 4, lmax), mvh[m, :, 0], mwh[m, :, 0]) for m in ms}
     fl = list(range(nf))
     eng.solve("ml", mv, mw, fl, lmax, acond=1e-4, rcond=1e-3)
     import ctypes as C
@@ -63,8 +59,7 @@ def main():
         alm = eng.solve("ml", mv, mw, fl, lmax, acond=1e-4, rcond=1e-3)
         ctx.sync()
         dt = time.perf_counter() - t0
-        err = max(np.abs(alm[0, :, m, :].cpu().numpy() - refs[m]).max() / np.abs(refs[m]).max() for m in ms)
-        print(json.dumps({"cfg": cfgn, "mode": label, "ml_eigen": eig, "nfreq": nf, "ms_per_tile": dt * 1e3 / (nf * (lmax + 1)), "total_s": dt, "max_rel_err": err,
+        print(json.dumps({"cfg": cfgn, "mode": label, "ml_eigen": eig, "nfreq": nf, "ms_per_tile": dt * 1e3 / (nf * (lmax + 1)), "total_s": dt,
                           "tiles_direct": counter(b"ml_tiles_direct") - d0, "tiles_eigen": counter(b"ml_tiles_eigen") - e0}), flush=True)
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
 

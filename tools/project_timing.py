@@ -17,7 +17,7 @@ def main():
     from draco_amd.analysis._solve import SolveEngine
     from draco_amd.core.products import SyntheticProvider, TransitTelescope
     from draco_amd.device import Context
-    from oracle import synth as osyn
+    from draco_amd import workloads as osyn
 
     cfgn = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 8

@@ -35,7 +35,7 @@ def main():
     from draco_amd.device import Context
     from draco_amd.synthesis.noise import GaussianNoise
     from draco_amd.synthesis.stream import SimulateSidereal
-    from oracle import synth as osyn  # config shapes only
+    from draco_amd import workloads as osyn
 
     cfg = dict(osyn.CONFIGS[args.config])
     if args.nfreq:

@@ -29,7 +29,7 @@ def main():
     from draco_amd.analysis.transform import mmode_forward, mmode_inverse
     from draco_amd.core.products import SyntheticProvider, TransitTelescope
     from draco_amd.device import Context, ptr
-    from oracle import synth as osyn
+    from draco_amd import workloads as osyn
 
     cfg = osyn.CONFIGS[args.config]
     ctx = Context.get()

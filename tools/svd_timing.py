@@ -23,7 +23,7 @@ def main():
     from draco_amd.analysis.svdfilter import _decompose
     from draco_amd.core.products import TransitTelescope
     from draco_amd.device import Context
-    from oracle import synth as osyn
+    from draco_amd import workloads as osyn
 
     cfg = osyn.CONFIGS[a.config]
     ctx = Context.get()

@@ -16,7 +16,7 @@ def main():
     import bench
     from draco_amd import _lib
     from draco_amd.device import ptr
-    from oracle import synth as osyn
+    from draco_amd import workloads as osyn
 
     cfg = osyn.CONFIGS[3]
     dtype = sys.argv[1] if len(sys.argv) > 1 else "complex128"
