@@ -3,7 +3,9 @@
 
     python tools/ml_tune.py [config [nfreq [modes [ml_eigen]]]]
     modes (ml_shortcut): 0 certified shortcut (default), 2 eigen path always, 3 telescope side only;
-    ml_eigen: 0 by batch size (default), 4 tridiagonalisation + QL, 1 blocked Jacobi
+    ml_eigen: 0 by batch size (default), 4 tridiagonalisation + QL, 1 blocked Jacobi;
+    a fifth argument `ill` spreads the noise weights over eight decades, so that no tile passes the certificate
+    (the situation with real, ill-conditioned beam transfers) while the default options stay in force
 """
 import json
 import os
@@ -39,6 +41,8 @@ def main():
     gen = torch.Generator(device=ctx.device).manual_seed(7)
     vis = torch.randn((nf, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
     w = torch.rand((nf, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) * 40 + 10
+    if len(sys.argv) > 5 and sys.argv[5] == "ill":  # one weight per baseline, 1 ... 1e-8
+        w = w * torch.pow(10.0, -8.0 * torch.rand((nf, tel.npairs, 1), dtype=torch.float32, device=ctx.device, generator=gen))
     mv, mw = mmode_forward(ctx, vis, w, lmax)
     fl = list(range(nf))
     eng.solve("ml", mv, mw, fl, lmax, acond=1e-4, rcond=1e-3)
