@@ -374,6 +374,44 @@ def test_ml_eigen_path_degenerate_tiles(variant):
 
 
 @pytest.mark.parametrize("variant", [4, 1])
+def test_ml_weights_over_eight_decades(variant):
+    """Well-conditioned beam transfers but noise weights spread over 1 ... 1e-8 (one per baseline): the weighted
+    matrix D B is ill conditioned, the certificate fails at low m, and the reference's cut drops the baselines whose
+    weight is negligible.  Against the oracle's SVD of D B."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    nfreq, lmax = 1, 40
+    tel = _tel(nfreq, lmax, 2, 4)
+    bt = SyntheticProvider(tel, seed=909)
+    rng = np.random.default_rng(8)
+    shape = (lmax + 1, 2, nfreq, tel.npairs)
+    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    mw = np.broadcast_to(10.0 ** (-8.0 * rng.uniform(size=(1, 2, nfreq, tel.npairs))), shape) * 30.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    beam = lambda m, f: osyn.beam_tile(909, m, f, tel.npairs, 4, lmax)  # noqa: E731
+    ref = omm.solve_alm("ml", beam, mv, np.array(mw), lmax, tel.mmax, [0])
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", variant))
+        e0 = _counter(ctx, b"ml_tiles_eigen")
+        task = MaximumLikelihoodMapMaker()
+        task.setup(bt)
+        out = task.alm_square(task.make_alm(mm))
+        assert _counter(ctx, b"ml_tiles_eigen") - e0 > 0
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+    for m in range(lmax + 1):
+        err = np.abs(out[..., m] - ref[..., m]).max() / np.abs(ref[..., m]).max()
+        assert err < 1e-7, (m, err)
+
+
+@pytest.mark.parametrize("variant", [4, 1])
 def test_ml_ill_conditioned_tiles(variant):
     """Beam transfers with a geometric singular spectrum (1 ... 1e-8, the regime of real telescopes): about a third of
     the modes survive pinv_svd's relative cut at 1e-3.  The Gram route squares the condition number, so a kept mode
