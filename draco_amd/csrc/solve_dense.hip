@@ -70,6 +70,26 @@ void td_launch_trail(TdParams& tp, int& np_pend, int nmat, hipStream_t st) {
   }
 }
 
+// Householder reduction of the launch's matrices to tridiagonal form: n column steps (k_td_col) and n-1 sweeps.
+void td_reduce(TdParams& tp, int nmat, hipStream_t st) {
+  const int n = tp.d.Np;
+  const size_t col_lds = (size_t)3 * n * sizeof(double2);
+  int np_pend = 0;
+  for (int j = 0; j < n; ++j) {
+    tp.j = j;
+    tp.np = np_pend;
+    hipLaunchKernelGGL(k_td_col, dim3(nmat), dim3(kThreads), col_lds, st, tp);
+    if (j >= 1) ++np_pend;  // k_td_col has completed the pair of column j-1
+    if (j < n - 1) td_launch_trail(tp, np_pend, nmat, st);
+  }
+}
+
+// QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
+void td_solve(const TdParams& tp, int nmat, hipStream_t st) {
+  const size_t sol_lds = (size_t)tp.d.Np * (sizeof(double2) + 2 * sizeof(double));
+  hipLaunchKernelGGL(k_td_solve, dim3(nmat), dim3(kThreads), sol_lds, st, tp);
+}
+
 }  // namespace
 
 namespace {
@@ -606,17 +626,8 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.fail = fail_d;
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         DMM_HIP(hipMemsetAsync(fail_d, 0, nsel * sizeof(int), ctx->stream));
-        const size_t col_lds = (size_t)3 * n * sizeof(double2);
-        const size_t sol_lds = (size_t)n * (sizeof(double2) + 2 * sizeof(double));
-        int np_pend = 0;
-        for (int j = 0; j < n; ++j) {
-          tp.j = j;
-          tp.np = np_pend;
-          hipLaunchKernelGGL(k_td_col, dim3(nsel), dim3(kThreads), col_lds, ctx->stream, tp);
-          if (j >= 1) ++np_pend;  // k_td_col has completed the pair of column j-1
-          if (j < n - 1) td_launch_trail(tp, np_pend, nsel, ctx->stream);
-        }
-        hipLaunchKernelGGL(k_td_solve, dim3(nsel), dim3(kThreads), sol_lds, ctx->stream, tp);
+        td_reduce(tp, nsel, ctx->stream);
+        td_solve(tp, nsel, ctx->stream);
         DMM_HIP(hipGetLastError());
         td_fail_h.assign(nsel, 0);
         DMM_HIP(hipMemcpyAsync(td_fail_h.data(), fail_d, nsel * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -786,20 +797,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.fail = fail_hd;
     tp.tri = n <= 2048 ? 1 : 0;
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
-    const size_t col_lds = (size_t)3 * n * sizeof(double2);
-    const size_t sol_lds = (size_t)n * (sizeof(double2) + 2 * sizeof(double));
-    int np_pend = 0;
-    for (int j = 0; j < n; ++j) {
-      tp.j = j;
-      tp.np = np_pend;
-      hipLaunchKernelGGL(k_td_col, dim3(nmat), dim3(kThreads), col_lds, S1, tp);
-      if (j >= 1) ++np_pend;
-      if (j < n - 1) td_launch_trail(tp, np_pend, nmat, S1);
-    }
+    td_reduce(tp, nmat, S1);
     DMM_HIP(hipGetLastError());
     DMM_HIP(hipEventRecord(ctx->aux_ev[h], S1));
     DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
-    hipLaunchKernelGGL(k_td_solve, dim3(nmat), dim3(kThreads), sol_lds, S2, tp);
+    td_solve(tp, nmat, S2);
     DMM_HIP(hipGetLastError());
     if (!sky) {  // back-projection a = B^H w of the half's tiles, behind its solve on the second stream
       ctx->stream = S2;
