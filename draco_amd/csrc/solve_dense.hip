@@ -893,6 +893,18 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       int rc = certify(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first);
       if (rc) return rc;
     }
+  // A handful of rejected sky-side tiles spread over many padded orders would pay one launch chain (and its latency
+  // floor) per order: they are decomposed together at the largest of their orders instead (order_of() keeps every
+  // tile's own size; the padding is zeros).
+  size_t nsky_def = 0;
+  for (auto& kv : sky_deferred) nsky_def += kv.second.size();
+  if (sky_deferred.size() > 1 && nsky_def <= 128) {
+    std::vector<int64_t> all;
+    for (auto& kv : sky_deferred) all.insert(all.end(), kv.second.begin(), kv.second.end());
+    const int np_max = sky_deferred.rbegin()->first;
+    sky_deferred.clear();
+    sky_deferred[np_max] = all;
+  }
   int rc = eigen_list(tel_deferred, false, 0);
   for (auto& kv : sky_deferred)
     if (!rc) rc = eigen_list(kv.second, true, kv.first);
