@@ -20,6 +20,31 @@ _ELEM = {_lib.DMM_C64: 8, _lib.DMM_C128: 16}
 _TORCH = {_lib.DMM_C64: torch.complex64, _lib.DMM_C128: torch.complex128}
 
 
+# One multi-slab pool per device, kept between passes (a day's map-making is several passes: simulate, dirty, Wiener
+# ...): pools are a large fraction of the HBM, and handing one back to the caching allocator only to ask for a
+# slightly different size a moment later ends in a second pool-sized allocation.  Contents never outlive a slab.
+_POOLS: dict[int, torch.Tensor] = {}
+
+
+def _take_pool(ctx, nelem, b_dtype):
+    """A ``[nelem]`` tensor of the B storage type on the context's device, carved from the kept pool when it fits."""
+    need = int(nelem) * _ELEM[b_dtype]
+    kept = _POOLS.get(ctx.device_index)
+    if kept is None or kept.numel() < need:
+        _POOLS.pop(ctx.device_index, None)
+        del kept
+        torch.cuda.empty_cache()  # give the old block back before asking for a larger one
+        kept = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+        _POOLS[ctx.device_index] = kept
+    return kept[:need].view(_TORCH[b_dtype])
+
+
+def release_pools():
+    """Give the kept pools back (to the caching allocator, and on to the device)."""
+    _POOLS.clear()
+    torch.cuda.empty_cache()
+
+
 class Slab:
     """A resident pool of B tiles + the plan that solves them."""
 
@@ -79,12 +104,14 @@ class SolveEngine:
         if self.pool_bytes is not None:
             return int(self.pool_bytes)
         free, _total = torch.cuda.mem_get_info(self.ctx.device)
-        return int(free * 0.6)
+        kept = _POOLS.get(self.ctx.device_index)  # the previous pass's pool is ours to take again
+        return int((free + (kept.numel() if kept is not None else 0)) * 0.6)
 
     def _slab_ranges(self, ms):
-        """Split the tile list into consecutive ranges whose pool fits the budget."""
+        """Split the tile list into consecutive ranges whose pool fits the budget; also the largest range's size
+        in elements (the one pool every slab of the pass is filled into)."""
         budget = self._budget() // _ELEM[self.b_dtype]
-        ranges, start, acc = [], 0, 0
+        ranges, start, acc, largest = [], 0, 0, 0
         for i, m in enumerate(ms):
             n = self.provider.tile_elems(int(m), self.b_layout)
             n += n & 1
@@ -92,9 +119,11 @@ class SolveEngine:
                 raise MemoryError(f"one B tile ({n} elements) exceeds the pool budget ({budget})")
             if acc + n > budget:
                 ranges.append((start, i))
+                largest = max(largest, acc)
                 start, acc = i, 0
             acc += n
         ranges.append((start, len(ms)))
+        self._pool_elems = max(largest, acc)
         return ranges
 
     def slabs(self, freq_ind, mmax, nfreq_data, n_m):
@@ -114,7 +143,9 @@ class SolveEngine:
             self._cached_key, self._cached_slabs = key, [s]
             yield s
             return
-        pool = None
+        # one pool for the whole pass, sized for its largest slab (slabs differ by a few tiles: growing the pool
+        # for a later one would need a second pool-sized allocation while the first is still alive)
+        pool = _take_pool(self.ctx, max(self._pool_elems, 1), self.b_dtype)
         for a, b in ranges:
             s = Slab(self.ctx, self.provider, ms[a:b], fs_data[a:b], fs_bt[a:b], self.b_dtype, self.b_layout, nfreq_data, n_m, pool)
             pool = s.pool

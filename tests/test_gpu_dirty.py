@@ -197,3 +197,33 @@ def test_project_vs_oracle():
         ref = np.stack([osyn.beam_tile(9, mi, f, tel.npairs, 4, 14).reshape(bt.ntel, -1) @ vec[f].reshape(-1) for f in range(3)])
         assert out.shape == (3, bt.ntel)
         assert _rel(out, ref) < 1e-13
+
+
+def test_slabs_share_one_pool_sized_for_the_largest():
+    """Slabs are cut where the budget is reached, so their sizes differ by a few tiles and a later one may be larger
+    than the first: the pool is allocated once, for the largest (growing it would need a second pool-sized block while
+    the first is alive -- 168 GB twice at cfg 3)."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis import _solve
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    tel = _tel(3, 30, 1, 4)
+    bt = SyntheticProvider(tel, seed=21)
+    gen = torch.Generator(device=ctx.device).manual_seed(2)
+    shape = (31, 2, 3, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen)
+    ref = _solve.SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED).solve("dirty", mv, mw, [0, 1, 2], 30).cpu().numpy()
+    eng = _solve.SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, pool_bytes=400_000, cache=False)
+    pools, sizes = set(), []
+    for slab in eng.slabs([0, 1, 2], 30, 3, 31):
+        pools.add(slab.pool.data_ptr())
+        sizes.append(slab.nelem)
+        assert slab.nelem <= slab.pool.numel()
+    assert len(sizes) >= 4 and len(pools) == 1
+    assert max(sizes[1:]) > sizes[0]  # the case that used to re-allocate
+    assert np.array_equal(eng.solve("dirty", mv, mw, [0, 1, 2], 30).cpu().numpy(), ref)
