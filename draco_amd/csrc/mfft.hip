@@ -153,6 +153,7 @@ struct BeamParams {
   const double* coef_b;
   float2* out;  // [mmax+1, 2, nrow]
   int mmax, mlim, mlim_neg;
+  int tw_lds;
 };
 
 // Analytic transit beam (ringmapmaker.py:1019-1025,1046-1064), conjugated (:1066), generated straight into the LDS
@@ -161,15 +162,17 @@ template <bool BLUESTEIN>
 __global__ __launch_bounds__(kThreads) void k_beam_mfft(BeamParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   C<double>* buf = reinterpret_cast<C<double>*>(smem);
-  C<double>* tw = buf + (size_t)p.RB * p.P;
+  C<double>* tw_s = buf + (size_t)p.RB * p.P;
+  const C<double>* tw = p.tw_lds ? tw_s : reinterpret_cast<const C<double>*>(p.tw);
   __shared__ double s_u[16], s_is2[16];
   const int N = p.N, M = p.M, RB = p.RB, P = p.P;
   const int64_t r0 = (int64_t)blockIdx.x * RB;
 
-  for (int k = threadIdx.x; k < (M >> 1); k += kThreads) {
-    const double2 w = p.tw[k];
-    tw[k] = {w.x, w.y};
-  }
+  if (p.tw_lds)
+    for (int k = threadIdx.x; k < (M >> 1); k += kThreads) {
+      const double2 w = p.tw[k];
+      tw_s[k] = {w.x, w.y};
+    }
   if (threadIdx.x < RB && r0 + threadIdx.x < p.nrow) {
     int64_t r = r0 + threadIdx.x;
     const int el = (int)(r % p.nel);
@@ -250,6 +253,7 @@ struct MifftParams {
   int mmax_plus, mmax_minus;
   const double* mscale;
   float2* out;  // [nrow, N]
+  int tw_lds;   // twiddles staged in LDS (0: read from the table in memory)
 };
 
 // Inverse: gather the +/-m slots into FFT order (transform.py:838-849), run
@@ -259,14 +263,16 @@ template <bool BLUESTEIN>
 __global__ __launch_bounds__(kThreads) void k_mifft_unpack(MifftParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   C<double>* buf = reinterpret_cast<C<double>*>(smem);
-  C<double>* tw = buf + (size_t)p.RB * p.P;
+  C<double>* tw_s = buf + (size_t)p.RB * p.P;
+  const C<double>* tw = p.tw_lds ? tw_s : reinterpret_cast<const C<double>*>(p.tw);
   const int N = p.N, M = p.M, RB = p.RB, P = p.P;
   const int64_t r0 = (int64_t)blockIdx.x * RB;
 
-  for (int k = threadIdx.x; k < (M >> 1); k += kThreads) {
-    const double2 w = p.tw[k];
-    tw[k] = {w.x, w.y};
-  }
+  if (p.tw_lds)
+    for (int k = threadIdx.x; k < (M >> 1); k += kThreads) {
+      const double2 w = p.tw[k];
+      tw_s[k] = {w.x, w.y};
+    }
   // transposed gather: consecutive threads -> consecutive rows of one (m, s) slot
   for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
     const int r = idx % RB, k = idx / RB;
@@ -455,7 +461,9 @@ int get_tables(std::map<int, dmm_fft_tables>& cache, int n, dmm_fft_tables** out
 }
 
 // rows per block and LDS bytes for an M-point transform with elem-byte elements
-bool choose_rb(int M, size_t elem, int64_t nrow, int* RB, int* P, size_t* lds) {
+// tw_lds (optional): set to 0 when only the row fits the LDS and the twiddles have to be read from memory instead
+// (double-precision Bluestein transforms of 2049 ... 4096 points: M = 8192)
+bool choose_rb(int M, size_t elem, int64_t nrow, int* RB, int* P, size_t* lds, int* tw_lds = nullptr) {
   const size_t tw = (size_t)(M / 2) * elem;
   *P = M + 1;
   int rb = 16;
@@ -463,6 +471,11 @@ bool choose_rb(int M, size_t elem, int64_t nrow, int* RB, int* P, size_t* lds) {
   while (rb > 1 && rb / 2 >= nrow) rb >>= 1;
   *lds = (size_t)rb * (*P) * elem + tw;
   *RB = rb;
+  if (tw_lds) *tw_lds = 1;
+  if (*lds > 160 * 1024 && tw_lds && rb == 1 && (size_t)(*P) * elem <= 160 * 1024) {
+    *tw_lds = 0;
+    *lds = (size_t)(*P) * elem;
+  }
   return *lds <= 160 * 1024;
 }
 
@@ -535,7 +548,7 @@ int dmm_analytic_beam_mmodes(dmm_ctx* ctx, int npol, int nfreq, int new_, int ne
   p.M = t->M;
   p.logM = ilog2(t->M);
   size_t lds = 0;
-  if (!choose_rb(p.M, sizeof(double2), nrow, &p.RB, &p.P, &lds))
+  if (!choose_rb(p.M, sizeof(double2), nrow, &p.RB, &p.P, &lds, &p.tw_lds))
     return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_analytic_beam_mmodes: nra=%d needs %zu B of LDS", nra, lds);
   p.tw = (const double2*)t->tw;
   p.chirp = (const double2*)t->chirp;
@@ -595,7 +608,7 @@ int dmm_mifft_unpack(dmm_ctx* ctx, const void* mvis, int n_m, int64_t nrow, int 
   p.M = t->M;
   p.logM = ilog2(t->M);
   size_t lds = 0;
-  if (!choose_rb(p.M, sizeof(double2), nrow, &p.RB, &p.P, &lds))
+  if (!choose_rb(p.M, sizeof(double2), nrow, &p.RB, &p.P, &lds, &p.tw_lds))
     return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_mifft_unpack: nra=%d needs %zu B of LDS", nra, lds);
   p.tw = (const double2*)t->tw;
   p.chirp = (const double2*)t->chirp;

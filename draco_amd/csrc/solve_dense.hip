@@ -824,6 +824,10 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const int eig = ctx->opt_ml_eigen;
     const bool pipelined = capE >= 1 && (eig == 4 || eig == 3 || (eig == 0 && (double)std::min<size_t>(capE, list.size()) * np >= 12000.0));
     if (!pipelined) {
+      // the synchronous batches use the whole workspace: nothing of the pipeline may still be in flight in it
+      int rc = retire(0);
+      if (!rc) rc = retire(1);
+      if (rc) return rc;
       for (size_t i0 = 0; i0 < list.size(); i0 += cap) {
         int rc = run_batch(list, i0, (int)std::min<size_t>(cap, list.size() - i0), sky, np_sky, true);
         if (rc) return rc;

@@ -166,9 +166,9 @@ def test_analytic_beam_reference_golden(golden_dir):
             assert np.abs(ds[:] - r).max() < 5e-6 * np.abs(r).max(), (i, name)
 
 
-@pytest.mark.parametrize("mmax,oddra,nel,nfreq", [(64, False, 33, 2), (100, True, 7, 3), (512, False, 5, 1), (300, False, 4, 2)])
+@pytest.mark.parametrize("mmax,oddra,nel,nfreq", [(64, False, 33, 2), (100, True, 7, 3), (512, False, 5, 1), (300, False, 4, 2), (1024, True, 2, 1)])
 def test_analytic_beam_vs_oracle(mmax, oddra, nel, nfreq):
-    """nra = 128 / 1024 (radix-2) and 201 / 600 (Bluestein) against the float64 oracle."""
+    """nra = 128 / 1024 (radix-2) and 201 / 600 / 2049 (Bluestein; the last at M = 8192) against the float64 oracle."""
     from draco_amd.analysis.ringmapmaker import TikhonovRingMapMakerAnalytical
     from draco_amd.core import containers
 

@@ -160,7 +160,7 @@ def test_inverse_task_golden(T, golden_dir):
         assert np.array_equal(mm.vis[:], mv)
 
 
-@pytest.mark.parametrize("N", [64, 127, 1000, 1024, 2047])
+@pytest.mark.parametrize("N", [64, 127, 1000, 1024, 2047, 2049, 4095])  # the last two: Bluestein at M = 8192, twiddles read from memory
 def test_inverse_vs_oracle(T, N):
     rng = np.random.default_rng(N)
     mmax = N // 2

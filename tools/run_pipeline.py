@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--makers", nargs="*", default=["dirty", "wiener"])
     ap.add_argument("--noise", action="store_true")
     ap.add_argument("--nfreq", type=int, default=0, help="override the number of frequencies")
+    ap.add_argument("--pool-gb", type=float, default=0.0, help="B pool budget in GB (default: 0.6 of the free HBM)")
     args = ap.parse_args()
 
     import torch
@@ -70,9 +71,11 @@ def main():
         out = fn()
         ctx.sync()
         report[name + "_s"] = round(time.perf_counter() - t0, 4)
+        print(f"[run_pipeline] {name}: {report[name + '_s']} s", file=sys.stderr, flush=True)
         return out
 
-    sim = SimulateSidereal()
+    pool = int(args.pool_gb * 1e9) if args.pool_gb > 0 else None
+    sim = SimulateSidereal(pool_bytes=pool)
     sim.setup(bt)
     ss = timed("SimulateSidereal", lambda: sim.process(mp))
     if args.noise:
@@ -84,7 +87,7 @@ def main():
     mm = timed("MModeTransform", lambda: tr.process(ss))
     makers = {"dirty": DirtyMapMaker, "wiener": WienerMapMaker, "ml": MaximumLikelihoodMapMaker}
     for name in args.makers:
-        task = makers[name](nside=nside)
+        task = makers[name](nside=nside, pool_bytes=pool)
         task.setup(bt)
         timed(name + "_first_call(incl. B fill)", lambda: task.process(mm))
         out = timed(name, lambda: task.process(mm))
