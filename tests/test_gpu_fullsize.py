@@ -201,3 +201,37 @@ def test_cfg4_sht_roundtrip_nside512():
     _lib.check(_lib.lib.dmm_map2alm(ctx.handle, ptr(maps), 1, 4, lmax, lmax, nside, 8, ptr(back)))
     err8 = float((back - alm).abs().max()) / float(alm.abs().max())
     assert err8 < 0.5 * err, (err, err8)  # and the iteration converges
+
+
+def test_cfg3_ml_eigen_pass_mixes_pipelined_and_synchronous_batches():
+    """All 513 m of one cfg-3 frequency with every tile sent to the eigen path: the 324 telescope-side tiles run as
+    pipelined half-batches (QL on the second stream), most sky-side orders have too few tiles for that and run as
+    synchronous Jacobi batches in the same workspace.  The two must not overlap in it (they once did: the
+    synchronous batch overwrote reflectors and rotation logs still in use); the answer must equal the all-Jacobi one."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    tel = _tel(3, 1)
+    lmax = tel.lmax
+    bt = SyntheticProvider(tel, seed=31)
+    gen = torch.Generator(device=ctx.device).manual_seed(4)
+    shape = (lmax + 1, 2, 1, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) * 30.0 + 5.0
+    eng = SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED)
+    out = {}
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+        for eig in (0, 1):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", eig))
+            out[eig] = eng.solve("ml", mv, mw, [0], lmax).cpu().numpy()
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+    assert np.all(np.isfinite(out[0]))
+    assert _rel(out[0], out[1]) < 1e-9
