@@ -80,8 +80,15 @@ class DeconvolveHybridMBase(ContainerTask):
         raise NotImplementedError(f"{self.__class__} must define a _get_regularisation method.")
 
     def _get_window(self, hybrid_vis_m, freq):
-        """Window over (freq, m, el) shaping the EW synthesized beam (``ringmapmaker.py:842-930``)."""
-        m = np.asarray(hybrid_vis_m.index_map["m"])
+        """Window over (freq, m, el) shaping the EW synthesized beam (``ringmapmaker.py:842-930``), on the device.
+
+        The per-(freq, el) limits are a handful of numbers (host, float64, exactly the reference's expressions); the
+        ``[nfreq, nm, nel]`` table itself is filled by ``dmm_ringmap_window``.
+        """
+        import ctypes as C
+
+        ctx = Context.get()
+        nm = len(hybrid_vis_m.index_map["m"])
         el = np.asarray(hybrid_vis_m.index_map["el"], dtype=np.float64)
         ew = np.array([x for i, x in enumerate(hybrid_vis_m.index_map["ew"]) if i not in self.exclude_cyl], dtype=np.float64)
         nlocal = len(freq)
@@ -94,12 +101,13 @@ class DeconvolveHybridMBase(ContainerTask):
         ew_to_m = 2.0 * np.pi * np.abs(np.cos(dec)) / lmbda
         min_m, max_m = ew_to_m * (center - 0.5 * width), ew_to_m * (center + 0.5 * width)
         if self.window_scaled:
-            min_m = np.max(min_m, axis=0, keepdims=True)
-            max_m = np.min(max_m, axis=0, keepdims=True)
-        x = (m[np.newaxis, :, np.newaxis] - min_m[:, np.newaxis, :]) / (max_m - min_m)[:, np.newaxis, :]
-        window = window_generalised(x, self.window_type).astype(np.float32)
-        if self.window_scaled:
-            window = np.repeat(window, nlocal, axis=0)
+            min_m = np.repeat(np.max(min_m, axis=0, keepdims=True), nlocal, axis=0)
+            max_m = np.repeat(np.min(max_m, axis=0, keepdims=True), nlocal, axis=0)
+        lo = ctx.to_device(np.ascontiguousarray(min_m), np.float64)
+        hi = ctx.to_device(np.ascontiguousarray(max_m), np.float64)
+        window = ctx.empty((nlocal, nm, len(el)), np.float32)
+        coef = (C.c_double * 4)(*[float(a) for a in _WINDOW_COEF[self.window_type]])
+        _lib.check(_lib.lib.dmm_ringmap_window(ctx.handle, int(nlocal), int(nm), int(len(el)), ptr(lo), ptr(hi), coef, ptr(window)))
         return window
 
     def process(self, hybrid_vis_m, hybrid_beam_m):
@@ -135,7 +143,7 @@ class DeconvolveHybridMBase(ContainerTask):
 
         window = None
         if self.window_type != "none":
-            window = ctx.to_device(self._get_window(hybrid_vis_m, freq), np.float32)
+            window = self._get_window(hybrid_vis_m, freq)
         iref = 0
         if self.skip_deconvolution:
             el = np.asarray(rm.index_map["el"], dtype=np.float64)

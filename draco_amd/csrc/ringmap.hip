@@ -287,6 +287,27 @@ inline int ilog2i(int n) {
   return l;
 }
 
+// window[f, m, el] = sum_i coef_i cos(2 pi i x), x = (m - min_m[f, el]) / (max_m[f, el] - min_m[f, el]), zero outside
+// [0, 1] (window_generalised, reference draco/util/tools.py:547-601, as used at ringmapmaker.py:917-925); float64
+// arithmetic, stored float32 like the reference's `.astype(np.float32)`
+__global__ void k_rm_window(int nfreq, int nm, int nel, const double* __restrict__ min_m, const double* __restrict__ max_m,
+                            double c0, double c1, double c2, double c3, float* __restrict__ out) {
+  const int64_t n = (int64_t)nfreq * nm * nel;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int el = (int)(idx % nel);
+    const int64_t fm = idx / nel;
+    const int m = (int)(fm % nm), f = (int)(fm / nm);
+    const double lo = min_m[(int64_t)f * nel + el], hi = max_m[(int64_t)f * nel + el];
+    const double x = ((double)m - lo) / (hi - lo);
+    double w = 0.0;
+    if (x >= 0.0 && x <= 1.0) {
+      const double t = 2.0 * M_PI * x;
+      w = c0 + c1 * cos(t) + c2 * cos(2.0 * t) + c3 * cos(3.0 * t);
+    }
+    out[idx] = (float)w;
+  }
+}
+
 }  // namespace
 
 extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npol, int nfreq, int new_, int nel,
@@ -368,6 +389,21 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_rm_fft, dim3((unsigned)((nrow + rb - 1) / rb)), dim3(kThreads), lds, ctx->stream, p, q);
   hipLaunchKernelGGL(k_rm_store, dim3((nra + 31) / 32, (nel + 31) / 32, npol * nfreq), dim3(kThreads), 0, ctx->stream, p);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
+extern "C" int dmm_ringmap_window(dmm_ctx* ctx, int nfreq, int nm, int nel, const double* min_m, const double* max_m,
+                                  const double* coef /*[host] 4*/, float* window) {
+  DMM_REQUIRE(ctx != nullptr, "dmm_ringmap_window: ctx is NULL");
+  DMM_REQUIRE(nfreq >= 0 && nm >= 0 && nel >= 0, "dmm_ringmap_window: bad sizes nfreq=%d nm=%d nel=%d", nfreq, nm, nel);
+  const int64_t n = (int64_t)nfreq * nm * nel;
+  if (n == 0) return DMM_OK;
+  DMM_REQUIRE(min_m && max_m && coef && window, "dmm_ringmap_window: NULL argument");
+  DMM_HIP(hipSetDevice(ctx->device));
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_rm_window, dim3(blocks), dim3(256), 0, ctx->stream, nfreq, nm, nel, min_m, max_m, coef[0], coef[1], coef[2],
+                     coef[3], window);
   DMM_HIP(hipGetLastError());
   return DMM_OK;
 }

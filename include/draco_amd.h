@@ -214,6 +214,14 @@ int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npol, int nfre
                            const float* window, double* map, double* weight, double* dirty_beam_power,
                            double* dirty_beam);
 
+/* dmm_ringmap_window: the cosine-sum window over (freq, m, el) that shapes the EW synthesised beam
+ * (DeconvolveHybridMBase._get_window, reference ringmapmaker.py:842-930 with window_generalised,
+ * util/tools.py:547-601): window[f, m, el] = sum_i coef[i] cos(2 pi i x) for 0 <= x <= 1, else 0,
+ * x = (m - min_m[f, el]) / (max_m[f, el] - min_m[f, el]).
+ * min_m, max_m [dev] double [nfreq, nel]; coef [host] 4 doubles; window [dev] float32 [nfreq, nm, nel].  */
+int dmm_ringmap_window(dmm_ctx* ctx, int nfreq, int nm, int nel, const double* min_m, const double* max_m,
+                       const double* coef, float* window);
+
 /* dmm_analytic_beam_mmodes replaces DeconvolveAnalyticalBeam._get_beam_mmodes (reference
  * ringmapmaker.py:1004-1072): for every (pol, freq, ew, el) the conjugated transit of the analytic
  * beam  exp(2 pi i u cos(dec) sin(phi)) * exp(-(2 tan(phi/2))^2 / (2 sigma^2)),  phi = 2 pi k / nra,
