@@ -78,6 +78,7 @@ _SIGS = {
     "dmm_map2alm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dmm_ringmap_deconvolve": (_i, [_vp] + [_i] * 10 + [_vp] * 10),
     "dmm_analytic_beam_mmodes": (_i, [_vp] + [_i] * 6 + [_vp] * 6),
+    "dmm_mmode_fill0": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "dmm_ringmap_window": (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "dmm_synth_beam_fill": (_i, [_vp, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, C.c_uint64, _vp]),
 }

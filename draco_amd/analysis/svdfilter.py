@@ -28,19 +28,15 @@ from .transform import _dev_dataset
 
 
 def _fill0(mvis, mweight):
-    """First guess of the missing entries of every m: ``np.median`` of the present ones (:176).
-
-    The complex median (NumPy's lexicographic order) is host logic, as in the reference; only
-    the m that actually miss entries are brought to the host.  ``None`` if nothing is missing.
-    """
-    missing = (mweight == 0.0).flatten(1).any(dim=1).cpu().numpy()
-    if not missing.any():
+    """First guess of the missing entries of every m: ``np.median`` of the present ones (:176), as a device
+    ``[n_m]`` complex128 tensor (``dmm_mmode_fill0``: NumPy's complex order, real part first).  ``None`` if nothing
+    is missing."""
+    if not bool((mweight == 0.0).any()):
         return None
-    out = np.zeros(mvis.shape[0], dtype=np.complex128)
-    for m in np.nonzero(missing)[0]:
-        v = mvis[m].cpu().numpy()
-        w = mweight[m].cpu().numpy()
-        out[m] = np.median(v[w != 0.0]) if (w != 0.0).any() else 0.0
+    ctx = Context.get()
+    n_m = mvis.shape[0]
+    out = ctx.empty((n_m,), np.complex128)
+    _lib.check(_lib.lib.dmm_mmode_fill0(ctx.handle, ptr(mvis), ptr(mweight), int(n_m), int(mvis[0].numel()), ptr(out)))
     return out
 
 
@@ -53,7 +49,7 @@ def _decompose(ctx, mvis, mweight, niter, rank, mode, global_max=0.0, global_thr
     nmode = min(2 * nbase, nfreq)
     spec = ctx.empty((n_m, nmode), np.float64)
     f0 = _fill0(mvis, mweight) if fill0 is None else fill0
-    f0_d = None if f0 is None else ctx.to_device(f0, np.complex128)
+    f0_d = None if f0 is None else (f0 if torch.is_tensor(f0) else ctx.to_device(f0, np.complex128))
     u = uha = None
     if factors:
         u = ctx.empty((n_m, nfreq, nmode), np.complex128)

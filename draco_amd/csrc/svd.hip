@@ -107,9 +107,105 @@ __global__ void k_diag_out(const double2* A, int Np, int nmat, double* out) {  /
   }
 }
 
+// ---- complex median of the present entries of every m, in NumPy's order (real part first, then imaginary): the
+// first guess svd_em puts into the missing entries (reference svdfilter.py:176, `np.median(A[~mask])`).
+// One block per m; the two middle elements are found by a radix select over the 128-bit key (8 bits per pass).
+constexpr int kMedThreads = 1024;
+
+__device__ __forceinline__ unsigned long long med_key(double x) {
+  if (x == 0.0) x = 0.0;  // -0.0 and +0.0 compare equal in NumPy's order
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double med_unkey(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(kMedThreads) void k_masked_median(const double2* __restrict__ vis, const double* __restrict__ w, int64_t per_m,
+                                                             double2* __restrict__ out) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned long long s_hi, s_lo;
+  __shared__ long long s_rank;
+  __shared__ unsigned int s_count;
+  const int m = blockIdx.x;
+  const double2* v = vis + (int64_t)m * per_m;
+  const double* wm = w + (int64_t)m * per_m;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  unsigned int cnt = 0;
+  for (int64_t i = threadIdx.x; i < per_m; i += kMedThreads) cnt += wm[i] != 0.0;
+  atomicAdd(&s_count, cnt);
+  __syncthreads();
+  const long long n = s_count;
+  if (n == 0) {
+    if (threadIdx.x == 0) out[m] = make_double2(0.0, 0.0);
+    return;
+  }
+  double2 res[2];
+  for (int which = 0; which < 2; ++which) {
+    if (threadIdx.x == 0) {
+      s_hi = s_lo = 0;
+      s_rank = which == 0 ? (n - 1) / 2 : n / 2;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 16; ++pass) {  // bits 127..0 of (key(re), key(im)), eight at a time
+      const int shift = 56 - 8 * (pass & 7);
+      const bool in_hi = pass < 8;
+      for (int b = threadIdx.x; b < 256; b += kMedThreads) hist[b] = 0;
+      __syncthreads();
+      const unsigned long long phi = s_hi, plo = s_lo;
+      const unsigned long long mask = pass == 0 || pass == 8 ? 0ull : ~0ull << (shift + 8);  // bits already fixed in this word
+      for (int64_t i = threadIdx.x; i < per_m; i += kMedThreads) {
+        if (wm[i] == 0.0) continue;
+        const double2 x = v[i];
+        const unsigned long long kh = med_key(x.x), kl = med_key(x.y);
+        bool match;
+        unsigned int bin;
+        if (in_hi) {
+          match = (kh & mask) == (phi & mask);
+          bin = (unsigned int)(kh >> shift) & 255u;
+        } else {
+          match = kh == phi && (kl & mask) == (plo & mask);
+          bin = (unsigned int)(kl >> shift) & 255u;
+        }
+        if (match) atomicAdd(&hist[bin], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        long long r = s_rank;
+        int b = 0;
+        for (; b < 255; ++b) {
+          if (r < (long long)hist[b]) break;
+          r -= hist[b];
+        }
+        s_rank = r;
+        if (in_hi) s_hi = phi | ((unsigned long long)b << shift);
+        else s_lo = plo | ((unsigned long long)b << shift);
+      }
+      __syncthreads();
+    }
+    res[which] = make_double2(med_unkey(s_hi), med_unkey(s_lo));
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[m] = make_double2(0.5 * (res[0].x + res[1].x), 0.5 * (res[0].y + res[1].y));
+}
+
 }  // namespace
 
 extern "C" {
+
+int dmm_mmode_fill0(dmm_ctx* ctx, const void* mvis, const double* mweight, int n_m, int64_t per_m, void* fill0) {
+  DMM_REQUIRE(ctx != nullptr, "dmm_mmode_fill0: ctx is NULL");
+  DMM_REQUIRE(n_m >= 0 && per_m >= 0, "dmm_mmode_fill0: bad sizes n_m=%d per_m=%lld", n_m, (long long)per_m);
+  if (n_m == 0) return DMM_OK;
+  DMM_REQUIRE(mvis && mweight && fill0, "dmm_mmode_fill0: NULL argument");
+  DMM_REQUIRE(per_m < ((int64_t)1 << 32), "dmm_mmode_fill0: %lld entries per m do not fit the counters", (long long)per_m);
+  DMM_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_masked_median, dim3(n_m), dim3(kMedThreads), 0, ctx->stream, (const double2*)mvis, mweight, per_m, (double2*)fill0);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
 
 // SVD with missing entries of every m of an MModes array, through the frequency-side Gram matrix.
 //   mode 0: spectrum[m][0..nmode) = singular values, largest first        (SVDSpectrumEstimator, svdfilter.py:22-57)

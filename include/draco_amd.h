@@ -242,6 +242,12 @@ int dmm_synth_beam_fill(dmm_ctx* ctx, const dmm_tile* tiles /*[host]*/, int64_t 
                         int npairs, int npol, int lmax, int b_dtype, int b_layout,
                         uint64_t seed, void* B);
 
+/* dmm_mmode_fill0: for every m the complex median (NumPy's order: real part, then imaginary) of the entries
+ * whose weight is non-zero -- the first guess svd_em puts into the missing ones (reference
+ * svdfilter.py:176); 0 where nothing is present.  mvis/mweight as below, viewed as [n_m, per_m];
+ * fill0 [dev] complex128 [n_m].                                                                   */
+int dmm_mmode_fill0(dmm_ctx* ctx, const void* mvis, const double* mweight, int n_m, int64_t per_m, void* fill0);
+
 /* ------------------------------------------------- m-mode SVD filter
  * dmm_mmode_svd replaces the per-m loops of SVDSpectrumEstimator.process (reference
  * svdfilter.py:22-57) and SVDFilter.process (:79-149) including svd_em (:152-187): for every m

@@ -128,3 +128,45 @@ def test_filter_fullsize_properties():
         n = spec0.shape[1] - cut
         assert np.abs(spec1[m, :n] - spec0[m, cut:]).max() < 1e-9 * spec0[m, 0]
         assert spec1[m, n:].max() < 1e-6 * spec0[m, 0]
+
+
+def test_masked_complex_median_is_numpys():
+    """``dmm_mmode_fill0`` against ``np.median`` on complex data: odd and even counts, ties in the real part (ordered by
+    the imaginary part), exact duplicates, +-0.0, negative values, one present entry, none (-> 0)."""
+    from draco_amd import _lib
+    from draco_amd.device import Context, ptr
+
+    ctx = Context.get()
+    rng = np.random.default_rng(12)
+    per_m = 2 * 7 * 33
+    rows, wts = [], []
+    for case in range(9):
+        v = rng.standard_normal(per_m) + 1j * rng.standard_normal(per_m)
+        w = (rng.uniform(size=per_m) > 0.3).astype(np.float64)
+        if case == 1:
+            w[np.nonzero(w)[0][0]] = 0.0  # flip the parity of the count
+        if case == 2:
+            v.real = np.round(v.real * 2) / 2  # many equal real parts
+        if case == 3:
+            v[: per_m // 2] = v[0]  # duplicates straddling the middle
+        if case == 4:
+            v.real[::2], v.real[1::2] = 0.0, -0.0
+        if case == 5:
+            v = -np.abs(v.real) - 1j * np.abs(v.imag)
+        if case == 6:
+            w[:] = 0.0
+            w[17] = 1.0
+        if case == 7:
+            w[:] = 0.0
+        if case == 8:
+            w[:] = 1.0
+        rows.append(v)
+        wts.append(w)
+    v, w = np.array(rows), np.array(wts)
+    out = ctx.empty((len(rows),), np.complex128)
+    v_d, w_d = ctx.to_device(v, np.complex128), ctx.to_device(w, np.float64)
+    _lib.check(_lib.lib.dmm_mmode_fill0(ctx.handle, ptr(v_d), ptr(w_d), len(rows), per_m, ptr(out)))
+    got = out.cpu().numpy()
+    for i in range(len(rows)):
+        ref = np.median(v[i][w[i] != 0]) if (w[i] != 0).any() else 0.0
+        assert got[i] == ref, (i, got[i], ref)
