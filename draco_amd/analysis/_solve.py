@@ -39,6 +39,17 @@ def _take_pool(ctx, nelem, b_dtype):
     return kept[:need].view(_TORCH[b_dtype])
 
 
+def _tile_sizes(provider, ms, b_layout):
+    """Elements of every tile of the list, padded to an even count (every tile stays 16-byte aligned for complex64
+    too); the size depends on m only."""
+    ms = np.asarray(ms, dtype=np.int64)
+    if ms.size == 0:
+        return np.zeros(0, dtype=np.int64)
+    per_m = np.array([provider.tile_elems(int(m), b_layout) for m in range(int(ms.max()) + 1)], dtype=np.int64)
+    per_m += per_m & 1
+    return per_m[ms]
+
+
 def release_pools():
     """Give the kept pools back (to the caching allocator, and on to the device)."""
     _POOLS.clear()
@@ -52,13 +63,11 @@ class Slab:
         tel = provider.telescope
         self.ctx = ctx
         self.ntile = len(ms)
+        sizes = _tile_sizes(provider, ms, b_layout)
         offs = np.zeros(self.ntile, dtype=np.int64)
-        acc = 0
-        for i, m in enumerate(ms):
-            offs[i] = acc
-            n = provider.tile_elems(int(m), b_layout)
-            acc += n + (n & 1)  # keep every tile 16-byte aligned for complex64 too
-        self.nelem = int(acc)
+        if self.ntile:
+            np.cumsum(sizes[:-1], out=offs[1:])
+        self.nelem = int(sizes.sum())
         self.tiles = _lib.tile_array(ms, fs_data, offs)
         fill_tiles = _lib.tile_array(ms, fs_bt, offs)
         if pool is None or pool.numel() < self.nelem or pool.dtype != _TORCH[b_dtype]:
@@ -111,19 +120,20 @@ class SolveEngine:
         """Split the tile list into consecutive ranges whose pool fits the budget; also the largest range's size
         in elements (the one pool every slab of the pass is filled into)."""
         budget = self._budget() // _ELEM[self.b_dtype]
-        ranges, start, acc, largest = [], 0, 0, 0
-        for i, m in enumerate(ms):
-            n = self.provider.tile_elems(int(m), self.b_layout)
-            n += n & 1
-            if n > budget:
-                raise MemoryError(f"one B tile ({n} elements) exceeds the pool budget ({budget})")
-            if acc + n > budget:
-                ranges.append((start, i))
-                largest = max(largest, acc)
-                start, acc = i, 0
-            acc += n
-        ranges.append((start, len(ms)))
-        self._pool_elems = max(largest, acc)
+        sizes = _tile_sizes(self.provider, ms, self.b_layout)
+        if len(sizes) and int(sizes.max()) > budget:
+            raise MemoryError(f"one B tile ({int(sizes.max())} elements) exceeds the pool budget ({budget})")
+        cum = np.concatenate([[0], np.cumsum(sizes)])
+        ranges, start, largest = [], 0, 0
+        while start < len(ms):  # greedy: as many consecutive tiles as fit (one searchsorted per slab)
+            stop = int(np.searchsorted(cum, cum[start] + budget, side="right")) - 1
+            stop = max(stop, start + 1)
+            ranges.append((start, stop))
+            largest = max(largest, int(cum[stop] - cum[start]))
+            start = stop
+        if not ranges:
+            ranges.append((0, 0))
+        self._pool_elems = largest
         return ranges
 
     def slabs(self, freq_ind, mmax, nfreq_data, n_m):
