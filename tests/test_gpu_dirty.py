@@ -199,7 +199,8 @@ def test_project_vs_oracle():
         assert _rel(out, ref) < 1e-13
 
 
-def test_slabs_share_one_pool_sized_for_the_largest():
+@pytest.mark.parametrize("b_dtype", ["c128", "c64"])
+def test_slabs_share_one_pool_sized_for_the_largest(b_dtype):
     """Slabs are cut where the budget is reached, so their sizes differ by a few tiles and a later one may be larger
     than the first: the pool is allocated once, for the largest (growing it would need a second pool-sized block while
     the first is alive -- 168 GB twice at cfg 3)."""
@@ -217,8 +218,9 @@ def test_slabs_share_one_pool_sized_for_the_largest():
     shape = (31, 2, 3, tel.npairs)
     mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
     mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen)
-    ref = _solve.SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED).solve("dirty", mv, mw, [0, 1, 2], 30).cpu().numpy()
-    eng = _solve.SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, pool_bytes=400_000, cache=False)
+    dt = _lib.DMM_C128 if b_dtype == "c128" else _lib.DMM_C64
+    ref = _solve.SolveEngine(bt, ctx, dt, _lib.DMM_B_PACKED).solve("dirty", mv, mw, [0, 1, 2], 30).cpu().numpy()
+    eng = _solve.SolveEngine(bt, ctx, dt, _lib.DMM_B_PACKED, pool_bytes=400_000 if b_dtype == "c128" else 200_000, cache=False)
     pools, sizes = set(), []
     for slab in eng.slabs([0, 1, 2], 30, 3, 31):
         pools.add(slab.pool.data_ptr())
