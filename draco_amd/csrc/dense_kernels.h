@@ -81,13 +81,24 @@ __device__ __forceinline__ void fetch(double2 (&v)[CPT], const DenseParams& p, c
   if (SRC == 0) {
     const int L = p.lmax + 1 - tile.m;
     int k = k0 + c0;
-    if (!p.full_layout && p.b_c128 && (K & 3) == 0) {
-      // fast path (packed complex128 tiles, npol*L a multiple of 4): the row is contiguous in k and the
-      // thread's columns are inside or outside in groups of four -> 16-byte loads, one predicate per group
+    if (!p.full_layout && (K & 3) == 0) {
+      // fast path (packed tiles, npol*L a multiple of 4): the row is contiguous in k and the thread's columns
+      // are inside or outside in groups of four -> 16-byte loads, one predicate per group
       const bool rin = row < p.N;
-      const double2* src = reinterpret_cast<const double2*>(p.B) + tile.b_off + (int64_t)row * K + k;
+      if (p.b_c128) {
+        const double2* src = reinterpret_cast<const double2*>(p.B) + tile.b_off + (int64_t)row * K + k;
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) v[c] = (rin && k + (c & ~3) < K) ? src[c] : make_double2(0.0, 0.0);
+        for (int c = 0; c < CPT; ++c) v[c] = (rin && k + (c & ~3) < K) ? src[c] : make_double2(0.0, 0.0);
+      } else {  // complex64 storage: two values per 16-byte load (tiles start 16-byte aligned, k is a multiple of 4)
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(p.B) + tile.b_off + (int64_t)row * K + k);
+#pragma unroll
+        for (int c = 0; c < CPT; c += 2) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rin && k + (c & ~3) < K) x = src[c >> 1];
+          v[c] = make_double2((double)x.x, (double)x.y);
+          v[c + 1] = make_double2((double)x.z, (double)x.w);
+        }
+      }
       if (scale_s && p.Sl && rin) {
         int lrel = k % L;
 #pragma unroll
