@@ -216,6 +216,11 @@ class WienerMapMaker(BaseMapMaker):
     _kind = "wiener"
 
     def _solve_params(self):
+        # the reference builds the prior for exactly four sky polarisations (`np.concatenate([cl_TT] * 4)`,
+        # mapmaker.py:264) and fails on its first product with any other telescope: same error class here
+        npol = self.beamtransfer.telescope.num_pol_sky
+        if npol != 4:
+            raise ValueError(f"operands could not be broadcast together: the Wiener prior covers 4 sky polarisations, the telescope has {npol}")
         return {"prior_amp": self.prior_amp, "prior_tilt": self.prior_tilt}
 
 

@@ -339,3 +339,36 @@ def test_expand_products_golden(golden_dir):
         c.setup(tel)
         back = c.process(full)
         np.testing.assert_allclose(back.vis[:], vis, rtol=2e-6, atol=1e-6)
+
+
+def test_single_polarisation_dense_solvers():
+    """num_pol_sky = 1 through the dense solvers.  ML: nsky_m = lmax+1-m is not a multiple of four (the generic operand
+    path), telescope- and sky-side systems both occur (ntel = 22, nsky_m from 31 down to 1).  Wiener: the reference's
+    prior is hard-wired to four polarisations (mapmaker.py:264) and raises ValueError on its first solve; so do we."""
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker, WienerMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+
+    lmax = 30
+    tel = _tel(2, lmax, num_pol_sky=1)
+    bt = SyntheticProvider(tel, seed=8)
+    rng = np.random.default_rng(8)
+    shape = (lmax + 1, 2, 2, tel.npairs)
+    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    mw = rng.uniform(0.5, 1.5, shape) * 10.0
+    mw[rng.uniform(size=shape) < 0.1] = 0.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    task = MaximumLikelihoodMapMaker()
+    task.setup(bt)
+    alm = task.alm_square(task.make_alm(mm))
+    ref = omm.solve_alm("ml", lambda m, f: osyn.beam_tile(8, m, f, tel.npairs, 1, lmax), mv, mw, lmax, lmax, [0, 1], npol=1)
+    ref[:, 1:] = ref[:, :1]
+    assert _rel(alm, ref) < 1e-8
+    w = WienerMapMaker()
+    w.setup(bt)
+    with pytest.raises(ValueError, match="could not be broadcast"):
+        w.make_alm(mm)
+    with pytest.raises(ValueError, match="could not be broadcast"):
+        w._solve_m(0, 0, mv[0, :, 0], mw[0, :, 0])
