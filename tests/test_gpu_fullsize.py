@@ -235,3 +235,39 @@ def test_cfg3_ml_eigen_pass_mixes_pipelined_and_synchronous_batches():
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
     assert np.all(np.isfinite(out[0]))
     assert _rel(out[0], out[1]) < 1e-9
+
+
+@pytest.mark.parametrize("nfeed_cyl,np_expected", [(33, 832), (70, 1728), (90, 2176)])
+def test_ml_tridiagonal_path_at_other_orders(nfeed_cyl, np_expected):
+    """The kernel variants of the tridiagonal eigen path are chosen by matrix order: six column chunks per wave and two
+    pending updates up to 1536, eight chunks and one up to 2048, full-matrix trailing sweeps beyond.  One telescope-side
+    tile (m = 0) and one sky-side tile at each of three orders in those ranges, against the blocked Jacobi."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core.products import SyntheticProvider, TransitTelescope
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    lmax = 600
+    tel = TransitTelescope(osyn.frequencies(1), lmax=lmax, ncyl=2, nfeed_cyl=nfeed_cyl)
+    ntel = 2 * tel.npairs
+    assert (ntel + 63) // 64 * 64 == np_expected and 4 * (lmax + 1) >= ntel
+    bt = SyntheticProvider(tel, seed=60 + nfeed_cyl)
+    ml = MaximumLikelihoodMapMaker()
+    ml.setup(bt)
+    rng = np.random.default_rng(nfeed_cyl)
+    for m in (0, lmax - 100):  # telescope side; sky side of order 404 (padded 448)
+        v = rng.standard_normal((2, tel.npairs)) + 1j * rng.standard_normal((2, tel.npairs))
+        Ni = rng.uniform(0.5, 1.5, (2, tel.npairs)) * 10
+        Ni[rng.uniform(size=Ni.shape) < 0.05] = 0
+        out = {}
+        try:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+            for eig in (1, 4):
+                _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", eig))
+                out[eig] = ml._solve_m(m, 0, v, Ni)
+        finally:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+        assert np.all(np.isfinite(out[4]))
+        assert _rel(out[4], out[1]) < 1e-9, (m, _rel(out[4], out[1]))
