@@ -58,6 +58,19 @@ class SimulateSidereal(ContainerTask):
             self._engine = _solve.SolveEngine(self.beamtransfer, Context.get(), dt, _lib.DMM_B_PACKED, self.pool_bytes)
         return self._engine
 
+    def _sky_alm(self, ctx, row_map, nside):
+        """sky -> a_lm trimmed to m <= mmax, device ``[nfreq, npol, mmax+1, lmax+1]`` (``stream.py:85-90``).
+
+        The one stage that stands in for third-party code (``hputil.sphtrans_sky`` -> healpy); kept apart so that
+        the rest of ``process`` can be checked against the reference run with a recorded a_lm
+        (``tests/golden/stream_simulate.npz``).
+        """
+        tel = self.telescope
+        nfreq, npol = row_map.shape[:2]
+        alm = ctx.empty((nfreq, npol, tel.mmax + 1, tel.lmax + 1), np.complex128)
+        _lib.check(_lib.lib.dmm_map2alm(ctx.handle, ptr(row_map), nfreq, npol, tel.lmax, tel.mmax, nside, int(self.map2alm_iter), ptr(alm)))
+        return alm
+
     def process(self, map_):
         """Simulate a SiderealStream from ``map_`` (``stream.py:48-178``)."""
         tel = self.telescope
@@ -76,9 +89,7 @@ class SimulateSidereal(ContainerTask):
         row_map = row_map[:, :npol].contiguous()
         nside = int(round((row_map.shape[-1] // 12) ** 0.5))
 
-        # sky -> a_lm, trimmed to m <= mmax (stream.py:85-90)
-        alm = ctx.empty((nfreq, npol, mmax + 1, lmax + 1), np.complex128)
-        _lib.check(_lib.lib.dmm_map2alm(ctx.handle, ptr(row_map), nfreq, npol, lmax, mmax, nside, int(self.map2alm_iter), ptr(alm)))
+        alm = self._sky_alm(ctx, row_map, nside)
 
         # a_lm -> m-mode visibilities for every (m, f) (stream.py:102-112)
         vis_m = eng.project(alm, list(range(nfreq)), mmax)  # [mmax+1, 2, nfreq, npairs]

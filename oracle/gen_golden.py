@@ -933,6 +933,289 @@ def gen_expand(out):
     np.savez_compressed(os.path.join(out, "stream_expand.npz"), **cases)
 
 
+# --------------------------------------------------------------------------- orchestration: fake MPIArray
+class FakeMPIArray(np.ndarray):
+    """Single-process stand-in for caput's ``MPIArray`` [3P]: an ndarray whose distributed axis is whole.
+
+    Only what ``SimulateSidereal.process`` (stream.py:91-127) and ``BaseMapMaker.process``
+    (mapmaker.py:62-113) touch: the constructor ``MPIArray(global_shape, axis=, dtype=, comm=)``, ``wrap``,
+    ``redistribute`` (one rank: a no-op), ``enumerate`` (local index == global index), ``local_array``,
+    ``local_shape`` and ``reshape`` with ``None`` standing for the distributed axis.
+    """
+
+    def __new__(cls, global_shape, axis=0, comm=None, dtype=np.float64, **kw):
+        return np.zeros(global_shape, dtype=dtype).view(cls)
+
+    @staticmethod
+    def wrap(arr, axis=0, comm=None):
+        return np.asarray(arr).view(FakeMPIArray)
+
+    def redistribute(self, axis=None):
+        return self
+
+    def enumerate(self, axis):
+        return [(i, i) for i in range(self.shape[axis])]
+
+    @property
+    def local_array(self):
+        return self.view(np.ndarray)
+
+    @property
+    def local_shape(self):
+        return self.shape
+
+    def reshape(self, *shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], tuple | list):
+            shape = tuple(shape[0])
+        shape = tuple(-1 if s is None else s for s in shape)
+        return np.ndarray.reshape(self, shape, **kw)
+
+
+class _MPIDS:
+    """Dataset whose slices are FakeMPIArrays (``mmodes.vis[: mmax + 1]`` must answer ``redistribute``)."""
+
+    def __init__(self, arr):
+        self.arr = np.asarray(arr)
+
+    def __getitem__(self, k):
+        return self.arr[k].view(FakeMPIArray)
+
+    def __setitem__(self, k, v):
+        self.arr[k] = v
+
+    @property
+    def shape(self):
+        return self.arr.shape
+
+
+def _freqmap(centres, width=1.0):
+    fm = np.zeros(len(centres), dtype=[("centre", np.float64), ("width", np.float64)])
+    fm["centre"], fm["width"] = centres, width
+    return fm
+
+
+class FakeMap(_FakeCont):
+    """cora/draco ``Map`` duck type: ``map [freq, pol, pixel]`` (containers.py:470-486)."""
+
+    def __init__(self, nside=None, axes_from=None, comm=None, freq=None, npol=4, map_=None):
+        if map_ is None:
+            nfreq = len(axes_from.index_map["freq"]) if axes_from is not None else len(freq)
+            map_ = np.zeros((nfreq, npol, 12 * nside**2))
+            freq = axes_from.index_map["freq"] if axes_from is not None else freq
+        self.map = _MPIDS(map_)
+        self.index_map = {"freq": freq}
+        self.nside = nside
+
+
+class FakeSimStream(_FakeCont):
+    """Records what ``SimulateSidereal.process`` hands the SiderealStream constructor (stream.py:167-176)."""
+
+    def __init__(self, freq=None, ra=None, input=None, distributed=None, comm=None, **kwargs):
+        self.ctor = dict(freq=freq, ra=ra, input=input, **kwargs)
+        npr = len(kwargs["stack"]) if "stack" in kwargs else len(kwargs["prod"])
+        self.vis = _DS(np.zeros((len(freq), npr, ra), np.complex64))  # containers.py:501-503 dtype
+        self.weight = _DS(np.zeros((len(freq), npr, ra), np.float32))
+
+
+class _SimTel:
+    """Telescope attributes stream.py:68-71,144-162 reads; a 1-cylinder grid of ``nfeed`` like feeds."""
+
+    def __init__(self, nfeed, freqs, lmax, mmax, npol, stackable, with_input_index):
+        self.nfeed, self.lmax, self.mmax, self.num_pol_sky = nfeed, lmax, mmax, npol
+        self.frequencies = np.asarray(freqs, dtype=np.float64)
+        self.nfreq = len(self.frequencies)
+        if with_input_index:
+            self.input_index = np.array([(7 + i, i) for i in range(nfeed)], dtype=[("chan_id", "<u2"), ("correlator_input", "<u2")])
+        if stackable:  # unique baselines = separations (autos included): npairs = nfeed < nfeed(nfeed+1)/2
+            self.uniquepairs = np.array([(0, d) for d in range(nfeed)])
+            prod = [(i, j) for i in range(nfeed) for j in range(i, nfeed)]
+            self.index_map_prod = np.array(prod, dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+            self.index_map_stack = np.array([(prod.index((0, d)), 0) for d in range(nfeed)], dtype=[("prod", "<u4"), ("conjugate", "u1")])
+            self.reverse_map_stack = np.array([(j - i, 0) for i, j in prod], dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        else:  # the full triangle
+            self.uniquepairs = np.array([(i, j) for i in range(nfeed) for j in range(i, nfeed)])
+        self.npairs = len(self.uniquepairs)
+
+
+class _SimBT(_BT):
+    """``_BT`` + driftscan's ``project_vector_sky_to_telescope`` [3P] as the call site stream.py:109-112 uses it:
+    ``[nfreq, npol, lmax+1] -> [nfreq, ntel]``, per frequency ``B_m[f] a`` with B reshaped ``[ntel, nsky]``."""
+
+    def __init__(self, tel, seed):
+        self.telescope = tel
+        self.npairs, self.ntel = tel.npairs, 2 * tel.npairs
+        self.npol = tel.num_pol_sky
+        self.nsky = self.npol * (tel.lmax + 1)
+        self.seed = seed
+
+    def project_vector_sky_to_telescope(self, mi, vec):
+        out = np.zeros((self.telescope.nfreq, self.ntel), dtype=np.complex128)
+        for f in range(self.telescope.nfreq):
+            out[f] = self.beam_m(mi, fi=f).reshape(self.ntel, self.nsky) @ vec[f].reshape(-1)
+        return out
+
+
+def _install_fake_mpi(mod):
+    import types
+
+    mod.mpiarray = types.SimpleNamespace(MPIArray=FakeMPIArray)
+
+
+def gen_stream_simulate(out):
+    """``SimulateSidereal.process`` (stream.py:48-178) executed from the reference source.
+
+    Third-party pieces served by stand-ins: ``MPIArray`` -> :class:`FakeMPIArray` (one rank),
+    ``mpitools.split_local(n)`` -> ``(n, 0, n)``, ``hputil.sphtrans_sky(map, lmax=)`` -> returns the seeded a_lm
+    the fixture stores (so the fixture pins everything *after* the SHT: m trim, ``B_m a``, the +/-m unwrap with the
+    conjugate-only rule, ``ifft * ntime``, the axis order, the complex64 cast and the prod/stack bookkeeping).
+    """
+    import types
+
+    from draco.synthesis import stream
+
+    _install_fake_mpi(stream)
+    stream.mpitools = types.SimpleNamespace(split_local=lambda n: (n, 0, n))
+    stream.containers = type("C", (), {"SiderealStream": FakeSimStream})
+    stream.io.get_beamtransfer = lambda b: b
+    stream.io.get_telescope = lambda b: b.telescope
+    rng = np.random.default_rng(11011)
+    cases = {}
+    idx = 0
+    # (nfeed, nfreq, lmax, mmax, npol, stackable telescope, task.stacked, telescope has input_index)
+    for nfeed, nfreq, lmax, mmax, npol, stackable, stacked, has_idx in (
+        (4, 3, 6, 6, 4, True, True, True),
+        (4, 2, 7, 4, 4, True, False, True),
+        (3, 2, 5, 5, 4, False, True, False),
+        (5, 3, 6, 3, 1, True, True, True),
+    ):
+        freqs = 400.0 + 10.0 * np.arange(nfreq)
+        tel = _SimTel(nfeed, freqs, lmax, mmax, npol, stackable, has_idx)
+        bt = _SimBT(tel, 500 + idx)
+        alm_in = crandn(rng, (nfreq, npol, lmax + 1, lmax + 1))
+        alm_in[:, :, :, 0] = alm_in[:, :, :, 0].real  # a real sky has real m = 0 coefficients
+        for l_ in range(lmax + 1):
+            alm_in[:, :, l_, l_ + 1 :] = 0.0
+        seen = {}
+
+        def sphtrans_sky(m_, lmax=None, _alm=alm_in, _seen=seen):
+            _seen["shape"], _seen["lmax"] = m_.shape, lmax
+            return _alm.copy()
+
+        stream.hputil = types.SimpleNamespace(sphtrans_sky=sphtrans_sky)
+        nside = 4
+        map_in = rng.standard_normal((nfreq, npol, 12 * nside**2))
+        t = stream.SimulateSidereal.__new__(stream.SimulateSidereal)
+        t.stacked = stacked
+        t.setup(bt)
+        ss = t.process(FakeMap(freq=_freqmap(freqs), map_=map_in))
+        assert seen["shape"] == map_in.shape and seen["lmax"] == lmax
+        c = f"c{idx}_"
+        cases[c + "dims"] = np.array([nfeed, nfreq, lmax, mmax, npol, tel.npairs, int(stackable), int(stacked), int(has_idx)])
+        cases[c + "freq"] = freqs
+        cases[c + "alm"] = alm_in
+        cases[c + "beam"] = np.array([[bt.beam_m(m, fi=f) for f in range(nfreq)] for m in range(mmax + 1)])
+        cases[c + "uniquepairs"] = tel.uniquepairs
+        if stackable:
+            cases[c + "tel_prod"], cases[c + "tel_stack"], cases[c + "tel_rev"] = tel.index_map_prod, tel.index_map_stack, tel.reverse_map_stack
+        if has_idx:
+            cases[c + "tel_input"] = tel.input_index
+        cases[c + "vis"] = ss.vis.arr.view(np.ndarray)
+        cases[c + "weight"] = ss.weight.arr.view(np.ndarray)
+        cases[c + "ctor_ra"] = np.int64(ss.ctor["ra"])
+        cases[c + "ctor_input"] = np.asarray(ss.ctor["input"])
+        cases[c + "ctor_prod_a"] = np.asarray(ss.ctor["prod"]["input_a"]).astype(np.int64)
+        cases[c + "ctor_prod_b"] = np.asarray(ss.ctor["prod"]["input_b"]).astype(np.int64)
+        cases[c + "ctor_has_stack"] = np.bool_("stack" in ss.ctor)
+        idx += 1
+    # frequency mismatch -> ValueError (stream.py:81-82)
+    try:
+        t.process(FakeMap(freq=_freqmap(freqs + 1.0), map_=map_in))
+        raised = "none"
+    except ValueError as e:
+        raised = str(e)
+    cases["mismatch_message"] = np.array(raised)
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "stream_simulate.npz"), **cases)
+
+
+class FakeProcMModes(_FakeCont):
+    def __init__(self, vis, weight, freqs):
+        self.vis, self.weight = _MPIDS(vis), _MPIDS(weight)
+        self.index_map = {"m": np.arange(vis.shape[0]), "freq": _freqmap(freqs)}
+
+
+def gen_mapmaker_process(mapmaker, out):
+    """``BaseMapMaker.process`` (mapmaker.py:35-118) executed from the reference source for the three makers.
+
+    ``hputil.sphtrans_inv_sky(alm, nside)`` [3P] is served by a recorder: the fixture stores the square
+    ``alm [nfreq, 4, lmax+1, lmax+1]`` the reference hands to the SHT (frequency matching, m trim, the (m, f)
+    loop, the broadcast into the four polarisation slots and the zero padding in m are all the reference's own).
+    """
+    import importlib
+    import types
+
+    _install_fake_mpi(mapmaker)
+    mapmaker.containers = type("C", (), {"Map": FakeMap})
+    mapmaker.io.get_beamtransfer = lambda b: b
+    hp = importlib.import_module("cora.util.hputil")
+    rec = {}
+
+    def sphtrans_inv_sky(alm, nside):
+        rec["alm"] = np.array(alm.view(np.ndarray))
+        rec["nside"] = nside
+        return np.zeros((alm.shape[0], 4, 12 * nside**2))
+
+    hp.sphtrans_inv_sky = sphtrans_inv_sky
+    importlib.import_module("cora.util").hputil = hp
+    rng = np.random.default_rng(12012)
+    cases = {}
+    idx = 0
+    # (npairs, lmax, tel_mmax, n_m of the data, npol, data frequencies as indices into the telescope's 4)
+    for npairs, lmax, tel_mmax, n_m, npol, fsel in (
+        (6, 5, 5, 6, 4, [0, 1, 2, 3]),   # matched
+        (5, 6, 6, 4, 4, [2, 0]),         # data hold fewer m than the telescope; permuted frequency subset
+        (7, 4, 3, 7, 4, [3, 1, 2]),      # data hold excess m (trimmed, :63-66)
+        (4, 5, 5, 6, 1, [1, 3]),         # num_pol_sky = 1: broadcast into the four slots (:91-94)
+    ):
+        bt = _BT(npairs, lmax, 4, 700 + idx, npol)
+        bt.telescope.mmax = tel_mmax
+        tfreq = bt.telescope.frequencies
+        dfreq = tfreq[fsel]
+        mv = crandn(rng, (n_m, 2, len(fsel), npairs))
+        mw = rng.uniform(0.5, 1.5, mv.shape)
+        mw[rng.uniform(size=mw.shape) < 0.1] = 0.0
+        c = f"c{idx}_"
+        cases[c + "dims"] = np.array([npairs, lmax, tel_mmax, n_m, npol])
+        cases[c + "tel_freq"], cases[c + "freq"] = tfreq, dfreq
+        cases[c + "mvis"], cases[c + "mweight"] = mv, mw
+        mm_eff = min(tel_mmax, n_m - 1)
+        cases[c + "beam"] = np.array([[bt.beam_m(m, fi=f) for f in range(4)] for m in range(mm_eff + 1)])
+        for name, cls in (("dirty", mapmaker.DirtyMapMaker), ("ml", mapmaker.MaximumLikelihoodMapMaker), ("wiener", mapmaker.WienerMapMaker)):
+            t = cls.__new__(cls)
+            t.nside, t.prior_amp, t.prior_tilt, t.bt_cache = 2, 1.0, 0.5, None
+            t.setup(bt)
+            rec.clear()
+            try:
+                m_out = t.process(FakeProcMModes(mv.copy(), mw.copy(), dfreq))
+                cases[c + name] = rec["alm"]
+                assert rec["nside"] == 2 and m_out.map.shape == (len(fsel), 4, 48)
+            except ValueError as e:  # the Wiener prior is hard-wired to four polarisations (:264)
+                cases[c + name + "_error"] = np.array(type(e).__name__)
+        idx += 1
+    # a data frequency the telescope does not have -> ValueError (tools.py:124-125 via mapmaker.py:59)
+    try:
+        t = mapmaker.DirtyMapMaker.__new__(mapmaker.DirtyMapMaker)
+        t.nside, t.bt_cache = 2, None
+        t.setup(bt)
+        t.process(FakeProcMModes(mv.copy(), mw.copy(), dfreq + 0.5))
+        raised = "none"
+    except ValueError as e:
+        raised = str(e)
+    cases["mismatch_message"] = np.array(raised)
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "mapmaker_process.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -959,6 +1242,10 @@ def main():
         gen_expand(GOLDEN)
     if not only or "--only-svd" in only:
         gen_svd(GOLDEN)
+    if not only or "--only-simulate" in only:
+        gen_stream_simulate(GOLDEN)
+    if not only or "--only-process" in only:
+        gen_mapmaker_process(mapmaker, GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 

@@ -134,5 +134,5 @@ def solve_alm(kind, beam_m, mvis, mweight, lmax, tel_mmax, freq_ind, npol=4, **p
                 a = wiener_solve(bm, m, v, Ni, **prior)
             else:
                 raise ValueError(kind)
-            alm[fi, :npol, :, m] = a
+            alm[fi, :, :, m] = a  # [npol, lmax+1] into 4 slots: npol = 1 broadcasts (mapmaker.py:91-94; pinned by mapmaker_process.npz)
     return alm

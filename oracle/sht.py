@@ -77,6 +77,49 @@ def pix_angles(nside):
     return th, ph
 
 
+def ang2pix_ring(nside, theta, phi):
+    """RING pixel index containing the direction(s) ``(theta, phi)`` -- the published HEALPix point-in-pixel rule
+    (Gorski et al. 2005, section 4.1: pixel boundaries are lines of constant ``phi +/- f(z)``), written from the
+    boundary equations, NOT from :func:`ring_info`.  Used only as an independent witness of the ring geometry
+    (``tests/test_oracle_sht.py``); the reference's own healpy call sites use it with ``lonlat=True``
+    (``draco/analysis/beamform.py:1708,1760``: ``ang2pix(nside, ra_deg, dec_deg, lonlat=True)``).
+    """
+    nside = int(nside)
+    theta, phi = np.broadcast_arrays(np.asarray(theta, dtype=np.float64), np.asarray(phi, dtype=np.float64))
+    z = np.cos(theta)
+    za = np.abs(z)
+    tt = np.mod(phi, 2.0 * np.pi) / (0.5 * np.pi)  # [0, 4)
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    out = np.empty(z.shape, dtype=np.int64)
+    eq = za <= 2.0 / 3.0
+    # equatorial belt: the two families of boundary lines are straight in (z, phi)
+    t1 = nside * (0.5 + tt[eq])
+    t2 = nside * z[eq] * 0.75
+    jp = np.floor(t1 - t2).astype(np.int64)  # ascending edge line index
+    jm = np.floor(t1 + t2).astype(np.int64)  # descending edge line index
+    ir = nside + 1 + jp - jm  # ring counted from z = 2/3, in 1 .. 2 nside + 1
+    kshift = 1 - (ir & 1)
+    ip = (jp + jm - nside + kshift + 1) // 2
+    ip = np.mod(ip, 4 * nside)
+    out[eq] = ncap + (ir - 1) * 4 * nside + ip
+    # polar caps: boundaries are curves sqrt(3 (1 - |z|)) * {phi_t, 1 - phi_t} = integer / nside
+    pc = ~eq
+    tp = tt[pc] - np.floor(tt[pc])
+    tmp = nside * np.sqrt(3.0 * (1.0 - za[pc]))
+    jp = np.floor(tp * tmp).astype(np.int64)
+    jm = np.floor((1.0 - tp) * tmp).astype(np.int64)
+    ir = jp + jm + 1  # ring counted from the closest pole
+    ip = np.mod(np.floor(tt[pc] * ir).astype(np.int64), 4 * ir)
+    out[pc] = np.where(z[pc] > 0, 2 * ir * (ir - 1) + ip, npix - 2 * ir * (ir + 1) + ip)
+    return out
+
+
+def ang2pix_lonlat(nside, lon_deg, lat_deg):
+    """``healpy.ang2pix(nside, lon, lat, lonlat=True)``: longitude = phi (RA), latitude = 90 deg - theta (dec)."""
+    return ang2pix_ring(nside, np.radians(90.0 - np.asarray(lat_deg, dtype=np.float64)), np.radians(lon_deg))
+
+
 # ------------------------------------------------------------- Legendre functions
 def lambda_lm(lmax, m, x):
     """Normalised associated Legendre ``lambda_lm(x)``, ``l = m..lmax`` -> ``[lmax+1, len(x)]`` (rows l<m zero).

@@ -263,3 +263,44 @@ def test_expand_products(golden_dir):
         np.testing.assert_array_equal(v, g[f"c{i}_out_vis"])
         np.testing.assert_array_equal(w, g[f"c{i}_out_w"])
         assert np.abs(v).max() > 0
+
+
+def test_simulate_sidereal_process(golden_dir):
+    """oracle.stream.simulate_from_alm vs the reference's SimulateSidereal.process run from source
+    (stream.py:48-178 under a one-rank MPIArray stand-in; the SHT output is part of the fixture)."""
+    from oracle import stream as ostream
+
+    g = _load(golden_dir, "stream_simulate.npz")
+    assert str(g["mismatch_message"]) == "Frequencies in map do not match those in Beam Transfers."
+    for i in range(int(g["ncase"])):
+        nfeed, nfreq, lmax, mmax, npol, npairs = (int(x) for x in g[f"c{i}_dims"][:6])
+        beam = g[f"c{i}_beam"]  # [m, f, 2, npairs, npol, lmax+1]
+        vis = ostream.simulate_from_alm(g[f"c{i}_alm"], lambda m, f: beam[m, f], lmax, mmax, npairs, npol)
+        ref = g[f"c{i}_vis"]
+        assert vis.shape == ref.shape == (nfreq, npairs, 2 * mmax + 1) and vis.dtype == ref.dtype == np.complex64
+        # same operations in a different association order, then one rounding to complex64
+        assert np.abs(vis - ref).max() <= 2e-7 * np.abs(ref).max()
+        np.testing.assert_array_equal(g[f"c{i}_weight"], 1.0)
+        assert int(g[f"c{i}_ctor_ra"]) == 2 * mmax + 1
+
+
+def test_mapmaker_process(golden_dir):
+    """oracle.mapmaker.solve_alm vs the alm the reference's BaseMapMaker.process hands to the SHT
+    (mapmaker.py:35-112 run from source: frequency matching, m trim, pol broadcast, square padding)."""
+    g = _load(golden_dir, "mapmaker_process.npz")
+    assert str(g["mismatch_message"]) == "Could not find all of the keys."
+    for i in range(int(g["ncase"])):
+        npairs, lmax, tel_mmax, n_m, npol = (int(x) for x in g[f"c{i}_dims"])
+        beam = g[f"c{i}_beam"]  # [m, tel f, 2, npairs, npol, lmax+1]
+        freq_ind = omm.find_keys(g[f"c{i}_tel_freq"], g[f"c{i}_freq"], require_match=True)
+        for kind in ("dirty", "ml", "wiener"):
+            if f"c{i}_{kind}_error" in g.files:
+                assert npol != 4 and kind == "wiener" and str(g[f"c{i}_{kind}_error"]) == "ValueError"
+                continue
+            ref = g[f"c{i}_{kind}"]
+            prior = {"prior_amp": 1.0, "prior_tilt": 0.5} if kind == "wiener" else {}
+            out = omm.solve_alm(kind, lambda m, f: beam[m, f], g[f"c{i}_mvis"], g[f"c{i}_mweight"], lmax, tel_mmax, freq_ind, npol=npol, **prior)
+            assert out.shape == ref.shape == (len(freq_ind), 4, lmax + 1, lmax + 1)
+            assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max(), (i, kind)
+            mm_eff = min(tel_mmax, n_m - 1)
+            assert not ref[..., mm_eff + 1 :].any()  # padded m columns stay zero (:108)

@@ -134,3 +134,118 @@ def test_cora_shaped_wrappers():
     assert mp.shape == (2, 4, 192)
     back = sht.sphtrans_sky(mp, 6, niter=10)
     assert back.shape == a.shape and np.abs(back - a).max() < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Independent witnesses of the conventions that cora/healpy would fix (both absent: a10 stays "parity unpinned").
+# Each test names the convention it pins.
+
+
+def test_pixel_centres_literal_tables_nside_1_2():
+    """RING pixel centres for nside 1 and 2 written out as literal (z, phi/pi) rationals -- the published HEALPix
+    values (Gorski et al. 2005 eqs. 4-9 with the library's ring start: belt rings with odd ``i + nside`` start at
+    phi = 0, the others half a pixel in).  Pins: ring order north -> south, pixel order west -> east inside a ring,
+    ring latitudes, the half-pixel stagger."""
+    from fractions import Fraction as F
+
+    tables = {
+        1: [(F(2, 3), [F(1, 4), F(3, 4), F(5, 4), F(7, 4)]), (F(0), [F(0), F(1, 2), F(1), F(3, 2)]), (F(-2, 3), [F(1, 4), F(3, 4), F(5, 4), F(7, 4)])],
+        2: [
+            (F(11, 12), [F(2 * k + 1, 4) for k in range(4)]),
+            (F(2, 3), [F(2 * k + 1, 8) for k in range(8)]),
+            (F(1, 3), [F(k, 4) for k in range(8)]),
+            (F(0), [F(2 * k + 1, 8) for k in range(8)]),
+            (F(-1, 3), [F(k, 4) for k in range(8)]),
+            (F(-2, 3), [F(2 * k + 1, 8) for k in range(8)]),
+            (F(-11, 12), [F(2 * k + 1, 4) for k in range(4)]),
+        ],
+    }
+    for nside, rings in tables.items():
+        zs = np.array([float(z) for z, phis in rings for _ in phis])
+        ph = np.array([float(p) * np.pi for _, phis in rings for p in phis])
+        assert zs.size == 12 * nside**2
+        th, phi = sht.pix_angles(nside)
+        np.testing.assert_allclose(np.cos(th), zs, atol=1e-15)
+        np.testing.assert_allclose(phi, ph, atol=1e-15)
+    # the values quoted in healpy's documentation of pix2ang(nside=1/2): theta of the first rings
+    th1, _ = sht.pix_angles(1)
+    np.testing.assert_allclose(th1[[0, 4, 8]], [0.84106867, 1.57079633, 2.30052398], atol=5e-9)
+    th2, _ = sht.pix_angles(2)
+    np.testing.assert_allclose(th2[[0, 4, 12, 20]], [0.41113786, 0.84106867, 1.23095942, 1.57079633], atol=5e-9)
+
+
+@pytest.mark.parametrize("nside", [1, 2, 3, 4, 8, 16, 32])
+def test_point_in_pixel_rule_agrees_with_ring_tables(nside):
+    """The boundary-equation ``ang2pix`` (independent of ``ring_info``) maps every tabulated centre to its own
+    index, and random directions fall into equal-area pixels.  Pins the pixel numbering against the published
+    point-in-pixel rule; ``lonlat=True`` is the form the reference calls (beamform.py:1708,1760)."""
+    th, ph = sht.pix_angles(nside)
+    npix = 12 * nside**2
+    np.testing.assert_array_equal(sht.ang2pix_ring(nside, th, ph), np.arange(npix))
+    np.testing.assert_array_equal(sht.ang2pix_lonlat(nside, np.degrees(ph), 90.0 - np.degrees(th)), np.arange(npix))
+    if nside <= 8:
+        rng = np.random.default_rng(nside)
+        n = 400 * npix
+        z = rng.uniform(-1, 1, n)
+        cnt = np.bincount(sht.ang2pix_ring(nside, np.arccos(z), rng.uniform(0, 2 * np.pi, n)), minlength=npix)
+        assert cnt.size == npix and np.abs(cnt - 400).max() < 6 * 20  # Poisson sigma = 20
+
+
+@pytest.mark.parametrize("nside,lmax", [(1, 2), (2, 5), (4, 8), (8, 16)])
+def test_scalar_synthesis_whole_map_against_scipy(nside, lmax):
+    """The whole scalar map from SciPy's Y_lm at the pixel centres: T = sum_l a_l0 Y_l0 + 2 Re sum_{m>0} a_lm Y_lm.
+    Pins, independently of the oracle's recurrences: the a_lm index order [l, m], the Condon-Shortley phase, the
+    real-field (m >= 0 only) convention and the orthonormal Y_lm normalisation healpy documents."""
+    from scipy.special import sph_harm_y
+
+    rng = np.random.default_rng(100 * nside + lmax)
+    a = _rand_alm(rng, lmax, npol=1)
+    th, ph = sht.pix_angles(nside)
+    ref = np.zeros(th.size)
+    for l in range(lmax + 1):
+        ref += (a[0, l, 0] * sph_harm_y(l, 0, th, ph)).real
+        for m in range(1, l + 1):
+            ref += 2.0 * (a[0, l, m] * sph_harm_y(l, m, th, ph)).real
+    np.testing.assert_allclose(sht.alm2map(a, nside)[0], ref, atol=1e-12 * np.abs(ref).max())
+    # V (slot 3 of a four-polarisation transform) is the same scalar transform
+    a4 = _rand_alm(rng, lmax)
+    a4[3] = a[0]
+    np.testing.assert_allclose(sht.alm2map(a4, nside)[3], ref, atol=1e-12 * np.abs(ref).max())
+
+
+def test_spin2_whole_map_against_scipy_derivatives():
+    """Q, U of a whole map from second derivatives of SciPy's Y_lm: with P = Q + iU = sum_lm -(E + iB)_lm (+2Y_lm) and
+    +2Y_lm = edth edth Y_lm / sqrt((l+2)!/(l-2)!) (Newman-Penrose; Zaldarriaga & Seljak 1997 eq. 6 -- the convention
+    HEALPix documents).  edth is applied by finite differences in theta to SciPy's functions, so nothing of the oracle's
+    Legendre/KKS code is involved.  Pins the (E, B) -> (Q, U) signs and the HEALPix polarisation convention."""
+    from scipy.special import sph_harm_y
+
+    nside, lmax = 2, 4
+    rng = np.random.default_rng(77)
+    a = _rand_alm(rng, lmax)
+    th, ph = sht.pix_angles(nside)
+
+    P = np.zeros(th.size, complex)
+    h = 1e-3
+    for l in range(2, lmax + 1):
+        norm = np.sqrt(float((l - 1) * l * (l + 1) * (l + 2)))
+        for m in range(-l, l + 1):
+            am = abs(m)
+            E = a[1, l, am] if m >= 0 else (-1) ** am * np.conj(a[1, l, am])
+            B = a[2, l, am] if m >= 0 else (-1) ** am * np.conj(a[2, l, am])
+
+            def Y(t):
+                return sph_harm_y(l, m, t, 0.0)
+
+            def spin1(t):  # edth Y (spin 0 -> 1): -(dY/dtheta - m/sin Y)   [i d/dphi -> -m]
+                return -((Y(t + h) - Y(t - h)) / (2 * h) - m / np.sin(t) * Y(t))
+
+            def spin2(t):  # edth (spin 1 -> 2): -(d/dtheta - m/sin - cot) f
+                f = spin1
+                return -((f(t + h) - f(t - h)) / (2 * h) - m / np.sin(t) * f(t) - np.cos(t) / np.sin(t) * f(t))
+
+            P += -(E + 1j * B) * spin2(th) / norm * np.exp(1j * m * ph)
+    mp = sht.alm2map(a, nside)
+    scale = np.abs(P).max()
+    np.testing.assert_allclose(mp[1], P.real, atol=3e-5 * scale)  # finite differences: O(h^2)
+    np.testing.assert_allclose(mp[2], P.imag, atol=3e-5 * scale)
