@@ -299,23 +299,32 @@ class TelescopeStreamMixIn:
 
 
 def _redefine_stack_index_map(tel, tel_index, prod, stack, reverse_stack):
-    """Representative products made of present, unmasked inputs (``util/tools.py:359-414``)."""
-    stack_new = stack.copy()
-    stack_flag = np.zeros(stack_new.size, dtype=bool)
-    feedmask = np.asarray(tel.feedmask)
-    for sind, (ii, jj) in enumerate(zip(prod["input_a"][stack["prod"]], prod["input_b"][stack["prod"]])):
-        bi, bj = tel_index[ii], tel_index[jj]
-        if (bi is None) or (bj is None) or not feedmask[bi, bj]:
-            for ts in np.flatnonzero(reverse_stack["stack"] == sind):
-                ti, tj = tel_index[prod["input_a"][ts]], tel_index[prod["input_b"][ts]]
-                if (ti is not None) and (tj is not None) and feedmask[ti, tj]:
-                    stack_new["prod"][sind] = ts
-                    stack_new["conjugate"][sind] = reverse_stack["conjugate"][ts]
-                    stack_flag[sind] = True
-                    break
-        else:
-            stack_flag[sind] = True
-    return stack_new, stack_flag
+    """Give every stack entry a representative product the telescope can use (``util/tools.py:359-414``).
+
+    A product is *usable* when both of its inputs exist in the telescope (``tel_index[i]`` is not None) and the pair
+    is not masked there.  Entries whose current representative is usable keep it; the others take the first usable
+    member of their stack (lowest product index) together with that member's conjugation flag.  Returns the new map
+    and, per entry, whether a usable representative exists at all.
+    """
+    present = np.array([t is not None for t in tel_index], dtype=bool)
+    slot = np.array([t if t is not None else 0 for t in tel_index], dtype=np.int64)
+    pa, pb = np.asarray(prod["input_a"], dtype=np.int64), np.asarray(prod["input_b"], dtype=np.int64)
+    usable = present[pa] & present[pb] & np.asarray(tel.feedmask)[slot[pa], slot[pb]]  # per product of the file
+
+    nstack = stack.size
+    member_of = np.asarray(reverse_stack["stack"], dtype=np.int64)
+    cand = np.flatnonzero(usable & (member_of >= 0) & (member_of < nstack))
+    first = np.full(nstack, len(pa), dtype=np.int64)
+    np.minimum.at(first, member_of[cand], cand)  # lowest usable member of every stack
+
+    current = np.asarray(stack["prod"], dtype=np.int64)
+    keep = usable[current]
+    found = keep | (first < len(pa))
+    swap = ~keep & found
+    out = stack.copy()
+    out["prod"][swap] = first[swap]
+    out["conjugate"][swap] = reverse_stack["conjugate"][first[swap]]
+    return out, found
 
 
 class CollateProducts(TelescopeStreamMixIn, ContainerTask):

@@ -79,41 +79,51 @@ class GaussianNoise(_RandomTask):
     def setup(self, manager=None):
         self.telescope = io.get_telescope(manager) if manager is not None else None
 
-    def process(self, data):
-        data.redistribute("freq")
-        visdata = data.vis[:]
-        if isinstance(data, containers.SiderealStream):
-            dt = 240 * (data.ra[1] - data.ra[0]) * STELLAR_S
-            ntime = len(data.ra)
-        else:
-            dt = data.time[1] - data.time[0]
-            ntime = len(data.time)
-        df = data.index_map["freq"]["width"][0] * 1e6  # assumes uniform channels, like the reference
-        nfreq = visdata.shape[0]
-        prodstack = _prodstack(data)
-        nprod = len(prodstack)
-        ninput = len(data.index_map["input"])
+    def _samples_per_product(self, data, nprod):
+        """Independent samples behind each (stacked) product of ``data``: ``int(ndays * dt * df) * redundancy``.
 
-        if self.telescope is not None and nprod == getattr(self.telescope, "nbase", -1):
-            redundancy = np.asarray(self.telescope.redundancy)
-        elif nprod == ninput * (ninput + 1) / 2:
-            redundancy = np.ones(nprod)
+        The radiometer count uses the first channel's width for the whole band, as the reference does
+        (``noise.py:243-244``).  A stream that matches the telescope's unique baselines is taken to be redundancy
+        stacked; the full triangle of its inputs counts every product once; anything else is refused (``:250-256``).
+        """
+        cadence = _sample_interval(data)
+        bandwidth = data.index_map["freq"]["width"][0] * 1e6
+        ninput = len(data.index_map["input"])
+        tel = self.telescope
+        if tel is not None and nprod == getattr(tel, "nbase", -1):
+            copies = np.asarray(tel.redundancy, dtype=np.float64)
+        elif 2 * nprod == ninput * (ninput + 1):
+            copies = np.ones(nprod)
         else:
             raise ValueError("Unexpected number of products")
+        return int(self.ndays * cadence * bandwidth) * copies
 
-        nsamp = int(self.ndays * dt * df) * redundancy
-        std = self.recv_temp / np.sqrt(nsamp)
+    def process(self, data):
+        """Add the noise to ``data`` in place and/or set its weights to ``1 / sigma^2`` (``noise.py:219-284``)."""
+        data.redistribute("freq")
+        pairs = _prodstack(data)
+        sigma = self.recv_temp / np.sqrt(self._samples_per_product(data, len(pairs)))  # [nprod]
 
         if self.add_noise:
-            noise = random.complex_normal(size=(nfreq, nprod, ntime), scale=std[np.newaxis, :, np.newaxis], rng=self.rng)
-            auto = prodstack["input_a"] == prodstack["input_b"]
-            # autos are real with twice the variance (noise.py:270-277)
-            visdata[:, auto] = visdata[:, auto] + (np.sqrt(2) * noise[:, auto].real).astype(visdata.real.dtype)
-            visdata[:, ~auto] = visdata[:, ~auto] + noise[:, ~auto].astype(visdata.dtype)
-            data.vis[:] = visdata
+            vis = data.vis[:]
+            nfreq, nprod, ntime = vis.shape
+            # one draw for the whole stream, standard deviation per product (the reference's single call, :261-265)
+            draw = random.complex_normal(size=(nfreq, nprod, ntime), scale=sigma[None, :, None], rng=self.rng)
+            is_auto = np.asarray(pairs["input_a"]) == np.asarray(pairs["input_b"])
+            # an auto-correlation is real: all of sigma^2 goes into its real part (sqrt(2) x the real half, :270-273)
+            draw[:, is_auto] = np.sqrt(2) * draw[:, is_auto].real
+            np.add(vis, draw, out=vis, casting="same_kind")  # summed in float64, rounded once to the stream's dtype
+            data.vis[:] = vis
         if self.set_weights:
-            data.weight[:] = (1.0 / std[:, np.newaxis] ** 2)[np.newaxis]
+            data.weight[:] = np.broadcast_to((1.0 / sigma**2)[None, :, None], data.weight.shape)
         return data
+
+
+def _sample_interval(data):
+    """Seconds between samples: 240 s of sidereal time per degree of RA for a sidereal stream, else the time step."""
+    if isinstance(data, containers.SiderealStream):
+        return 240 * (data.ra[1] - data.ra[0]) * STELLAR_S
+    return data.time[1] - data.time[0]
 
 
 class SampleNoise(_RandomTask):
@@ -140,10 +150,7 @@ class SampleNoise(_RandomTask):
         weight = data_exp.weight[:]
         if vis_data.shape[1] != nfeed * (nfeed + 1) // 2:
             raise ValueError("SampleNoise needs the full triangle of products")
-        if isinstance(data_exp, containers.SiderealStream):
-            dt = 240 * (data_exp.ra[1] - data_exp.ra[0]) * STELLAR_S
-        else:
-            dt = data_exp.time[1] - data_exp.time[0]
+        dt = _sample_interval(data_exp)
         iu = np.triu_indices(nfeed)
         diag = np.array([_cmap(i, i, nfeed) for i in range(nfeed)])
         pa, pb = iu

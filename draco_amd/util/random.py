@@ -1,61 +1,86 @@
-"""Random draws used by the noise tasks (host side, NumPy ``Generator``).
+"""Random draws behind the noise tasks of config 5 (host side, NumPy ``Generator``).
 
-Same draw order as ``draco/util/random.py`` so that a seeded ``np.random.Generator`` gives the
-reference's stream: :func:`complex_normal` (``random.py:7-83``),
-:func:`standard_complex_wishart` (``:106-137``, Bartlett factor), :func:`complex_wishart`
-(``:140-166``).  Input generation only -- not a GPU target.
+Input generation, not a GPU target.  What has to agree with
+``draco/util/random.py`` is the *stream*: a ``Generator`` seeded alike must give the same numbers,
+which fixes the order and the dtype of the underlying draws and nothing else --
+
+* :func:`complex_normal`: ONE ``standard_normal`` call of the real dtype over the output viewed as
+  interleaved (re, im) pairs (``random.py:7-83``);
+* :func:`standard_complex_wishart`: the strict lower triangle of the Bartlett factor in row-major order,
+  all real parts first and then all imaginary parts, then one ``gamma`` draw per diagonal entry from the
+  top (``random.py:106-137``);
+* :func:`complex_wishart`: colours a standard draw with the Cholesky factor of ``C`` (``random.py:140-166``).
+
+``tests/golden/noise.npz`` (the reference functions run from source) enforces exactly that.
 """
 
 from __future__ import annotations
 
 import numpy as np
 
+_REAL_OF = {np.dtype(np.complex64): np.float32, np.dtype(np.complex128): np.float64}
+
+
+def _target(size, dtype, out):
+    """Settle shape / dtype / destination of a draw from whichever of the three the caller gave."""
+    if out is not None:
+        if size is not None and tuple(np.shape(out)) != tuple(np.atleast_1d(size)):
+            raise ValueError(f"`out` has shape {np.shape(out)} but size={size} was requested")
+        if dtype is not None and np.dtype(dtype) != out.dtype:
+            raise ValueError(f"`out` is {out.dtype} but dtype={np.dtype(dtype)} was requested")
+        cdt = out.dtype
+    else:
+        cdt = np.dtype(np.complex128 if dtype is None else dtype)
+    if cdt not in _REAL_OF:
+        raise ValueError(f"complex draws exist for complex64 and complex128 only, not {cdt}")
+    if out is None:
+        shape = (1,) if size is None else tuple(int(n) for n in np.atleast_1d(size))
+        out = np.empty(shape, dtype=cdt)
+    return out, _REAL_OF[cdt]
+
 
 def complex_normal(loc=0.0, scale=1.0, size=None, dtype=None, rng=None, out=None):
-    """Complex normal variates with total standard deviation ``scale`` (``random.py:7-83``)."""
-    if size is None:
-        size = (1,) if out is None else out.shape
-    elif out is not None and tuple(out.shape) != tuple(size):
-        raise ValueError(f"Shape of output array ({out.shape}) != size argument ({size}")
-    if dtype is None:
-        dtype = np.complex128 if out is None else out.dtype.type
-    elif out is not None and out.dtype.type != dtype:
-        raise ValueError(f"Dtype of output array ({out.dtype.type}) != dtype argument ({dtype}")
-    real = {np.complex64: np.float32, np.complex128: np.float64}.get(dtype)
-    if real is None:
-        raise ValueError(f"Only dtype must be complex64 or complex128. Got dtype={dtype}.")
-    if rng is None:
-        rng = np.random.default_rng()
-    if out is None:
-        out = np.empty(size, dtype=dtype)
-    # (re, im) interleaved draws straight into the output's real view
-    rng.standard_normal((*size[:-1], 2 * size[-1]), dtype=real, out=out.view(real))
+    """Circular complex Gaussian variates, mean ``loc`` and *total* standard deviation ``scale``.
+
+    ``loc`` / ``scale`` broadcast against the result; ``out`` (a C-contiguous complex array) is filled in place
+    when given.  Real and imaginary parts each carry ``scale**2 / 2`` of the variance.
+    """
+    out, real = _target(size, dtype, out)
+    gen = np.random.default_rng() if rng is None else rng
+    pairs = out.view(real)  # [..., 2 n]: re0 im0 re1 im1 ...
+    gen.standard_normal(pairs.shape, dtype=real, out=pairs)
+    # (a Python-float scale must stay a Python float: NumPy then multiplies in the output's own precision)
     out *= scale / 2**0.5
-    if np.any(loc != 0.0):
+    if np.any(np.asarray(loc) != 0):
         out += loc
     return out
 
 
 def standard_complex_normal(shape, dtype=None, rng=None):
+    """Unit-variance, zero-mean :func:`complex_normal` of the given shape."""
     return complex_normal(size=shape, dtype=dtype, rng=rng)
 
 
 def standard_complex_wishart(m, n, rng=None):
-    """Standard complex Wishart ``T T^H`` from the Bartlett factor ``T`` (``random.py:106-137``)."""
-    if rng is None:
-        rng = np.random.default_rng()
-    nlow = m * (m - 1) // 2
+    """A draw from the standard complex Wishart distribution ``W_m(I, n)`` by Bartlett's decomposition.
+
+    ``A = T T^H`` with ``T`` lower triangular, ``T_ii^2 ~ Gamma(n - i)`` and unit complex normals below the
+    diagonal.
+    """
+    gen = np.random.default_rng() if rng is None else rng
+    below = np.tril_indices(m, k=-1)
+    count = below[0].size
+    re = gen.standard_normal(count)
+    im = gen.standard_normal(count)
     T = np.zeros((m, m), dtype=np.complex128)
-    T[np.tril_indices(m, k=-1)] = (rng.standard_normal(nlow) + 1.0j * rng.standard_normal(nlow)) / 2**0.5
-    for i in range(m):
-        T[i, i] = rng.gamma(n - i) ** 0.5
-    return T @ T.T.conj()
+    T[below] = (re + 1j * im) / 2**0.5
+    T[np.diag_indices(m)] = [np.sqrt(gen.gamma(n - k)) for k in range(m)]
+    return T @ T.conj().T
 
 
 def complex_wishart(C, n, rng=None):
-    """``L A L^H`` with ``C = L L^H`` and ``A`` standard Wishart (``random.py:140-166``)."""
-    import scipy.linalg as la
-
-    L = la.cholesky(C, lower=True)
+    """A draw from ``W(C, n)``: ``L A L^H`` for ``C = L L^H`` and ``A`` standard Wishart with ``n`` samples."""
+    C = np.asarray(C)
+    L = np.linalg.cholesky(C)
     A = standard_complex_wishart(C.shape[0], n, rng=rng)
-    return L @ (A @ L.T.conj())
+    return L @ A @ L.conj().T

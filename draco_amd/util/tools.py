@@ -17,14 +17,26 @@ def invert_no_zero(x):
     return out
 
 
-def find_keys(key_list, keys, require_match=False):
-    """Indices of ``keys`` in ``key_list`` by exact match (``tools.py:95-127``)."""
+def _as_key(k):
+    """A hashable form of one key: scalars as they are, sequences (rows of a 2-D key list) as tuples."""
     try:
-        lookup = {tuple(k): i for i, k in enumerate(key_list)}
-        index = [lookup.get(tuple(k)) for k in keys]
+        hash(k)
+        return k
     except TypeError:
-        lookup = {k: i for i, k in enumerate(key_list)}
-        index = [lookup.get(k) for k in keys]
-    if require_match and any(i is None for i in index):
+        return tuple(k)
+
+
+def find_keys(key_list, keys, require_match=False):
+    """Position of every entry of ``keys`` inside ``key_list`` (exact equality; ``tools.py:95-127``).
+
+    Entries that do not occur give ``None``, or -- with ``require_match`` -- the reference's
+    ``ValueError("Could not find all of the keys.")``, which ``BaseMapMaker.process`` relies on for data frequencies
+    the beam transfers lack (``mapmaker.py:59``).  When a key occurs twice the last occurrence wins, as in a dict.
+    """
+    position = {}
+    for i, k in enumerate(key_list):
+        position[_as_key(k)] = i
+    found = [position.get(_as_key(k)) for k in keys]
+    if require_match and None in found:
         raise ValueError("Could not find all of the keys.")
-    return index
+    return found

@@ -52,6 +52,38 @@ def beam_tile(seed, m, f, npairs, npol, lmax):
     return b
 
 
+def beam_row(seed, m, f, row, npairs, npol, lmax):
+    """Row ``row`` (0 .. 2*npairs-1: sign-major, pair-minor) of :func:`beam_tile` as ``[npol, lmax+1]`` without
+    generating the rest of the tile (config-sized read-back checks touch every (m, f) but one row of each)."""
+    m = int(m)
+    ntel = 2 * npairs
+    scale = np.sqrt(3.0 / (2.0 * ntel))
+    key = np.uint64(tile_key(seed, m, f))
+    n = npol * (lmax + 1)
+    ctr = np.arange(int(row) * n, (int(row) + 1) * n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h1 = _mix64(key + np.uint64(2) * ctr)
+        h2 = _mix64(key + np.uint64(2) * ctr + np.uint64(1))
+    re = ((h1 >> np.uint64(11)).astype(np.float64) * 2.0**-53 * 2.0 - 1.0) * scale
+    im = ((h2 >> np.uint64(11)).astype(np.float64) * 2.0**-53 * 2.0 - 1.0) * scale
+    b = (re + 1j * im).reshape(npol, lmax + 1)
+    b[:, :m] = 0.0
+    return b
+
+
+def sky_alm(cfg_seed, nfreq, lmax, npol=4):
+    """Band-limited Gaussian sky of SURVEY 8d: ``a_lm [nfreq, npol, lmax+1, lmax+1]`` with ``C_l = (l+1)^-2``,
+    seed ``4000 + cfg``; real m = 0, E/B start at l = 2."""
+    rng = np.random.default_rng(4000 + cfg_seed)
+    amp = (np.arange(lmax + 1) + 1.0) ** -1.0
+    a = (rng.standard_normal((nfreq, npol, lmax + 1, lmax + 1)) + 1j * rng.standard_normal((nfreq, npol, lmax + 1, lmax + 1))) * amp[None, None, :, None]
+    a *= np.tril(np.ones((lmax + 1, lmax + 1)))[None, None]
+    a[..., 0] = a[..., 0].real
+    if npol == 4:
+        a[:, 1:3, :2] = 0
+    return a
+
+
 def npairs_of(ncyl, nfeed_cyl):
     """Unique baselines (autos included) of ncyl x nfeed_cyl x 2-pol regular grid."""
     return 4 * (nfeed_cyl + (ncyl - 1) * (2 * nfeed_cyl - 1)) - 1
