@@ -19,7 +19,9 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdraco_amd.so")
+# DRACO_AMD_LIBRARY: load another build of the same library (the host-only sanitizer build, `make -C draco_amd/csrc
+# asan`, for the CPU-side ABI tests); unset in normal use.
+LIB_PATH = os.environ.get("DRACO_AMD_LIBRARY") or os.path.join(_HERE, "libdraco_amd.so")
 
 DMM_C64, DMM_C128 = 0, 1
 DMM_B_FULL, DMM_B_PACKED = 0, 1

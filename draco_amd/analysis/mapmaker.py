@@ -116,6 +116,7 @@ class BaseMapMaker(ContainerTask):
                 if "maps" not in out:
                     out["maps"] = ctx.empty((nfreq, 4, npix), np.float64)
                 side.wait_for(main)
+                side.uses(alm, out["maps"])  # read / written on the side stream: held until side.sync()
                 _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(out["maps"][f0:f1])))
 
             alm_d = self.make_alm(mmodes, on_freqs_done=sht_of)

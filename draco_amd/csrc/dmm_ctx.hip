@@ -126,6 +126,7 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
 int dmm_ctx_sync(dmm_ctx* c) {
   DMM_REQUIRE(c != nullptr, "dmm_ctx_sync: ctx is NULL");
   DMM_HIP(hipStreamSynchronize(c->stream));
+  if (c->aux_stream) DMM_HIP(hipStreamSynchronize(c->aux_stream));  // both streams: host-side reuse of any buffer is safe
   return DMM_OK;
 }
 

@@ -64,6 +64,22 @@ struct dmm_plan {
   int64_t b_bytes = 0;
 };
 
+// ---- Buffer rule of the library's second stream (`aux_stream`).
+// Caller buffers (B pool, workspace, alm ...) may be touched by work the library enqueues on `aux_stream` ONLY inside
+// an entry point that holds a `dmm_aux_scope`.  The scope's destructor host-synchronises the stream, so on EVERY
+// return path -- error returns included -- nothing of the second stream is still reading or writing a caller buffer
+// when the entry point returns: after the call the caller's buffers are governed by the caller's stream alone
+// (stream-ordered reuse or free is safe), and `dmm_ctx_sync` drains both streams for host-side reuse.
+struct dmm_aux_scope {
+  dmm_ctx* c;
+  explicit dmm_aux_scope(dmm_ctx* ctx) : c(ctx) {}
+  dmm_aux_scope(const dmm_aux_scope&) = delete;
+  dmm_aux_scope& operator=(const dmm_aux_scope&) = delete;
+  ~dmm_aux_scope() {
+    if (c && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+  }
+};
+
 int dmm_set_error(int code, const char* fmt, ...);
 #define DMM_HIP(call)                                                                  \
   do {                                                                                 \

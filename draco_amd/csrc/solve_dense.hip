@@ -459,6 +459,14 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   if (pl->ntile == 0) return DMM_OK;
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
+  // the eigen pass runs half-batches on the library's second stream inside B, workspace and alm: drained on every
+  // return path (dmm_internal.h, "Buffer rule"); the caller's stream pointer is restored with it
+  dmm_aux_scope aux_guard(ctx);
+  struct StreamRestore {
+    dmm_ctx* c;
+    hipStream_t s;
+    ~StreamRestore() { c->stream = s; }
+  } stream_guard{ctx, ctx->stream};
   const Layout L = layout_of(pl, 2);  // telescope-side order: the largest any batch uses
   const int64_t wsb = dmm_ml_workspace_bytes(pl);
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));

@@ -39,6 +39,7 @@ class Context:
         _lib.check(_lib.lib.dmm_ctx_create(self.device_index, C.byref(h)))
         self.handle = h
         self.stream = stream  # None: follow torch's current stream; else pinned to this one
+        self._held: list = []  # tensors in use by this context's stream, released at sync()
         self.bind_stream()
 
     @classmethod
@@ -71,6 +72,20 @@ class Context:
             cls._side_cache[device] = cls(device, st)
         return cls._side_cache[device]
 
+    # ---- buffer ownership across streams
+    # Rule: a tensor handed to work on a context whose stream is not the one torch allocated it on is (a) recorded on
+    # that stream (the caching allocator then will not hand its memory to anyone else before the work has finished)
+    # and (b) kept referenced by the context until `join()` / `sync()` -- so correctness never depends on which Python name
+    # happens to stay alive at the call site.  `uses()` is called by every task that launches on `Context.side()`.
+    def uses(self, *tensors):
+        st = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        for t in tensors:
+            if t is None:
+                continue
+            t.record_stream(st)
+            self._held.append(t)
+        return tensors[0] if len(tensors) == 1 else tensors
+
     def wait_for(self, other: "torch.cuda.Stream"):
         """Work launched on this (pinned) context after the call starts after ``other``'s work so far."""
         ev = torch.cuda.Event()
@@ -80,6 +95,9 @@ class Context:
     def join(self, other: "torch.cuda.Stream"):
         """``other``'s later work waits for everything launched on this (pinned) context so far."""
         other.wait_stream(self.stream)
+        # from here on `other` is ordered behind this context's work and `record_stream` guards the allocator:
+        # the references taken by `uses()` have done their job
+        self._held.clear()
 
     def bind_stream(self):
         """Launch on torch's current stream of this device (so torch allocations/copies order with kernels)."""
@@ -87,7 +105,9 @@ class Context:
         _lib.check(_lib.lib.dmm_ctx_set_stream(self.handle, C.c_void_p(s)))
 
     def sync(self):
+        """Drain the context's stream (and the library's second one); buffers held by `uses()` are released."""
         _lib.check(_lib.lib.dmm_ctx_sync(self.handle))
+        self._held.clear()
 
     def timer_start(self):
         _lib.check(_lib.lib.dmm_timer_start(self.handle))

@@ -14,6 +14,10 @@
  *     library never frees caller memory and keeps no caller pointer after a call
  *     returns (work is enqueued on the context's stream: the caller must keep the
  *     buffers alive until dmm_ctx_sync / a stream sync of its own);
+ *   - second-stream rule: an entry point may run part of its work on a stream the
+ *     library owns (dmm_ml_run does); that stream is drained before the entry point
+ *     returns on every path, error returns included, so after ANY call the caller's
+ *     buffers are governed by the context's stream alone; dmm_ctx_sync drains both;
  *   - row-major (C order) everywhere, matching NumPy; complex = interleaved
  *     (re, im); complex64 = 2 x float, complex128 = 2 x double;
  *   - a context is not thread-safe; distinct contexts are independent;

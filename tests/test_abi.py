@@ -14,7 +14,7 @@ def _declared():
 
 
 def test_header_symbols_exported():
-    lib = ctypes.CDLL(os.path.join(ROOT, "draco_amd", "libdraco_amd.so"))
+    lib = ctypes.CDLL(os.environ.get("DRACO_AMD_LIBRARY") or os.path.join(ROOT, "draco_amd", "libdraco_amd.so"))
     names = _declared()
     assert len(names) >= 20
     for n in names:
