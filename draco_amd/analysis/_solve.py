@@ -20,23 +20,59 @@ _ELEM = {_lib.DMM_C64: 8, _lib.DMM_C128: 16}
 _TORCH = {_lib.DMM_C64: torch.complex64, _lib.DMM_C128: torch.complex128}
 
 
-# One multi-slab pool per device, kept between passes (a day's map-making is several passes: simulate, dirty, Wiener
-# ...): pools are a large fraction of the HBM, and handing one back to the caching allocator only to ask for a
-# slightly different size a moment later ends in a second pool-sized allocation.  Contents never outlive a slab.
+# One block of HBM per device for B, kept between passes (a day's map-making is several passes: simulate, dirty,
+# Wiener ...): it is a large fraction of the HBM, and handing it back to the caching allocator only to ask for a
+# slightly different size a moment later ends in a second pool-sized allocation.  The block is used whole (one buffer)
+# or as two halves (double buffering for providers whose tiles come over PCIe).  What each buffer currently HOLDS is
+# remembered (`content`), so a slab whose tiles are already resident -- the same day again, or the hbm-pool policy's
+# repeating frequencies -- is not filled a second time.
 _POOLS: dict[int, torch.Tensor] = {}
 
 
-def _take_pool(ctx, nelem, b_dtype):
-    """A ``[nelem]`` tensor of the B storage type on the context's device, carved from the kept pool when it fits."""
-    need = int(nelem) * _ELEM[b_dtype]
+class _Buffer:
+    """One buffer of the device's B block: its memory, what it holds, and the events that order its reuse."""
+
+    def __init__(self):
+        self.mem = None  # uint8 view
+        self.content = None  # key of the tiles it holds (None: garbage)
+        self.filled = None  # event: the fill that produced `content` has finished (on the fill stream)
+        self.last_use = None  # event: the last solve that read it has finished (on the caller's stream)
+
+
+_BUFFERS: dict[int, list[_Buffer]] = {}
+
+
+def _take_block(ctx, nbytes):
+    """The kept uint8 block of the context's device, grown if needed (growing discards what the buffers hold)."""
     kept = _POOLS.get(ctx.device_index)
-    if kept is None or kept.numel() < need:
+    if kept is None or kept.numel() < nbytes:
         _POOLS.pop(ctx.device_index, None)
+        _BUFFERS.pop(ctx.device_index, None)
         del kept
+        torch.cuda.synchronize(ctx.device)
         torch.cuda.empty_cache()  # give the old block back before asking for a larger one
-        kept = torch.empty(need, dtype=torch.uint8, device=ctx.device)
+        kept = torch.empty(int(nbytes), dtype=torch.uint8, device=ctx.device)
         _POOLS[ctx.device_index] = kept
-    return kept[:need].view(_TORCH[b_dtype])
+    return kept
+
+
+def _buffers(ctx, nbuf, buf_bytes):
+    """``nbuf`` buffers of ``buf_bytes`` carved from the device's block; contents survive while the carving does."""
+    buf_bytes = (int(buf_bytes) + 255) & ~255
+    block = _take_block(ctx, nbuf * buf_bytes)
+    bufs = _BUFFERS.get(ctx.device_index)
+    # a carving made for larger buffers still serves (its contents stay valid); anything else is re-carved
+    if bufs is None or len(bufs) != nbuf or bufs[0].mem.numel() < buf_bytes:
+        if bufs is not None:
+            torch.cuda.synchronize(ctx.device)  # re-carving moves buffer boundaries under work that may be in flight
+        size = block.numel() // nbuf & ~255
+        bufs = []
+        for k in range(nbuf):
+            b = _Buffer()
+            b.mem = block[k * size : (k + 1) * size]
+            bufs.append(b)
+        _BUFFERS[ctx.device_index] = bufs
+    return bufs
 
 
 def _tile_sizes(provider, ms, b_layout):
@@ -51,7 +87,9 @@ def _tile_sizes(provider, ms, b_layout):
 
 
 def release_pools():
-    """Give the kept pools back (to the caching allocator, and on to the device)."""
+    """Give the kept block back (to the caching allocator, and on to the device)."""
+    torch.cuda.synchronize()
+    _BUFFERS.clear()
     _POOLS.clear()
     torch.cuda.empty_cache()
 
@@ -59,7 +97,7 @@ def release_pools():
 class Slab:
     """A resident pool of B tiles + the plan that solves them."""
 
-    def __init__(self, ctx, provider, ms, fs_data, fs_bt, b_dtype, b_layout, nfreq_data, n_m, pool=None):
+    def __init__(self, ctx, provider, ms, fs_data, fs_bt, b_dtype, b_layout, nfreq_data, n_m, pool=None, fill=True):
         tel = provider.telescope
         self.ctx = ctx
         self.ntile = len(ms)
@@ -69,11 +107,12 @@ class Slab:
             np.cumsum(sizes[:-1], out=offs[1:])
         self.nelem = int(sizes.sum())
         self.tiles = _lib.tile_array(ms, fs_data, offs)
-        fill_tiles = _lib.tile_array(ms, fs_bt, offs)
+        self.fill_tiles = _lib.tile_array(ms, fs_bt, offs)
         if pool is None or pool.numel() < self.nelem or pool.dtype != _TORCH[b_dtype]:
             pool = torch.empty(max(self.nelem, 1), dtype=_TORCH[b_dtype], device=ctx.device)
         self.pool = pool
-        provider.fill_pool(ctx, pool, fill_tiles, b_dtype, b_layout)
+        if fill:
+            provider.fill_pool(ctx, pool, self.fill_tiles, b_dtype, b_layout)
         h = C.c_void_p()
         _lib.check(
             _lib.lib.dmm_solve_plan_create(
@@ -96,7 +135,21 @@ class Slab:
 
 
 class SolveEngine:
-    """Runs one of {dirty, wiener, ml, project} over all (m <= mmax, f) with slabbed B."""
+    """Runs one of {dirty, wiener, ml, project} over all (m <= mmax, f) with slabbed B.
+
+    Slabs are consecutive ranges of the f-major / m-minor tile list.  Per slab: make sure its tiles are in a buffer
+    of the device's B block (skipped when they already are), then hand the buffer + plan to the caller, who launches
+    the solves on the current stream.  Fills run on a separate *fill context* (own stream) and are ordered against
+    the solves by events only -- the host never waits for the GPU here:
+
+    * a buffer is refilled only after the last solve that read it (``last_use``, recorded on the caller's stream);
+    * a slab is solved only after its fill (``filled``, recorded on the fill stream).
+
+    Providers whose tiles come from the host (``fill_mode == "host"``) get two buffers, so the upload of slab k+1
+    (worker threads packing into pinned slots, copies on the fill stream) runs under the solves of slab k; providers
+    that generate on the device get one (their fill is as HBM-bound as the solve: nothing to hide).
+    Plans are kept for the engine's lifetime (``dmm_plan_destroy`` frees device memory, which synchronises).
+    """
 
     def __init__(self, provider, ctx=None, b_dtype=_lib.DMM_C128, b_layout=_lib.DMM_B_PACKED, pool_bytes=None, cache=True):
         self.provider = provider
@@ -107,63 +160,119 @@ class SolveEngine:
         self.cache = cache
         self._cached_key = None
         self._cached_slabs = None
+        self._plans: dict = {}
         self.last_b_bytes = 0
+        self.fills = 0  # slabs actually filled (the others were resident)
+
+    def close(self):
+        for s in self._plans.values():
+            s.close()
+        self._plans.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def nbuf(self):
+        return 2 if getattr(self.provider, "fill_mode", "host") == "host" else 1
 
     def _budget(self):
+        """Bytes one buffer may take."""
         if self.pool_bytes is not None:
-            return int(self.pool_bytes)
+            return int(self.pool_bytes) // self.nbuf
         free, _total = torch.cuda.mem_get_info(self.ctx.device)
-        kept = _POOLS.get(self.ctx.device_index)  # the previous pass's pool is ours to take again
-        return int((free + (kept.numel() if kept is not None else 0)) * 0.6)
+        kept = _POOLS.get(self.ctx.device_index)  # the previous pass's block is ours to take again
+        return int((free + (kept.numel() if kept is not None else 0)) * 0.6) // self.nbuf
 
-    def _slab_ranges(self, ms):
-        """Split the tile list into consecutive ranges whose pool fits the budget; also the largest range's size
-        in elements (the one pool every slab of the pass is filled into)."""
+    def _slab_ranges(self, ms, n_m):
+        """Split the tile list into consecutive ranges whose tiles fit one buffer; also the largest range's size in
+        elements.  With an aliasing provider (hbm-pool policy) slabs are whole multiples of frequencies that divide
+        the alias period, so that consecutive slabs hold identical contents."""
         budget = self._budget() // _ELEM[self.b_dtype]
         sizes = _tile_sizes(self.provider, ms, self.b_layout)
         if len(sizes) and int(sizes.max()) > budget:
             raise MemoryError(f"one B tile ({int(sizes.max())} elements) exceeds the pool budget ({budget})")
         cum = np.concatenate([[0], np.cumsum(sizes)])
+        period = getattr(self.provider, "alias_period", None)
         ranges, start, largest = [], 0, 0
-        while start < len(ms):  # greedy: as many consecutive tiles as fit (one searchsorted per slab)
-            stop = int(np.searchsorted(cum, cum[start] + budget, side="right")) - 1
-            stop = max(stop, start + 1)
-            ranges.append((start, stop))
-            largest = max(largest, int(cum[stop] - cum[start]))
-            start = stop
+        if period and len(ms) % n_m == 0 and len(ms) // n_m > 1:
+            per_freq = int(cum[n_m])
+            g = max((d for d in range(1, int(period) + 1) if period % d == 0 and d * per_freq <= budget), default=0)
+            if g:
+                step = g * n_m
+                while start < len(ms):
+                    stop = min(start + step, len(ms))
+                    ranges.append((start, stop))
+                    largest = max(largest, int(cum[stop] - cum[start]))
+                    start = stop
+        if not ranges:
+            while start < len(ms):  # greedy: as many consecutive tiles as fit (one searchsorted per slab)
+                stop = int(np.searchsorted(cum, cum[start] + budget, side="right")) - 1
+                stop = max(stop, start + 1)
+                ranges.append((start, stop))
+                largest = max(largest, int(cum[stop] - cum[start]))
+                start = stop
         if not ranges:
             ranges.append((0, 0))
         self._pool_elems = largest
         return ranges
 
+    def _content_key(self, ms, fs_bt):
+        if not self.cache:
+            return None  # never matches: every slab is filled
+        canon = np.asarray(self.provider.canonical_freq(fs_bt), dtype=np.int32) if hasattr(self.provider, "canonical_freq") else fs_bt
+        key_of = getattr(self.provider, "content_key", None)
+        if key_of is None:
+            return None  # a foreign provider says nothing about its contents: no reuse
+        return (key_of(), self.b_dtype, self.b_layout, len(ms), ms.tobytes(), canon.tobytes())
+
     def slabs(self, freq_ind, mmax, nfreq_data, n_m):
-        """Yield :class:`Slab` objects covering f-major, m-minor order (cached if it is one slab)."""
+        """Yield :class:`Slab` objects covering f-major, m-minor order; each is ready (on the current stream) when
+        yielded and must have its solves launched on the current stream before the generator is advanced."""
         nf = len(freq_ind)
         ms = np.tile(np.arange(mmax + 1, dtype=np.int32), nf)
         fs_data = np.repeat(np.arange(nf, dtype=np.int32), mmax + 1)
         fs_bt = np.repeat(np.asarray(freq_ind, dtype=np.int32), mmax + 1)
         key = (tuple(int(f) for f in freq_ind), int(mmax), int(nfreq_data), int(n_m), self.b_dtype, self.b_layout)
-        if self.cache and self._cached_key == key:
+        if self._cached_key == key and self._cached_slabs is not None:  # a slab installed by hand (single-tile solves)
             yield from self._cached_slabs
             return
-        ranges = self._slab_ranges(ms)
-        if self.cache and len(ranges) == 1:
-            a, b = ranges[0]
-            s = Slab(self.ctx, self.provider, ms[a:b], fs_data[a:b], fs_bt[a:b], self.b_dtype, self.b_layout, nfreq_data, n_m)
-            self._cached_key, self._cached_slabs = key, [s]
+        ctx = self.ctx
+        ranges = self._slab_ranges(ms, mmax + 1)
+        es = _ELEM[self.b_dtype]
+        bufs = _buffers(ctx, self.nbuf, max(self._pool_elems, 1) * es)
+        main = torch.cuda.current_stream(ctx.device)
+        fill_ctx = Context.fill(ctx.device_index) if self.nbuf > 1 else ctx
+        fill_stream = fill_ctx.stream if fill_ctx.stream is not None else main
+        for k, (a, b) in enumerate(ranges):
+            pkey = (key, a, b)
+            s = self._plans.get(pkey)
+            if s is None:
+                s = Slab(ctx, self.provider, ms[a:b], fs_data[a:b], fs_bt[a:b], self.b_dtype, self.b_layout, nfreq_data, n_m,
+                         pool=bufs[0].mem.view(_TORCH[self.b_dtype]), fill=False)
+                self._plans[pkey] = s
+            content = self._content_key(ms[a:b], fs_bt[a:b])
+            buf = next((x for x in bufs if content is not None and x.content == content), None)
+            if buf is None:
+                buf = bufs[k % len(bufs)]
+                buf.content = None
+                if buf.last_use is not None and fill_stream != main:
+                    fill_stream.wait_event(buf.last_use)  # the solves still reading the buffer
+                pool = buf.mem.view(_TORCH[self.b_dtype])
+                self.provider.fill_pool(fill_ctx, pool, s.fill_tiles, self.b_dtype, self.b_layout)
+                buf.filled = torch.cuda.Event()
+                buf.filled.record(fill_stream)
+                buf.content = content
+                self.fills += 1
+            if buf.filled is not None and fill_stream != main:
+                main.wait_event(buf.filled)
+            s.pool = buf.mem.view(_TORCH[self.b_dtype])
             yield s
-            return
-        # one pool for the whole pass, sized for its largest slab (slabs differ by a few tiles: growing the pool
-        # for a later one would need a second pool-sized allocation while the first is still alive)
-        pool = _take_pool(self.ctx, max(self._pool_elems, 1), self.b_dtype)
-        for a, b in ranges:
-            s = Slab(self.ctx, self.provider, ms[a:b], fs_data[a:b], fs_bt[a:b], self.b_dtype, self.b_layout, nfreq_data, n_m, pool)
-            pool = s.pool
-            try:
-                yield s
-            finally:
-                self.ctx.sync()  # the pool is about to be overwritten by the next slab
-                s.close()
+            buf.last_use = torch.cuda.Event()
+            buf.last_use.record(main)
 
     # ---- the four batched operations
     def solve(self, kind, mvis_d, mweight_d, freq_ind, mmax, on_freqs_done=None, **params):

@@ -23,6 +23,8 @@ HBM pool: :meth:`BeamTransferProvider.fill_pool`.
 
 from __future__ import annotations
 
+import itertools
+
 import numpy as np
 
 from .. import _lib
@@ -127,11 +129,46 @@ class TransitTelescope:
         self.uniquepairs = np.stack([up["input_a"].astype(int), up["input_b"].astype(int)], axis=1)
 
 
+_NPDT = {_lib.DMM_C128: np.complex128, _lib.DMM_C64: np.complex64}
+
+
+def tile_runs(tiles):
+    """Group a ``dmm_tile`` table into runs of consecutive m at one frequency whose pool offsets are back to back.
+
+    Returns a list of ``(f, m_lo, m_hi, b_off)`` (``m_hi`` exclusive).  Slabs are f-major / m-minor, so a slab is a
+    few runs: a partial first frequency, whole frequencies, a partial last one.
+    """
+    rec = np.frombuffer(tiles, dtype=_lib._TILE_DTYPE) if not isinstance(tiles, np.ndarray) else tiles
+    runs = []
+    n = len(rec)
+    if n == 0:
+        return runs
+    m, f, off = rec["m"].astype(np.int64), rec["f"].astype(np.int64), rec["b_off"]
+    brk = np.flatnonzero((np.diff(f) != 0) | (np.diff(m) != 1)) + 1
+    starts = np.concatenate([[0], brk])
+    stops = np.concatenate([brk, [n]])
+    for a, b in zip(starts, stops):
+        runs.append((int(f[a]), int(m[a]), int(m[b - 1]) + 1, int(off[a])))
+    return runs
+
+
 class BeamTransferProvider:
-    """Base provider: the reference-visible protocol + the bulk pool fill."""
+    """Base provider: the reference-visible protocol + the bulk hand-over (``beam_block`` / ``fill_pool``)."""
+
+    #: "device": ``fill_pool`` writes the pool with kernels (nothing crosses PCIe); "host": tiles come from host memory
+    fill_mode = "host"
+    #: tiles of frequency f are those of ``f % alias_period`` (the hbm-pool residency policy of SURVEY 8d); None: all distinct
+    alias_period = None
+    #: True when ``beam_block`` hands out views of memory the GPU can copy from directly (pinned)
+    block_is_pinned = False
+    #: worker threads that may call ``beam_block`` / ``beam_m`` at once (None: the host's share; 1: not thread-safe)
+    stage_workers = None
+
+    _uids = itertools.count(1)
 
     def __init__(self, telescope):
         self.telescope = telescope
+        self._uid = next(BeamTransferProvider._uids)  # never reused, unlike id(): a stale pool must not match a new provider
 
     # ---- names the reference tasks read
     @property
@@ -155,37 +192,121 @@ class BeamTransferProvider:
 
         return _solve.project_single_m(self, mi, vec)
 
+    # ---- identity of the tile contents (what may stay resident in a pool between passes)
+    def content_key(self):
+        """Identity of the tile CONTENTS: equal keys mean a pool filled from one serves the other.  Tiles are taken
+        to be immutable for the provider's lifetime (``beam_m`` of the same (m, f) always returns the same numbers)."""
+        return ("provider", self._uid)
+
+    def canonical_freq(self, f):
+        """The frequency index whose tiles frequency ``f`` shares (identity unless the provider aliases)."""
+        return f if self.alias_period is None else np.asarray(f) % int(self.alias_period)
+
     # ---- bulk hand-over
     def tile_elems(self, m, layout):
         tel = self.telescope
         w = tel.lmax + 1 if layout == _lib.DMM_B_FULL else tel.lmax + 1 - m
         return self.ntel * tel.num_pol_sky * w
 
-    def fill_pool(self, ctx, pool, tiles, dtype, layout):
-        """Write the tiles described by ``tiles`` (ctypes ``dmm_tile`` array) into ``pool``.
+    def beam_block(self, m_lo, m_hi, f_lo, f_hi, dtype=np.complex128, layout=_lib.DMM_B_PACKED, out=None):
+        """Tiles ``(m, f)`` for ``f_lo <= f < f_hi`` (outer), ``m_lo <= m < m_hi`` (inner) back to back in the pool's
+        wire format: each tile ``[ntel, npol, lmax+1-m]`` (packed) or ``[ntel, npol, lmax+1]`` (full), C order,
+        ``dtype``.  The bulk method SURVEY 8b asks of a provider; the reference has only the per-tile ``beam_m``
+        (``mapmaker.py:162``), which this generic version calls once per tile.  Returns a 1-D array (``out`` when
+        given); providers that hold their tiles in this format return views instead of copies.
+        """
+        tel = self.telescope
+        npdt = np.dtype(dtype)
+        sizes = [self.tile_elems(m, layout) for m in range(m_lo, m_hi)]
+        total = sum(sizes) * (f_hi - f_lo)
+        if out is None:
+            out = np.empty(total, dtype=npdt)
+        elif out.size != total or out.dtype != npdt:
+            raise ValueError(f"beam_block: out has {out.size} x {out.dtype}, need {total} x {npdt}")
+        pos = 0
+        for f in range(f_lo, f_hi):
+            for m, n in zip(range(m_lo, m_hi), sizes):
+                b = np.asarray(self.beam_m(m, fi=f)).reshape(self.ntel, tel.num_pol_sky, tel.lmax + 1)
+                if layout == _lib.DMM_B_PACKED:
+                    b = b[..., m:]
+                np.copyto(out[pos : pos + n].reshape(b.shape), b, casting="same_kind")
+                pos += n
+        return out
 
-        Generic implementation: one ``beam_m`` call per tile, pack on the host, copy up.
-        Providers that can do better (procedural, already-resident) override this.
+    def fill_pool(self, ctx, pool, tiles, dtype, layout, stager=None):
+        """Write the tiles described by ``tiles`` (ctypes ``dmm_tile`` array) into the device ``pool``.
+
+        Enqueues on ``ctx``'s stream and returns once everything is enqueued.  Generic host path: the table is cut
+        into chunks of whole tiles; each chunk is one :meth:`beam_block` call, packed into a pinned staging slot by a
+        worker thread and copied up asynchronously (``core/hoststage.py``), or copied straight from the provider's
+        own memory when that is pinned.  Providers that can do better (procedural, already resident) override this.
         """
         import torch
 
-        tel = self.telescope
-        npdt = np.complex128 if dtype == _lib.DMM_C128 else np.complex64
-        flat = pool.view(-1)
-        for t in tiles:
-            b = np.asarray(self.beam_m(t.m, fi=t.f)).reshape(self.ntel, tel.num_pol_sky, tel.lmax + 1)
-            if layout == _lib.DMM_B_PACKED:
-                b = b[..., t.m :]
-            h = np.ascontiguousarray(b, dtype=npdt).reshape(-1)
-            flat[t.b_off : t.b_off + h.size].copy_(torch.from_numpy(h), non_blocking=False)
+        from .hoststage import HostStager
+
+        npdt = np.dtype(_NPDT[dtype])
+        es = npdt.itemsize
+        if stager is None:
+            stager = HostStager.get(ctx.device, **({"workers": int(self.stage_workers)} if self.stage_workers else {}))
+        stream = ctx.stream if ctx.stream is not None else torch.cuda.current_stream(ctx.device)
+        pool_u8 = pool.view(-1).view(torch.uint8)
+        per_m = None
+        jobs = []
+        for f, m_lo, m_hi, b_off in tile_runs(tiles):
+            if per_m is None or len(per_m) < m_hi:
+                per_m = np.array([self.tile_elems(m, layout) for m in range(max(m_hi, self.telescope.mmax + 1))], dtype=np.int64)
+                per_m += per_m & 1  # the slab pads tiles to an even element count (a no-op: ntel is even)
+            # cut the run into chunks of whole tiles that fit a slot
+            m0 = m_lo
+            while m0 < m_hi:
+                cum = np.cumsum(per_m[m0:m_hi]) * es
+                k = int(np.searchsorted(cum, stager.slot_bytes, side="right"))
+                if k == 0:
+                    if not self.block_is_pinned:
+                        raise MemoryError(f"one tile ({int(cum[0])} bytes) exceeds the staging slot ({stager.slot_bytes})")
+                    k = 1
+                if self.block_is_pinned:
+                    k = m_hi - m0  # no staging: the whole run in one copy
+                m1 = m0 + k
+                nbytes = int(per_m[m0:m1].sum()) * es
+                dst = (b_off + int(per_m[m_lo:m0].sum())) * es
+                if self.block_is_pinned:
+                    src = self.beam_block(m0, m1, f, f + 1, npdt, layout)
+                    jobs.append((dst, nbytes, torch.from_numpy(src.view(np.uint8))))
+                else:
+                    jobs.append((dst, nbytes, _Producer(self, m0, m1, f, npdt, layout)))
+                m0 = m1
+        stager.upload(jobs, pool_u8, stream)
+
+
+class _Producer:
+    """Packs one chunk (tiles m0..m1-1 of frequency f) into a staging slot; runs on a worker thread."""
+
+    __slots__ = ("p", "m0", "m1", "f", "dt", "layout")
+
+    def __init__(self, p, m0, m1, f, dt, layout):
+        self.p, self.m0, self.m1, self.f, self.dt, self.layout = p, m0, m1, f, dt, layout
+
+    def __call__(self, out_u8):
+        out = out_u8.view(self.dt)
+        blk = self.p.beam_block(self.m0, self.m1, self.f, self.f + 1, self.dt, self.layout, out=out)
+        if blk is not out:  # the provider returned a view of its own (pageable) memory: one GIL-free memcpy
+            np.copyto(out, blk, casting="same_kind")
 
 
 class SyntheticProvider(BeamTransferProvider):
     """Seeded procedural B tiles, ``B ~ U``-complex with variance ``1/ntel``, zeros for ``l < m``."""
 
+    fill_mode = "device"
+
     def __init__(self, telescope, seed=3000):
         super().__init__(telescope)
         self.seed = int(seed)
+
+    def content_key(self):
+        tel = self.telescope
+        return ("synthetic", self.seed, tel.npairs, tel.num_pol_sky, tel.lmax)
 
     def beam_m(self, m, fi=None):
         tel = self.telescope
@@ -193,7 +314,7 @@ class SyntheticProvider(BeamTransferProvider):
             return np.stack([self.beam_m(m, fi=f) for f in range(tel.nfreq)])
         return synth_beam_tile(self.seed, m, fi, tel.npairs, tel.num_pol_sky, tel.lmax)
 
-    def fill_pool(self, ctx, pool, tiles, dtype, layout):
+    def fill_pool(self, ctx, pool, tiles, dtype, layout, stager=None):
         from ..device import ptr
 
         tel = self.telescope
@@ -219,8 +340,123 @@ class ArrayProvider(BeamTransferProvider):
         return np.asarray(b).reshape(2, tel.npairs, tel.num_pol_sky, tel.lmax + 1)
 
 
+class PackedStoreProvider(BeamTransferProvider):
+    """Tiles held in host memory ALREADY in the pool's wire format.
+
+    ``store`` is a flat array (ndarray, ``np.memmap`` or the NumPy view of a pinned torch tensor) holding, for every
+    frequency ``f`` of the telescope (outer) and every ``m = 0 .. mmax`` (inner), the packed tile
+    ``[ntel, npol, lmax+1-m]`` in C order -- what ``bt.beam_m(m, fi=f)[..., m:]`` flattens to.  ``beam_block`` then is
+    a slice: whole runs go to the GPU with no host-side packing; if the memory is pinned (``pinned=True``) the copy
+    engine reads it directly, otherwise worker threads memcpy it through the pinned staging ring.
+    A complex64 store halves the PCIe bytes (use it with ``b_dtype = "complex64"``).
+    """
+
+    def __init__(self, telescope, store, pinned=False, keepalive=None):
+        super().__init__(telescope)
+        tel = telescope
+        self.store = store
+        self.block_is_pinned = bool(pinned)
+        self._keepalive = keepalive  # e.g. the pinned torch tensor `store` is a view of
+        per_m = np.array([self.tile_elems(m, _lib.DMM_B_PACKED) for m in range(tel.mmax + 1)], dtype=np.int64)
+        self._m_off = np.concatenate([[0], np.cumsum(per_m)])
+        self.per_freq = int(self._m_off[-1])
+        if store.ndim != 1 or store.size != self.per_freq * tel.nfreq:
+            raise ValueError(f"store must be flat with {self.per_freq * tel.nfreq} elements, got shape {store.shape}")
+
+    @staticmethod
+    def elements(telescope):
+        """Number of store elements the telescope's tiles take (all frequencies, all m, packed)."""
+        tel = telescope
+        ntel = 2 * tel.npairs
+        return int(sum(ntel * tel.num_pol_sky * (tel.lmax + 1 - m) for m in range(tel.mmax + 1))) * tel.nfreq
+
+    def content_key(self):
+        return ("packed-store", self._uid)
+
+    def beam_m(self, m, fi=None):
+        tel = self.telescope
+        if fi is None:
+            return np.stack([self.beam_m(m, fi=f) for f in range(tel.nfreq)])
+        a = fi * self.per_freq + self._m_off[m]
+        out = np.zeros((self.ntel, tel.num_pol_sky, tel.lmax + 1), dtype=np.complex128)
+        out[..., m:] = np.asarray(self.store[a : a + self._m_off[m + 1] - self._m_off[m]]).reshape(self.ntel, tel.num_pol_sky, tel.lmax + 1 - m)
+        return out.reshape(2, tel.npairs, tel.num_pol_sky, tel.lmax + 1)
+
+    def beam_block(self, m_lo, m_hi, f_lo, f_hi, dtype=np.complex128, layout=_lib.DMM_B_PACKED, out=None):
+        whole = m_lo == 0 and m_hi == self.telescope.mmax + 1
+        if layout != _lib.DMM_B_PACKED or np.dtype(dtype) != self.store.dtype or (f_hi - f_lo > 1 and not whole):
+            return super().beam_block(m_lo, m_hi, f_lo, f_hi, dtype, layout, out)
+        a = f_lo * self.per_freq + self._m_off[m_lo]
+        b = (f_hi - 1) * self.per_freq + self._m_off[m_hi]
+        return self.store[a:b]  # a view: no packing, no copy
+
+    @classmethod
+    def from_provider(cls, provider, ctx, dtype=np.complex128, pin=True):
+        """Materialise ``provider``'s tiles into a host store (filled on the GPU frequency by frequency when the
+        provider generates on the device, so large stores do not take minutes of host hashing)."""
+        import torch
+
+        tel = provider.telescope
+        npdt = np.dtype(dtype)
+        n = cls.elements(tel)
+        tdt = torch.complex128 if npdt == np.complex128 else torch.complex64
+        host = torch.empty(n, dtype=tdt, pin_memory=bool(pin))
+        per_freq = n // tel.nfreq
+        b_dtype = _lib.DMM_C128 if npdt == np.complex128 else _lib.DMM_C64
+        ms = np.arange(tel.mmax + 1, dtype=np.int32)
+        sizes = np.array([provider.tile_elems(int(m), _lib.DMM_B_PACKED) for m in ms], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        dev = torch.empty(per_freq, dtype=tdt, device=ctx.device)
+        for f in range(tel.nfreq):
+            tiles = _lib.tile_array(ms, np.full(len(ms), f, np.int32), offs)
+            provider.fill_pool(ctx, dev, tiles, b_dtype, _lib.DMM_B_PACKED)
+            ctx.sync()
+            host[f * per_freq : (f + 1) * per_freq].copy_(dev)
+        del dev
+        return cls(tel, host.numpy(), pinned=bool(pin), keepalive=host)
+
+
+class PoolCycledProvider(BeamTransferProvider):
+    """The *hbm-pool* residency policy of SURVEY 8d as a provider: frequency ``f`` uses the tiles of ``f % period``.
+
+    The beam transfers of the metric configuration (1.64 TB at cfg 3) exceed one GPU; throughput runs therefore
+    keep ``period`` frequencies' worth of DISTINCT tiles resident (far more than the 256 MiB Infinity Cache) and
+    cycle the job's frequencies through them: every byte of B is read from HBM once per solve, tile contents repeat
+    every ``period`` frequencies.  With this provider the policy runs through ``DirtyMapMaker.process`` itself: the
+    engine sees that consecutive slabs hold the same contents and fills the pool once -- also across days.
+    """
+
+    def __init__(self, base, period):
+        super().__init__(base.telescope)
+        self.base = base
+        self.alias_period = int(period)
+        self.fill_mode = base.fill_mode
+        self.block_is_pinned = base.block_is_pinned
+
+    def content_key(self):
+        return ("cycled", self.alias_period, self.base.content_key())
+
+    def beam_m(self, m, fi=None):
+        if fi is None:
+            return np.stack([self.beam_m(m, fi=f) for f in range(self.telescope.nfreq)])
+        return self.base.beam_m(m, fi=int(fi) % self.alias_period)
+
+    def beam_block(self, m_lo, m_hi, f_lo, f_hi, dtype=np.complex128, layout=_lib.DMM_B_PACKED, out=None):
+        if f_hi - f_lo == 1:
+            f = f_lo % self.alias_period
+            return self.base.beam_block(m_lo, m_hi, f, f + 1, dtype, layout, out)
+        return super().beam_block(m_lo, m_hi, f_lo, f_hi, dtype, layout, out)
+
+    def fill_pool(self, ctx, pool, tiles, dtype, layout, stager=None):
+        rec = np.frombuffer(tiles, dtype=_lib._TILE_DTYPE)
+        canon = _lib.tile_array(rec["m"], rec["f"] % self.alias_period, rec["b_off"])
+        self.base.fill_pool(ctx, pool, canon, dtype, layout, stager)
+
+
 class ForeignProvider(BeamTransferProvider):
     """Wrap any object with ``telescope`` + ``beam_m`` (e.g. driftscan's ``BeamTransfer``)."""
+
+    stage_workers = 1  # a foreign object's ``beam_m`` (HDF5 reads) is not assumed to be thread-safe
 
     def __init__(self, bt):
         super().__init__(bt.telescope)

@@ -27,6 +27,7 @@ class Context:
 
     _cache: dict[int, "Context"] = {}
     _side_cache: dict[int, "Context"] = {}
+    _fill_cache: dict[int, "Context"] = {}
 
     def __init__(self, device: int = 0, stream: "torch.cuda.Stream | None" = None):
         if not torch.cuda.is_available():
@@ -71,6 +72,17 @@ class Context:
                 st = torch.cuda.Stream(device=dev)
             cls._side_cache[device] = cls(device, st)
         return cls._side_cache[device]
+
+    @classmethod
+    def fill(cls, device: int | None = None) -> "Context":
+        """A third ``dmm_ctx`` of the GPU pinned to a stream of its own, for filling B buffers (H2D copies of the next
+        slab's tiles, or a provider's fill kernels) under the current slab's solves; ordered by events in
+        ``analysis/_solve.py``."""
+        if device is None:
+            device = torch.cuda.current_device()
+        if device not in cls._fill_cache:
+            cls._fill_cache[device] = cls(device, torch.cuda.Stream(device=torch.device("cuda", device)))
+        return cls._fill_cache[device]
 
     # ---- buffer ownership across streams
     # Rule: a tensor handed to work on a context whose stream is not the one torch allocated it on is (a) recorded on
