@@ -1,26 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark: m-modes/sec through MModeTransform + DirtyMapMaker.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One *step* = one full pass of the hot path over one sidereal day of synthetic
-CHIME-pathfinder-shaped data at BASELINE.json's metric configuration (128 feeds ->
-379 stacked baselines, 256 frequencies, 1024 RA samples, lmax = mmax = 512; cfg 3 of
-SURVEY.md section 8d): sidereal-time -> m FFT + pack + noise weights for all 97 024
-(freq, baseline) rows, then all 131 328 (m, freq) Dirty solves a = B^H N^-1 v.
-Inputs (SiderealStream arrays and the B pool) are resident in HBM when the clock starts;
-the clock stops when the a_lm of every (m, f) is resident in HBM (SURVEY.md 8d metric).
+One *step* = one sidereal day of synthetic CHIME-pathfinder-shaped data at BASELINE.json's metric configuration
+(128 feeds -> 379 stacked baselines, 256 frequencies, 1024 RA samples, lmax = mmax = 512; cfg 3 of SURVEY.md 8d)
+through the PRODUCT's task classes: ``MModeTransform.process`` (sidereal-time -> m FFT + pack + noise weights of all
+97 024 (freq, baseline) rows) then ``DirtyMapMaker.process`` (all 131 328 (m, freq) solves a = B^H N^-1 v and the
+inverse SHT to IQUV HEALPix maps, mapmaker.py:35-118).  The SiderealStream and the B pool are resident in HBM when
+the clock starts; it stops when the maps of every frequency are resident in HBM.
 
-B residency (stated with every number): all B_m[f] of cfg 3 are 1.64 TB in complex128
-(l >= m columns only) and cannot be resident at once, so the job streams its 256
-frequencies through an HBM pool holding `pool_freqs` frequencies' worth of DISTINCT tiles
-(default 32 -> 205 GB, >> 256 MiB Infinity Cache), cycled 256/pool_freqs times per step:
-every byte of B is read from HBM exactly once per solve, but tile contents repeat
-between cycles ("B=hbm-pool").
+B residency (stated with every number): all B_m[f] of cfg 3 are 1.64 TB in complex128 (l >= m columns only) and
+cannot be resident on one GPU, so the job runs under SURVEY 8d's *hbm-pool* policy -- the provider
+(``PoolCycledProvider``) serves frequency f with the tiles of f % pool_freqs, ``pool_freqs`` frequencies' worth of
+DISTINCT tiles (default 32 -> 205 GB, >> 256 MiB Infinity Cache) stay resident across slabs and across days: every
+byte of B is read from HBM exactly once per solve, tile contents repeat every pool_freqs frequencies.
 
-Multi-GPU (torchrun, one rank per GPU): weak scaling -- every rank owns its own 256
-frequencies of a 256*N-frequency job (frequency is the path's natural shard axis; no
-collective inside the timed region), value = N * (mmax+1) / T with T the max over ranks.
+Multi-GPU (torchrun, one rank per GPU; frequency is the path's shard axis, no collective inside the timed region):
+``--scaling weak`` (default): every rank owns its own 256 frequencies of a 256*N-frequency job,
+value = N * (mmax+1) / T.  ``--scaling strong``: cfg 3's 256 frequencies are split over the ranks
+(``parallel.split_local``); at N = 8 every rank's 32 frequencies ARE the resident pool (no aliasing), value =
+(mmax+1) / T.  After the timed region the rank-local Maps are all-gathered (``parallel.allgather_map``, the north
+star's single RCCL collective) and its time is reported.
 
 Prints ONE JSON line on rank 0.
 """
@@ -44,51 +45,89 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3, help="sidereal days timed")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, help="SURVEY 8d config number (metric is quoted on 3)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--b-dtype", default="complex128", choices=["complex128", "complex64"])
     ap.add_argument("--pool-freqs", type=int, default=0, help="frequencies' worth of distinct B tiles resident (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-overlap", action="store_true", help="run alm2map after all solves on the main stream instead of beside them")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (c64 pool, cfg2 all-resident)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--no-overlap", action="store_true", help="(kept for compatibility; the product always overlaps alm2map with the solves)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --same-device: rehearse the N>1 code path on a one-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
 def _cpu_worker(args):
-    """One process of the multi-process CPU arm: Dirty solves (1 BLAS thread) on its own RAM pool of tiles."""
-    seed, npairs, lmax, ms, budget = args
+    """One process of a multi-process CPU arm (1 BLAS thread): the m-mode transform of one frequency's rows, then Dirty
+    solves on its own RAM pool of tiles until the budget is spent."""
+    seed, npairs, nra, lmax, ms, budget = args
     from oracle import mapmaker as omm
     from oracle import synth as osyn
+    from oracle import transform as otr
 
     rng = np.random.default_rng(seed)
+    vis = (rng.standard_normal((1, npairs, nra), dtype=np.float32) + 1j * rng.standard_normal((1, npairs, nra), dtype=np.float32)).astype(np.complex64)
+    w = rng.uniform(0.5, 1.5, (1, npairs, nra)).astype(np.float32)
+    otr.mmode_transform(vis, w, mmax=lmax)
+    t0 = time.perf_counter()
+    nfft = 0
+    while nfft < 2 or time.perf_counter() - t0 < 0.15 * budget:
+        otr.mmode_transform(vis, w, mmax=lmax)
+        nfft += 1
+    t_fft = (time.perf_counter() - t0) / nfft  # seconds per frequency, this process
     tiles = [osyn.beam_tile(3000, int(m), seed % 7, npairs, 4, lmax) for m in ms]
     v = rng.standard_normal((2, npairs)) + 1j * rng.standard_normal((2, npairs))
     Ni = rng.uniform(0.5, 1.5, (2, npairs))
     omm.dirty_solve(tiles[0], v, Ni)
     n = 0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget:
+    while time.perf_counter() - t0 < 0.85 * budget:
         for bm in tiles:
             omm.dirty_solve(bm, v, Ni)
             n += 1
-    return n, time.perf_counter() - t0
+    return n, time.perf_counter() - t0, t_fft
+
+
+def _process_arm(nproc, npairs, nra, lmax, ms, budget):
+    """`nproc` single-threaded worker processes at once (the reference's MPI decomposition over frequency).
+    Returns aggregate (seconds per solve, seconds per frequency of the transform, solves done)."""
+    import multiprocessing as mp
+
+    keys = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+    saved = {k: os.environ.get(k) for k in keys}
+    os.environ.update({k: "1" for k in keys})
+    try:
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            res = pool.map(_cpu_worker, [(100 + i, npairs, nra, lmax, ms[i % len(ms) :: 3][:6], budget) for i in range(nproc)], chunksize=1)
+        solve_rate = sum(n / t for n, t, _ in res)  # solves per second, all processes together
+        fft_rate = sum(1.0 / tf for _, _, tf in res)  # frequencies per second, all processes together
+        return 1.0 / solve_rate, 1.0 / fft_rate, sum(n for n, _, _ in res)
+    finally:
+        for k, v_ in saved.items():
+            if v_ is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v_
 
 
 def cpu_baseline(cfg, seconds):
     """Oracle (NumPy restatement of the reference) timed on this box's host cores.
 
-    Bounded sample of the SAME workload: the complex64 FFT + pack of a slice of rows, and
-    Dirty solves (complex128 np.dot) over an m-stratified set of tiles drawn from a RAM
-    pool; extrapolated linearly to the full job.  HDF5 I/O of B (dominant in real
-    reference runs) is excluded, as on the GPU side.  The final alm2map (healpy's C++ in the
-    reference; the NumPy oracle would overstate it by orders of magnitude) is NOT charged to
-    the CPU time, although the GPU step includes it: the CPU figure is an upper bound.
+    Bounded sample of the SAME workload: the complex64 FFT + pack of whole frequencies, and Dirty solves (complex128
+    np.dot on the FULL tile, like the reference) over an m-stratified set of tiles drawn from RAM pools; extrapolated
+    linearly to the full job.  HDF5 I/O of B (dominant in real reference runs) is excluded, as on the GPU side.  The
+    final alm2map (healpy's C++ in the reference; the NumPy oracle would overstate it by orders of magnitude) is NOT
+    charged to the CPU time, although the GPU step includes it: the CPU figure is an upper bound.
 
-    Three arms of the solve loop, the fastest one is reported with ITS core count: one process with one
-    BLAS thread; one process with every thread it may use; and P single-threaded processes each owning
-    its own tiles (the reference's MPI decomposition over frequency), P = this box's CPU share.
+    Arms (SURVEY 8d / BASELINE.md): (i) one process, one BLAS thread; (ii) one process, BLAS threads = every core
+    this process may use; (iii) 16 single-threaded processes (the CPU share a GPU box gives one GPU's job);
+    (iv) P = len(os.sched_getaffinity(0)) single-threaded processes -- the reference's MPI-over-frequency
+    decomposition on every core there is.  In the process arms the transform is timed INSIDE the workers (all of them
+    at once), not divided by the process count.  The fastest arm is reported with ITS core count.
     Runs BEFORE the GPU is touched (worker processes are spawned).
     """
     from oracle import mapmaker as omm
@@ -106,208 +145,174 @@ def cpu_baseline(cfg, seconds):
     npairs = osyn.npairs_of(cfg["ncyl"], cfg["nfeed_cyl"])
     nfreq, nra, lmax = cfg["nfreq"], cfg["nra"], cfg["lmax"]
     rng = np.random.default_rng(0)
+    narm = 4 if ncpu > 16 else 3
+    budget = seconds / narm
 
-    # (1) transform: time a slice of frequencies
-    nf_s = max(1, min(nfreq, 4))
+    # single-process arms: transform of a slice of frequencies, then solves on a RAM pool of stratified tiles
+    nf_s = max(1, min(nfreq, 2))
     vis = (rng.standard_normal((nf_s, npairs, nra), dtype=np.float32) + 1j * rng.standard_normal((nf_s, npairs, nra), dtype=np.float32)).astype(np.complex64)
     w = rng.uniform(0.5, 1.5, (nf_s, npairs, nra)).astype(np.float32)
     t0 = time.perf_counter()
     otr.mmode_transform(vis, w, mmax=lmax)
-    t_fft_per_freq = (time.perf_counter() - t0) / nf_s
-
-    # (2) solves: RAM pool of distinct tiles at stratified m, cycled until `seconds` of work
+    t_fft_1 = (time.perf_counter() - t0) / nf_s
     ms = np.unique(np.linspace(0, lmax, 24).astype(int))
-    tiles = [osyn.beam_tile(3000, int(m), 0, npairs, 4, lmax) for m in ms]
+    tiles = [osyn.beam_tile(3000, int(m), 0, npairs, 4, lmax) for m in ms[::2]]
     v = rng.standard_normal((2, npairs)) + 1j * rng.standard_normal((2, npairs))
     Ni = rng.uniform(0.5, 1.5, (2, npairs))
+
     def solve_arm(nthreads, budget):
         import contextlib
 
         cm = threadpool_limits(limits=nthreads) if threadpool_limits is not None else contextlib.nullcontext()
         with cm:
-            per_m = np.zeros(len(ms))
-            cnt = np.zeros(len(ms))
+            omm.dirty_solve(tiles[0], v, Ni)
             t_end = time.perf_counter() + budget
-            n = 0
+            n, t0 = 0, time.perf_counter()
             while time.perf_counter() < t_end:
-                for i, bm in enumerate(tiles):
-                    t0 = time.perf_counter()
+                for bm in tiles:
                     omm.dirty_solve(bm, v, Ni)
-                    per_m[i] += time.perf_counter() - t0
-                    cnt[i] += 1
                     n += 1
-        # the reference multiplies the FULL tile (zeros included): cost is m-independent -> mean
-        return float((per_m / np.maximum(cnt, 1)).mean()), n
+            # the reference multiplies the FULL tile (zeros included): the cost does not depend on m
+            return (time.perf_counter() - t0) / n, n
 
-    t1, n1 = solve_arm(1, seconds / 3)
+    arms = {}
+    t1, n1 = solve_arm(1, budget / 2)
+    arms["1_thread"] = {"cores": 1, "ms_per_solve": t1 * 1e3, "fft_ms_per_freq": t_fft_1 * 1e3, "solves": n1}
     if threadpool_limits is not None and ncpu > 1:
-        tn, nn = solve_arm(ncpu, seconds / 3)
-    else:
-        tn, nn = t1, 0
-    # P single-threaded processes (a GPU box gives one GPU's job 16 cores' worth of CPU)
-    nproc = max(1, min(ncpu, 16))
-    tp, npr = float("inf"), 0
-    if nproc > 1:
-        import multiprocessing as mp
-
-        saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
-        os.environ.update({k: "1" for k in saved})
+        tn, nn = solve_arm(ncpu, budget / 2)
+        arms[f"{ncpu}_blas_threads"] = {"cores": ncpu, "ms_per_solve": tn * 1e3, "fft_ms_per_freq": t_fft_1 * 1e3, "solves": nn}
+    del tiles
+    for nproc in sorted({min(ncpu, 16), ncpu}):
+        if nproc <= 1:
+            continue
         try:
-            with mp.get_context("spawn").Pool(nproc) as pool:
-                res = pool.map(_cpu_worker, [(100 + i, npairs, lmax, ms[i % len(ms) :: 3][:8], seconds / 3) for i in range(nproc)])
-            rate = sum(n / t for n, t in res)  # solves per second, all processes together
-            tp, npr = 1.0 / rate, sum(n for n, _ in res)
+            tp, tf, npr = _process_arm(nproc, npairs, nra, lmax, ms, budget)
+            arms[f"{nproc}_processes"] = {"cores": nproc, "ms_per_solve": tp * 1e3, "fft_ms_per_freq": tf * 1e3, "solves": npr}
         except Exception as e:  # the baseline must never break the bench line
-            tp, npr = float("inf"), 0
-            print(f"cpu_baseline: multi-process arm failed: {e!r}", file=sys.stderr)
-        finally:
-            for k, v_ in saved.items():
-                if v_ is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v_
-    t_solve, nthreads = min((t1, 1), (tn, ncpu), (tp, nproc))
-    nsolve = n1 + nn + npr
-    arms = {"1_thread_ms": t1 * 1e3, f"{ncpu}_threads_ms": tn * 1e3, f"{nproc}_processes_ms_per_solve": tp * 1e3 if np.isfinite(tp) else None}
-    t_job = t_fft_per_freq * nfreq / (nthreads if nthreads == nproc and nproc > 1 else 1) + t_solve * (lmax + 1) * nfreq
+            print(f"cpu_baseline: {nproc}-process arm failed: {e!r}", file=sys.stderr)
+    for a in arms.values():
+        a["job_seconds"] = a["fft_ms_per_freq"] * 1e-3 * nfreq + a["ms_per_solve"] * 1e-3 * (lmax + 1) * nfreq
+        a["m_modes_per_s"] = (lmax + 1) / a["job_seconds"]
+    best_name = min(arms, key=lambda k: arms[k]["job_seconds"])
+    best = arms[best_name]
     return {
-        "value": (lmax + 1) / t_job,
+        "value": best["m_modes_per_s"],
         "unit": "m-modes/s",
-        "cores": int(nthreads),
+        "cores": int(best["cores"]),
         "kind": "port",
-        "sample": f"FFT+pack of {nf_s}/{nfreq} freqs; {nsolve} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from RAM pools) in {seconds:.0f}s over three arms (1 thread / {ncpu} BLAS threads / {nproc} processes x 1 thread), fastest reported; extrapolated linearly; alm2map not charged to the CPU time (GPU step includes it)",
-        "t_solve_ms": t_solve * 1e3,
-        "t_solve_arms": arms,
-        "t_fft_per_freq_ms": t_fft_per_freq * 1e3,
+        "sample": f"arm '{best_name}' (fastest of {list(arms)}): {best['solves']} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from RAM pools) + the FFT+pack of whole frequencies, {seconds:.0f}s of wall time over all arms, extrapolated linearly to {(lmax+1)*nfreq} solves + {nfreq} frequencies; alm2map not charged to the CPU time (the GPU step includes it)",
+        "host_cores_visible": ncpu,
+        "arms": arms,
     }
 
 
 class Job:
-    """Device-resident inputs + plans for one rank's share of the job."""
+    """One rank's share of the job, held as the product's own containers and task objects."""
 
-    def __init__(self, cfg, rank, b_dtype, pool_freqs, seed=3003, overlap=True):
+    def __init__(self, cfg, rank, world, scaling, b_dtype, pool_freqs, seed=3003):
         import torch
 
-        from draco_amd import _lib
-        from draco_amd.analysis._solve import Slab
-        from draco_amd.core.products import SyntheticProvider, TransitTelescope
+        from draco_amd import parallel
+        from draco_amd import workloads as wl
+        from draco_amd.analysis.mapmaker import DirtyMapMaker
+        from draco_amd.analysis.transform import MModeTransform
+        from draco_amd.core import containers
+        from draco_amd.core.products import PoolCycledProvider, SyntheticProvider, TransitTelescope
         from draco_amd.device import Context
-        from draco_amd import workloads as osyn
 
         self.torch = torch
         self.ctx = ctx = Context.get()
-        self.side = Context.side() if overlap else None
         self.cfg = cfg
-        nfreq, nra, lmax = cfg["nfreq"], cfg["nra"], cfg["lmax"]
-        self.nfreq, self.nra, self.lmax = nfreq, nra, lmax
-        # this rank's frequencies of the weak-scaled job
-        freqs = osyn.frequencies(nfreq) + 400.0 * rank
-        self.tel = tel = TransitTelescope(freqs, lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
-        self.bt = SyntheticProvider(tel, seed=seed + rank)
+        nra, lmax = cfg["nra"], cfg["lmax"]
+        self.nra, self.lmax, self.nside = nra, lmax, cfg["nside"]
+        # the telescope knows every frequency of the job; the data containers hold this rank's slab
+        if scaling == "weak":
+            self.nfreq_job = cfg["nfreq"] * world
+            all_freqs = np.concatenate([wl.frequencies(cfg["nfreq"]) + 400.0 * r for r in range(world)])
+            count, start = cfg["nfreq"], cfg["nfreq"] * rank
+        else:
+            self.nfreq_job = cfg["nfreq"]
+            all_freqs = wl.frequencies(cfg["nfreq"])
+            count, start = parallel.split_local(cfg["nfreq"], rank, world)
+        self.nfreq = nfreq = count
+        self.tel = tel = TransitTelescope(all_freqs, lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
         self.npairs = npairs = tel.npairs
-        self.dt = {"complex128": _lib.DMM_C128, "complex64": _lib.DMM_C64}[b_dtype]
-        es = 16 if self.dt == _lib.DMM_C128 else 8
+        es = 16 if b_dtype == "complex128" else 8
+        self.per_freq = per_freq = sum(2 * npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * es
 
         gen = torch.Generator(device=ctx.device).manual_seed(1000 + rank)
-        self.vis = torch.randn((nfreq, npairs, nra), dtype=torch.complex64, device=ctx.device, generator=gen)
-        self.weight = torch.rand((nfreq, npairs, nra), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
-        self.weight[torch.rand(self.weight.shape, dtype=torch.float32, device=ctx.device, generator=gen) < 0.01] = 0.0  # 1 % exact zeros (SURVEY 8d)
-        self.n_m = lmax + 1
-        self.alm = torch.empty((nfreq, 4, self.n_m, lmax + 1), dtype=torch.complex128, device=ctx.device)
-        self.nside = cfg["nside"]
-        self.maps = torch.empty((nfreq, 4, 12 * self.nside * self.nside), dtype=torch.float64, device=ctx.device)
+        vis = torch.randn((nfreq, npairs, nra), dtype=torch.complex64, device=ctx.device, generator=gen)
+        weight = torch.rand((nfreq, npairs, nra), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
+        weight[torch.rand(weight.shape, dtype=torch.float32, device=ctx.device, generator=gen) < 0.01] = 0.0  # 1 % exact zeros (SURVEY 8d)
+        self.ss = containers.SiderealStream(freq=all_freqs[start : start + count], ra=nra, stack=npairs, allocate=False)
+        self.ss.attach("vis", vis)
+        self.ss.attach("vis_weight", weight)
 
-        per_freq = sum(2 * npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * es
         if pool_freqs <= 0:
             free, _ = torch.cuda.mem_get_info(ctx.device)
-            reserve = (self.n_m * 2 * nfreq * npairs) * 24 + (8 << 30)  # m-modes + slack
+            # per step: m-modes (24 B per (m, sign, f, base)), a_lm, maps, SHT scratch, + slack
+            reserve = (lmax + 1) * 2 * nfreq * npairs * 24 + nfreq * 4 * (lmax + 1) ** 2 * 16 + nfreq * 4 * 12 * self.nside**2 * 8 + (10 << 30)
             pool_freqs = 1
-            while pool_freqs * 2 <= nfreq and pool_freqs * 2 * per_freq <= (free - reserve) * 0.9:
+            while pool_freqs * 2 <= nfreq and pool_freqs * 2 * per_freq <= (free - reserve) * 0.95:
                 pool_freqs *= 2
             pool_freqs = min(pool_freqs, 32)
         while nfreq % pool_freqs:
             pool_freqs -= 1
         self.pool_freqs = pool_freqs
-        ms = np.tile(np.arange(lmax + 1, dtype=np.int32), pool_freqs)
-        fs = np.repeat(np.arange(pool_freqs, dtype=np.int32), lmax + 1)
-        self.slab = Slab(ctx, self.bt, ms, fs, fs, self.dt, _lib.DMM_B_PACKED, nfreq, self.n_m)
-        self.pool_bytes = self.slab.pool.numel() * es
-        ntel = 2 * npairs
-        # algorithmic bytes of ONE dirty launch (SURVEY 8d): B (l>=m) + v, Ni + a per tile
-        self.dirty_bytes = self.slab.b_bytes + self.slab.ntile * ntel * (16 + 8) + sum(4 * (lmax + 1 - int(m)) * 16 for m in ms)
         self.ncycle = nfreq // pool_freqs
-        self._lib = _lib
+        self.pool_bytes = pool_freqs * per_freq
+        base = SyntheticProvider(tel, seed=seed)
+        # frequencies alias with period pool_freqs (hbm-pool policy).  Under strong scaling at N = 8 a rank's 32
+        # frequencies are one period: every tile it solves against is distinct and stays resident across days.
+        self.bt = PoolCycledProvider(base, pool_freqs)
+        self.mt = MModeTransform()
+        self.mt.setup(self.bt)
+        self.dm = DirtyMapMaker(nside=self.nside, b_dtype=b_dtype, pool_bytes=self.pool_bytes + (1 << 20))
+        self.dm.setup(self.bt)
+        ntel = 2 * npairs
+        ms = np.tile(np.arange(lmax + 1), pool_freqs)
+        # algorithmic bytes of ONE dirty launch (SURVEY 8d): B (l>=m) + v, Ni + a per tile
+        self.dirty_bytes = self.pool_bytes + len(ms) * ntel * (16 + 8) + int(sum(4 * (lmax + 1 - int(m)) * 16 for m in ms))
         ctx.sync()
 
-    def stages_alone_ms(self):
-        """HIP-event times of the step's other two stages, each alone on the GPU (T_fft, T_sht)."""
-        from draco_amd.analysis.transform import mmode_forward
+    def step(self):
+        """One sidereal day through the task classes: SiderealStream -> MModes -> Map."""
+        mm = self.mt.process(self.ss)
+        return self.dm.process(mm)
+
+    def to_alm(self):
+        mm = self.mt.process(self.ss)
+        return self.dm.make_alm(mm)
+
+    def timed_launches(self, fn):
+        """Run ``fn`` with HIP events around every Dirty launch (on the launch stream); mean launch ms, count."""
+        eng = self.dm._get_engine()
+        eng.launch_events = []
+        fn()
+        self.torch.cuda.synchronize()
+        ev = eng.launch_events
+        eng.launch_events = None
+        ms = [a.elapsed_time(b) for a, b, _, _ in ev]
+        return float(np.mean(ms)), len(ms)
+
+    def stage_alone_ms(self):
+        """HIP-event times of the step's stages, each alone on the GPU (T_fft, T_solve, T_sht)."""
+        from draco_amd import _lib
         from draco_amd.device import ptr
 
-        ctx = self.ctx
-        ctx.sync()
-        self.torch.cuda.synchronize()
+        ctx, torch = self.ctx, self.torch
+        torch.cuda.synchronize()
         ctx.timer_start()
-        mmode_forward(ctx, self.vis, self.weight, self.lmax)
+        mm = self.mt.process(self.ss)
         t_fft = ctx.timer_stop()
         ctx.timer_start()
-        self._lib.check(self._lib.lib.dmm_alm2map(ctx.handle, ptr(self.alm), self.nfreq, 4, self.lmax, self.lmax, self.nside, ptr(self.maps)))
-        t_sht = ctx.timer_stop()
-        return {"fft": t_fft, "sht": t_sht}
-
-    def dirty_alone_ms(self, reps=2):
-        """Mean HIP-event time of one pool cycle's Dirty launch with nothing else on the GPU."""
-        from draco_amd.analysis.transform import mmode_forward
-        from draco_amd.device import ptr
-
-        ctx = self.ctx
-        mv, mw = mmode_forward(ctx, self.vis, self.weight, self.lmax)
-        ctx.sync()
-        self.torch.cuda.synchronize()
+        alm = self.dm.make_alm(mm)
+        t_solve = ctx.timer_stop()
+        maps = ctx.empty((self.nfreq, 4, 12 * self.nside**2), np.float64)
         ctx.timer_start()
-        for _ in range(reps):
-            self._lib.check(self._lib.lib.dmm_dirty_run(self.slab.plan, ptr(self.slab.pool), mv.data_ptr(), mw.data_ptr(), self.alm.data_ptr()))
-        return ctx.timer_stop() / reps
-
-    def step(self, time_dirty=False):
-        """One pass; returns the HIP-event time of the Dirty launches if asked."""
-        from draco_amd.analysis.transform import mmode_forward
-        from draco_amd.device import ptr
-
-        lib, ctx = self._lib.lib, self.ctx
-        main = self.torch.cuda.current_stream(ctx.device)
-        mv, mw = mmode_forward(ctx, self.vis, self.weight, self.lmax)
-        if time_dirty:
-            ctx.timer_start()
-        for c in range(self.ncycle):
-            f0 = c * self.pool_freqs
-            mv_c = mv[:, :, f0:, :]  # pointer offset only: strides stay those of the full array
-            mw_c = mw[:, :, f0:, :]
-            alm_c = self.alm[f0:]
-            self._lib.check(
-                lib.dmm_dirty_run(
-                    self.slab.plan,
-                    ptr(self.slab.pool),
-                    mv_c.data_ptr(),
-                    mw_c.data_ptr(),
-                    alm_c.data_ptr(),
-                )
-            )
-            if self.side is not None:
-                # DirtyMapMaker.process's last stage (mapmaker.py:112) for the frequencies just solved:
-                # compute-bound, on the side stream beside the next cycle's HBM-bound solves
-                self.side.wait_for(main)
-                self._lib.check(
-                    lib.dmm_alm2map(self.side.handle, alm_c.data_ptr(), self.pool_freqs, 4, self.lmax, self.lmax, self.nside, self.maps[f0:].data_ptr())
-                )
-        dirty_ms = ctx.timer_stop() if time_dirty else None
-        if self.side is not None:
-            self.side.join(main)
-        else:
-            self._lib.check(
-                lib.dmm_alm2map(ctx.handle, ptr(self.alm), self.nfreq, 4, self.lmax, self.lmax, self.nside, ptr(self.maps))
-            )
-        return dirty_ms
+        _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), self.nfreq, 4, self.lmax, self.lmax, self.nside, ptr(maps)))
+        t_sht = ctx.timer_stop()
+        return {"T_fft": t_fft, "T_solve": t_solve, "T_sht": t_sht}
 
 
 def main():
@@ -325,15 +330,27 @@ def main():
     import torch.distributed as dist
 
     if world > 1:
+        if args.same_device:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
 
-    from draco_amd import workloads as osyn
+    def allreduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    cfg = osyn.CONFIGS[args.config]
-    job = Job(cfg, rank, args.b_dtype, args.pool_freqs, overlap=not args.no_overlap)
+    from draco_amd import parallel
+    from draco_amd import workloads as wl
+    from draco_amd.analysis import _solve
+
+    cfg = wl.CONFIGS[args.config]
+    job = Job(cfg, rank, world, args.scaling, args.b_dtype, args.pool_freqs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -341,29 +358,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        job.step()
-    # reference point for the roofline object, outside the timed region: the Dirty kernel with the GPU to itself
-    # (inside the step the side stream's alm2map shares CUs and HBM with it)
-    alone_ms = job.dirty_alone_ms()
-    stage_ms = job.stages_alone_ms()
+    for _ in range(max(args.warmup, 1) if args.steps else args.warmup):
+        job.step()  # (the first pass fills the pool: at least one untimed pass so that B is resident when the clock starts)
+    # reference points outside the timed region: the stages each alone on the GPU
+    alone_ms, _ = job.timed_launches(job.to_alm)
+    stage_ms = job.stage_alone_ms()
+    fills_before = job.dm._get_engine().fills
+    eng = job.dm._get_engine()
+    eng.launch_events = []
     barrier()
     t0 = time.perf_counter()
-    dirty_ms = 0.0
     for _ in range(args.steps):
-        dirty_ms += job.step(time_dirty=True)
+        out_map = job.step()
     barrier()
     elapsed = time.perf_counter() - t0
+    ev = eng.launch_events
+    eng.launch_events = None
+    assert eng.fills == fills_before, "B was uploaded inside the timed region"
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = allreduce_max(elapsed)
+    launch_ms = [a.elapsed_time(b) for a, b, _, _ in ev]
+    dirty_avg_ms = float(np.mean(launch_ms))
+    nlaunch = len(launch_ms)
 
+    lmax = cfg["lmax"]
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * (cfg["lmax"] + 1) / (elapsed / args.steps)
-    nlaunch = job.ncycle * args.steps
-    dirty_avg_ms = dirty_ms / nlaunch
+    scale = world if args.scaling == "weak" else 1
+    value = scale * (lmax + 1) / (elapsed / args.steps)
     achieved = job.dirty_bytes / (dirty_avg_ms * 1e-3) / 1e9
+
+    # the north star's one collective, after the timed region: all-gather of the rank-local Maps over RCCL
+    gather = None
+    if world > 1 and not args.no_allgather:
+        _solve.release_pools()  # the gathered map of a weak-scaled job is N x 6.4 GB: make room first
+        shard_bytes = out_map.map._dev.numel() * 8
+        ts = []
+        for _ in range(2):
+            barrier()
+            t0 = time.perf_counter()
+            full = parallel.allgather_map(out_map)
+            barrier()
+            ts.append(time.perf_counter() - t0)
+            nfull = len(full.index_map["freq"])
+            del full
+        tg = allreduce_max(min(ts))
+        gather = {
+            "allgather_ms": tg * 1e3,
+            "shard_GB": shard_bytes / 1e9,
+            "gathered_GB": shard_bytes * world / 1e9,
+            "frequencies_gathered": nfull,
+            # every rank receives (N-1) shards; in a direct all-gather each arrives over its own xGMI link
+            "GBs_per_link": shard_bytes / tg / 1e9,
+            "GBs_per_gpu_in": shard_bytes * (world - 1) / tg / 1e9,
+            "backend": args.backend,
+            "note": "parallel.allgather_map (one all_gather_into_tensor; RCCL over xGMI under nccl) on the maps of the last timed day, outside the timed region; best of 2",
+        }
 
     traffic = None
     try:  # HBM bytes per launch from the committed PMC profile of this same command, if it matches
@@ -373,6 +422,7 @@ def main():
     except Exception:
         traffic = None
 
+    nfreq_rank = job.nfreq
     out = {
         "metric": "m-modes/sec through MModeTransform+DirtyMapMaker (128-feed, 256-freq)",
         "value": value,
@@ -382,22 +432,22 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64 accumulate; B stored " + args.b_dtype + "; FFT complex64 (as the reference)",
         "data": "synthetic",
         "config": {
-            "workload": f"cfg{args.config}: {job.tel.nfeed}-feed ({job.npairs} stacked baselines), {cfg['nfreq']} freq per GPU, {cfg['nra']} RA, lmax=mmax={cfg['lmax']}: MModeTransform + DirtyMapMaker ({(cfg['lmax']+1)*cfg['nfreq']} (m,f) solves + alm2map to nside={cfg['nside']} IQUV maps)",
-            "b_residency": f"hbm-pool: {job.pool_freqs} of {cfg['nfreq']} frequencies' B tiles resident ({job.pool_bytes/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), cycled {job.ncycle}x per step",
-            "solves_per_s": world * (cfg["lmax"] + 1) * cfg["nfreq"] / (elapsed / args.steps),
-            "parallelism": f"freq-sharded x{world} (no collective in the timed region)",
-            "alm2map": "side stream, per solved cycle, beside the next cycle's solves" if job.side is not None else "main stream, after all solves",
+            "workload": f"cfg{args.config}: {job.tel.nfeed}-feed ({job.npairs} stacked baselines), {nfreq_rank} freq per GPU ({job.nfreq_job} in the job), {cfg['nra']} RA, lmax=mmax={lmax}: MModeTransform.process + DirtyMapMaker.process through the task classes ({(lmax+1)*nfreq_rank} (m,f) solves + alm2map to nside={cfg['nside']} IQUV maps per GPU and day)",
+            "b_residency": f"hbm-pool: {job.pool_freqs} frequencies' B tiles resident ({job.pool_bytes/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {job.pool_freqs}: {job.ncycle} slab(s) per day, filled once, resident across days",
+            "solves_per_s": (lmax + 1) * job.nfreq_job / (elapsed / args.steps),
+            "parallelism": f"freq-sharded x{world}, {args.scaling} scaling (no collective in the timed region)",
+            "alm2map": "side stream, per solved slab, beside the next slab's solves (BaseMapMaker.process)",
         },
-        # SURVEY 8d asks for the stage times next to the metric; each measured alone on the GPU after warmup
-        # (in the step the SHT runs beside the solves).  value_to_alm = (mmax+1) / (T_fft + T_solve): the metric
-        # with T ending at "a_lm of all (m,f) resident", i.e. without DirtyMapMaker's final alm2map
-        "stages_alone_ms": {"T_fft": stage_ms["fft"], "T_solve": alone_ms * job.ncycle, "T_sht": stage_ms["sht"]},
-        "value_to_alm": world * (cfg["lmax"] + 1) / ((stage_ms["fft"] + alone_ms * job.ncycle) * 1e-3),
+        # SURVEY 8d asks for the stage times next to the metric; each measured alone on the GPU after warmup (in the
+        # step the SHT runs beside the solves).  value_to_alm = (mmax+1) / (T_fft + T_solve): the metric with T ending
+        # at "a_lm of all (m,f) resident", i.e. without DirtyMapMaker's final alm2map
+        "stages_alone_ms": stage_ms,
+        "value_to_alm": scale * (lmax + 1) / ((stage_ms["T_fft"] + stage_ms["T_solve"]) * 1e-3),
         "roofline": {
             "kernel": "k_dirty (a = B^H N^-1 v, batched over (m,f))",
             "bound": "hbm",
@@ -413,98 +463,134 @@ def main():
                 "avg_launch_ms": alone_ms,
                 "achieved": job.dirty_bytes / (alone_ms * 1e-3) / 1e9,
                 "frac": job.dirty_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "same kernel, same launch, no concurrent alm2map (untimed reference launches after warmup)",
+                "note": "same kernel, same launches through DirtyMapMaker.make_alm, no concurrent alm2map (untimed reference pass after warmup)",
             },
         },
     }
+    if gather is not None:
+        out["allgather"] = gather
 
     if rank == 0 and world == 1 and not args.no_extra:
-        extra = {}
-        per_freq = job.pool_bytes // job.pool_freqs  # bytes of one frequency's B tiles
-        try:
-            # complex64 storage of B (half the bytes, float64 accumulation)
-            if args.b_dtype == "complex128":
-                del job
-                torch.cuda.empty_cache()
-                j2 = Job(cfg, rank, "complex64", args.pool_freqs)
-                j2.step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                dms = 0.0
-                for _ in range(args.steps):
-                    dms += j2.step(time_dirty=True)
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t0
-                extra["b_complex64"] = {
-                    "value": (cfg["lmax"] + 1) / (el / args.steps),
-                    "unit": "m-modes/s",
-                    "roofline_GBs": j2.dirty_bytes / (dms / (j2.ncycle * args.steps) * 1e-3) / 1e9,
-                    "pool_freqs": j2.pool_freqs,
-                }
-                del j2
-                torch.cuda.empty_cache()
-            # the rest of the map-maker around the headline path, cfg 3 sizes, HIP-event timed:
-            # inverse SHT of all frequencies (DirtyMapMaker.process's last stage) and a Wiener sample
-            from draco_amd import _lib
-            from draco_amd.analysis._solve import SolveEngine
-            from draco_amd.analysis.transform import mmode_forward
-            from draco_amd.core.products import SyntheticProvider, TransitTelescope
-            from draco_amd.device import Context, ptr
-
-            ctx = Context.get()
-            nfreq, lmax, nside = cfg["nfreq"], cfg["lmax"], cfg["nside"]
-            gen = torch.Generator(device=ctx.device).manual_seed(7)
-            alm = torch.randn((nfreq, 4, lmax + 1, lmax + 1), dtype=torch.complex128, device=ctx.device, generator=gen)
-            maps = torch.empty((nfreq, 4, 12 * nside * nside), dtype=torch.float64, device=ctx.device)
-            for _ in range(2):
-                ctx.timer_start()
-                _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), nfreq, 4, lmax, lmax, nside, ptr(maps)))
-                t_sht = ctx.timer_stop()
-            extra["alm2map_all_freq_ms"] = t_sht
-            del alm, maps
-            tel = TransitTelescope(osyn.frequencies(nfreq), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
-            eng = SolveEngine(SyntheticProvider(tel, seed=5), ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=True)
-            nf_w = min(4, nfreq)  # a few frequencies (the headline job's 205 GB pool is still resident): the dense solves batch tiles of equal order across frequencies
-            vis1 = torch.randn((nf_w, tel.npairs, cfg["nra"]), dtype=torch.complex64, device=ctx.device, generator=gen)
-            w1 = torch.rand((nf_w, tel.npairs, cfg["nra"]), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
-            mv1, mw1 = mmode_forward(ctx, vis1, w1, lmax)
-            for kind in ("wiener", "ml"):
-                for _ in range(2):
-                    ctx.sync()
-                    t0 = time.perf_counter()
-                    eng.solve(kind, mv1, mw1, list(range(nf_w)), lmax, prior_amp=1.0, prior_tilt=0.5)
-                    ctx.sync()
-                    t_w = time.perf_counter() - t0
-                extra[f"{kind}_ms_per_solve"] = t_w * 1e3 / (nf_w * (lmax + 1))
-            extra["dense_sample"] = f"all {lmax + 1} m of {nf_w} frequencies, B resident"
-            # B = host-stream (SURVEY 8d's second residency policy): one frequency's tiles (6.4 GB) from pinned host
-            # memory into the pool per step of the stream, PCIe-bound; the solves hide completely behind the copy
-            hb = torch.empty(per_freq, dtype=torch.uint8).pin_memory()
-            dv = torch.empty(per_freq, dtype=torch.uint8, device="cuda")
-            for _ in range(2):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                dv.copy_(hb, non_blocking=True)
-                torch.cuda.synchronize()
-                t_h2d = time.perf_counter() - t0
-            extra["b_host_stream"] = {
-                "value": (lmax + 1) / (t_h2d * nfreq),
-                "unit": "m-modes/s",
-                "h2d_GBs": per_freq / t_h2d / 1e9,
-                "note": "pinned host -> HBM copy of one frequency's B tiles, times the job's frequencies; PCIe-bound, the solves (1 ms per frequency) hide behind it",
-            }
-            del hb, dv
-        except Exception as e:  # secondary numbers must never break the headline line
-            extra["error"] = repr(e)
-        out["extra"] = extra
+        out["extra"] = extras(args, cfg, job)
 
     if rank == 0:
         out["cpu_baseline"] = cpu
-
-    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def extras(args, cfg, job):
+    """Secondary measurements (single GPU, after the headline): never allowed to break the headline line."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd import workloads as wl
+    from draco_amd.analysis import _solve
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.analysis.mapmaker import DirtyMapMaker
+    from draco_amd.analysis.transform import mmode_forward
+    from draco_amd.core import containers
+    from draco_amd.core.hoststage import HostStager
+    from draco_amd.core.products import PackedStoreProvider, PoolCycledProvider, SyntheticProvider, TransitTelescope
+    from draco_amd.device import Context, ptr
+
+    extra = {}
+    ctx = Context.get()
+    nfreq, lmax, nside, nra = cfg["nfreq"], cfg["lmax"], cfg["nside"], cfg["nra"]
+    try:
+        # (1) the same day driven through the raw C ABI (no task objects): what the Python layer costs
+        eng = job.dm._get_engine()
+        mv, mw = mmode_forward(ctx, job.ss.vis.device(ctx), job.ss.weight.device(ctx), lmax)
+        alm = torch.empty((nfreq, 4, lmax + 1, lmax + 1), dtype=torch.complex128, device=ctx.device)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mv, mw = mmode_forward(ctx, job.ss.vis.device(ctx), job.ss.weight.device(ctx), lmax)
+            for s_ in eng.slabs(list(range(nfreq)), lmax, nfreq, lmax + 1):
+                _lib.check(_lib.lib.dmm_dirty_run(s_.plan, ptr(s_.pool), ptr(mv), ptr(mw), ptr(alm)))
+            torch.cuda.synchronize()
+            t_raw = time.perf_counter() - t0
+        extra["raw_abi_to_alm"] = {"value": (lmax + 1) / t_raw, "unit": "m-modes/s", "ms": t_raw * 1e3, "note": "dmm_mfft_pack + dmm_mmode_weight + one dmm_dirty_run per slab, no alm2map"}
+        del alm, mv, mw, s_
+        # (2) complex64 storage of B (half the bytes, float64 accumulation), same task classes
+        if args.b_dtype == "complex128":
+            _solve.release_pools()
+            pf = job.pool_freqs
+            dm64 = DirtyMapMaker(nside=nside, b_dtype="complex64", pool_bytes=job.pool_bytes // 2 + (1 << 20))
+            dm64.setup(PoolCycledProvider(SyntheticProvider(job.tel, seed=3003), pf))
+            mm = job.mt.process(job.ss)
+            dm64.process(mm)
+            e64 = dm64._get_engine()
+            e64.launch_events = []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dm64.process(job.mt.process(job.ss))
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            lm = [a.elapsed_time(b) for a, b, _, _ in e64.launch_events]
+            e64.launch_events = None
+            b64 = job.dirty_bytes - job.pool_bytes // 2
+            extra["b_complex64"] = {"value": (lmax + 1) / (el / args.steps), "unit": "m-modes/s", "roofline_GBs": b64 / (np.mean(lm) * 1e-3) / 1e9, "frac": b64 / (np.mean(lm) * 1e-3) / 1e9 / HBM_PEAK_GBS, "pool_freqs": pf}
+            del dm64, e64, mm
+            _solve.release_pools()
+        # (3) Wiener / ML samples at cfg-3 tile sizes
+        tel = TransitTelescope(wl.frequencies(nfreq), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+        gen = torch.Generator(device=ctx.device).manual_seed(7)
+        eng2 = SolveEngine(SyntheticProvider(tel, seed=5), ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=True)
+        nf_w = min(4, nfreq)
+        vis1 = torch.randn((nf_w, tel.npairs, nra), dtype=torch.complex64, device=ctx.device, generator=gen)
+        w1 = torch.rand((nf_w, tel.npairs, nra), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
+        mv1, mw1 = mmode_forward(ctx, vis1, w1, lmax)
+        for kind in ("wiener", "ml"):
+            for _ in range(2):
+                ctx.sync()
+                t0 = time.perf_counter()
+                eng2.solve(kind, mv1, mw1, list(range(nf_w)), lmax, prior_amp=1.0, prior_tilt=0.5)
+                ctx.sync()
+                t_w = time.perf_counter() - t0
+            extra[f"{kind}_ms_per_solve"] = t_w * 1e3 / (nf_w * (lmax + 1))
+        extra["dense_sample"] = f"all {lmax + 1} m of {nf_w} frequencies, B resident"
+        del eng2, mv1, mw1, vis1, w1
+        _solve.release_pools()
+        # (4) B = host-stream (SURVEY 8d's second residency policy) THROUGH DirtyMapMaker.process: the tiles of a few
+        # frequencies live in pinned host memory in the pool's wire format, nothing is resident on the GPU beforehand;
+        # uploads of slab k+1 run under the solves of slab k (two buffers)
+        nf_h = min(4, nfreq)
+        tel_h = TransitTelescope(wl.frequencies(nf_h), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+        shape = (lmax + 1, 2, nf_h, tel_h.npairs)
+        mm_h = containers.MModes(mmax=lmax, freq=tel_h.frequencies, stack=tel_h.npairs, allocate=False)
+        mm_h.attach("vis", torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen))
+        mm_h.attach("vis_weight", torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5)
+        hs = {}
+        for b_dtype, npdt in (("complex128", np.complex128), ("complex64", np.complex64)):
+            store = PackedStoreProvider.from_provider(SyntheticProvider(tel_h, seed=9), ctx, npdt, pin=True)
+            per_f = store.per_freq * np.dtype(npdt).itemsize
+            t_ = DirtyMapMaker(nside=64, b_dtype=b_dtype, pool_bytes=int(2 * 1.05 * per_f))  # two buffers of one frequency
+            t_.setup(store)
+            best = None
+            for _ in range(2):
+                _solve.release_pools()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                t_.process(mm_h)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            nb = t_._get_engine().last_b_bytes
+            hs[b_dtype] = {"value": (lmax + 1) / (best * nfreq / nf_h), "unit": "m-modes/s", "h2d_GBs": nb / best / 1e9, "seconds": best, "b_GB": nb / 1e9}
+            del store, t_
+        hs["note"] = f"DirtyMapMaker.process with a PackedStoreProvider over pinned host memory ({nf_h} frequencies' cfg-3 tiles, every byte crosses PCIe, double-buffered under the solves), scaled to the {nfreq}-frequency day"
+        extra["b_host_stream"] = hs
+        HostStager.release()
+        _solve.release_pools()
+    except Exception as e:  # secondary numbers must never break the headline line
+        import traceback
+
+        extra["error"] = repr(e)
+        extra["traceback"] = traceback.format_exc()[-1500:]
+    return extra
 
 
 if __name__ == "__main__":

@@ -163,6 +163,7 @@ class SolveEngine:
         self._plans: dict = {}
         self.last_b_bytes = 0
         self.fills = 0  # slabs actually filled (the others were resident)
+        self.launch_events = None  # set to a list to collect (start, stop, b_bytes, ntile) per Dirty launch
 
     def close(self):
         for s in self._plans.values():
@@ -253,6 +254,7 @@ class SolveEngine:
             if s is None:
                 s = Slab(ctx, self.provider, ms[a:b], fs_data[a:b], fs_bt[a:b], self.b_dtype, self.b_layout, nfreq_data, n_m,
                          pool=bufs[0].mem.view(_TORCH[self.b_dtype]), fill=False)
+                s.pool = None
                 self._plans[pkey] = s
             content = self._content_key(ms[a:b], fs_bt[a:b])
             buf = next((x for x in bufs if content is not None and x.content == content), None)
@@ -270,7 +272,10 @@ class SolveEngine:
             if buf.filled is not None and fill_stream != main:
                 main.wait_event(buf.filled)
             s.pool = buf.mem.view(_TORCH[self.b_dtype])
-            yield s
+            try:
+                yield s
+            finally:
+                s.pool = None  # plans outlive the pass; they must not keep the device's B block alive (release_pools)
             buf.last_use = torch.cuda.Event()
             buf.last_use.record(main)
 
@@ -294,7 +299,13 @@ class SolveEngine:
         for slab in self.slabs(freq_ind, mmax, nfreq, n_m):
             self.last_b_bytes += slab.b_bytes
             if kind == "dirty":
+                if self.launch_events is not None:  # HIP events on the launch stream, read by the caller after a sync
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 _lib.check(lib.dmm_dirty_run(slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(mweight_d), ptr(alm)))
+                if self.launch_events is not None:
+                    e1.record()
+                    self.launch_events.append((e0, e1, slab.b_bytes, slab.ntile))
             elif kind == "wiener":
                 ws = torch.empty(max(int(lib.dmm_wiener_workspace_bytes(slab.plan)), 16), dtype=torch.uint8, device=self.ctx.device)
                 _lib.check(
