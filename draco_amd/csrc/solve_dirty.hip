@@ -72,23 +72,37 @@ __device__ __forceinline__ void load_b(const BT* p, double& re, double& im) {
 
 // CPL adjacent columns per lane.  CPL == 2 exists only for packed complex64 tiles whose
 // rows are 16-byte aligned (plan->pair_ok): one 16-byte load brings both columns.
+// Loads return the RAW register image (no conversion): what is prefetched stays untouched until it is consumed.
+template <typename BT, int CPL> struct RawOf;
+template <> struct RawOf<double2, 1> { typedef v2d type; };
+template <> struct RawOf<float2, 1> { typedef v2f type; };
+template <> struct RawOf<float2, 2> { typedef v4f type; };
+
 template <typename BT, int CPL, bool NT>
-__device__ __forceinline__ void load_cols(const BT* p, const int64_t (&off)[CPL], int64_t roff, double (&re)[CPL],
-                                          double (&im)[CPL]) {
+__device__ __forceinline__ typename RawOf<BT, CPL>::type load_raw(const BT* p, const int64_t (&off)[CPL], int64_t roff) {
+  typedef typename RawOf<BT, CPL>::type R;
+  const R* q = reinterpret_cast<const R*>(p + off[0] + roff);
+  return NT ? __builtin_nontemporal_load(q) : *q;
+}
+
+// acc += conj(b) * w for the CPL columns of one raw row piece
+template <typename BT, int CPL>
+__device__ __forceinline__ void accumulate(const typename RawOf<BT, CPL>::type& r, const double2 wv, double (&are)[CPL], double (&aim)[CPL]) {
+  double br[CPL], bi[CPL];
   if constexpr (CPL == 2) {
-    const v4f* q = reinterpret_cast<const v4f*>(p + off[0] + roff);
-    const v4f v = NT ? __builtin_nontemporal_load(q) : *q;
-    re[0] = (double)v.x;
-    im[0] = (double)v.y;
-    re[1] = (double)v.z;
-    im[1] = (double)v.w;
+    br[0] = (double)r.x; bi[0] = (double)r.y; br[1] = (double)r.z; bi[1] = (double)r.w;
   } else {
-    load_b<BT, NT>(p + off[0] + roff, re[0], im[0]);
+    br[0] = (double)r.x; bi[0] = (double)r.y;
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    are[c] = fma(br[c], wv.x, fma(bi[c], wv.y, are[c]));
+    aim[c] = fma(br[c], wv.y, fma(-bi[c], wv.x, aim[c]));
   }
 }
 
 // a[pol, l] = sum_i conj(B[i, pol, l]) * Ni[i] * v[i]
-template <typename BT, int CPL, bool WMODE, bool NT = false, int kUnroll = 8>
+template <typename BT, int CPL, bool WMODE, bool NT = false, int kUnroll = 8, bool PIPE = true>
 __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __restrict__ B,
                                                     const double2* __restrict__ mvis,
                                                     const double* __restrict__ mweight,
@@ -159,31 +173,56 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
 #pragma unroll
     for (int c = 0; c < CPL; ++c) are[c] = aim[c] = 0.0;
 
+    // Software-pipelined row loop: the loads of the NEXT kUnroll rows are issued before the current ones are
+    // consumed.  With one wave per SIMD nothing else hides the arithmetic (4 f64 FMAs per 16 bytes at complex128, 8 + 4
+    // conversions at complex64): unpipelined, every group of rows cost a memory latency PLUS its arithmetic.
+    typedef typename RawOf<BT, CPL>::type Raw;
     int i = 0;
-    for (; i + kUnroll <= ntel; i += kUnroll) {
-      double br[kUnroll][CPL], bi[kUnroll][CPL];
+    if constexpr (!PIPE) {  // the first version's loop (kept for A/B: `dirty_variant` 7)
+      for (; i + kUnroll <= ntel; i += kUnroll) {
+        Raw r[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) load_cols<BT, CPL, NT>(B, off, (int64_t)(i + u) * row_stride, br[u], bi[u]);
+        for (int u = 0; u < kUnroll; ++u) r[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + u) * row_stride);
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        const double2 wv = w[i + u];
+        for (int u = 0; u < kUnroll; ++u) accumulate<BT, CPL>(r[u], w[i + u], are, aim);
+      }
+    } else if (ntel >= kUnroll) {
+      Raw ra[kUnroll], rb[kUnroll];  // ping-pong register sets: no copies between iterations
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {  // conj(b) * w
-          are[c] = fma(br[u][c], wv.x, fma(bi[u][c], wv.y, are[c]));
-          aim[c] = fma(br[u][c], wv.y, fma(-bi[u][c], wv.x, aim[c]));
-        }
+      for (int u = 0; u < kUnroll; ++u) ra[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)u * row_stride);
+      // invariant at the top: ra holds rows i .. i+kUnroll-1 (in flight or arrived)
+      // The scheduling barriers keep every group's loads in ONE burst ahead of the arithmetic.  Left to itself the
+      // compiler threads the loads between the FMAs; beside the SHT kernels of the side stream (which keep the f64
+      // pipe busy) the FMAs stall and hold the loads behind them back: 37.9 instead of 31.4 ms per launch in the step.
+      for (; i + 3 * kUnroll <= ntel; i += 2 * kUnroll) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) rb[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + kUnroll + u) * row_stride);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) accumulate<BT, CPL>(ra[u], w[i + u], are, aim);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) ra[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + 2 * kUnroll + u) * row_stride);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) accumulate<BT, CPL>(rb[u], w[i + kUnroll + u], are, aim);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i + 2 * kUnroll <= ntel) {  // one more full group behind the one in ra
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) rb[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + kUnroll + u) * row_stride);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) accumulate<BT, CPL>(ra[u], w[i + u], are, aim);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) accumulate<BT, CPL>(rb[u], w[i + kUnroll + u], are, aim);
+        i += 2 * kUnroll;
+      } else {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) accumulate<BT, CPL>(ra[u], w[i + u], are, aim);
+        i += kUnroll;
       }
     }
-    for (; i < ntel; ++i) {
-      const double2 wv = w[i];
-      double br[CPL], bi[CPL];
-      load_cols<BT, CPL, NT>(B, off, (int64_t)i * row_stride, br, bi);
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        are[c] = fma(br[c], wv.x, fma(bi[c], wv.y, are[c]));
-        aim[c] = fma(br[c], wv.y, fma(-bi[c], wv.x, aim[c]));
-      }
-    }
+    for (; i < ntel; ++i) accumulate<BT, CPL>(load_raw<BT, CPL, NT>(B, off, (int64_t)i * row_stride), w[i], are, aim);
 #pragma unroll
     for (int c = 0; c < CPL; ++c)
       if (ok[c]) {
@@ -314,15 +353,25 @@ int launch_dirty(dmm_plan* pl, const SolveParams& p_in, const void* B, const dou
       case 2: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 16>), double2); break;
       case 3: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 4>), double2); break;
       case 4: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 12>), double2); break;
-      default: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 8>), double2); break;
+      case 7: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 8>), double2); break;
+      // complex128 keeps the plain loop: prefetching a second group buys nothing with the GPU to itself (29.9 vs
+      // 29.7 ms per launch, tools/step_ab.py) and its 116 registers no longer fit beside two waves of the side stream's
+      // Legendre kernels on a SIMD (96 + 2 x 208 = 512): 37.4 instead of 31.6 ms per launch inside the step
+      default: DMM_LAUNCH_DIRTY((k_dirty<double2, 1, WMODE, true, 8, false>), double2); break;
     }
   } else if (pl->pair_ok) {
     switch (WMODE ? 0 : ctx->opt_dirty_variant) {
       case 1: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, false, 8>), float2); break;
       case 2: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 8>), float2); break;
       case 3: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 24>), float2); break;
-      case 4: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 16>), float2); break;
-      default: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 8>), float2); break;
+      case 4: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 8>), float2); break;
+      case 5: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 12>), float2); break;
+      case 6: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 32>), float2); break;
+      case 7: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 8, false>), float2); break;
+      // complex64: two pipelined groups of 16 rows -- 32 KB of B in flight per wave while the 12 f64 operations per
+      // 16 bytes of the group before run (tools/step_ab.py, cfg 3: 18.2 vs 21.4 ms per launch inside the step, 15.6 vs
+      // 15.7 alone, against the plain groups of 8)
+      default: DMM_LAUNCH_DIRTY((k_dirty<float2, 2, WMODE, true, 16>), float2); break;
     }
   } else {
     auto k = k_dirty<float2, 1, WMODE>;

@@ -1,5 +1,10 @@
 #!/usr/bin/env python
-"""Interleaved A/B of k_dirty tuning variants in ONE process (guide rule 24): median/min ms and TB/s."""
+"""Interleaved A/B of k_dirty tuning variants in ONE process (guide rule 24): median/min ms and TB/s per launch.
+
+    python tools/tune_dirty.py [complex128|complex64] [pool_freqs=16] [variants=0,2,3,4] [grid_mults=1,2]
+
+One launch = all 513 m of `pool_freqs` cfg-3 frequencies through DirtyMapMaker.make_alm (HIP events on the launch stream).
+"""
 import json
 import os
 import sys
@@ -13,41 +18,51 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
 
-    import bench
     from draco_amd import _lib
-    from draco_amd.device import ptr
-    from draco_amd import workloads as osyn
+    from draco_amd import workloads as wl
+    from draco_amd.analysis.mapmaker import DirtyMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider, TransitTelescope
+    from draco_amd.device import Context
 
-    cfg = osyn.CONFIGS[3]
     dtype = sys.argv[1] if len(sys.argv) > 1 else "complex128"
-    job = bench.Job(cfg, 0, dtype, 16)
-    ctx = job.ctx
-    from draco_amd.analysis.transform import mmode_forward
-
-    mv, mw = mmode_forward(ctx, job.vis, job.weight, job.lmax)
+    nf = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    variants = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "0,2,3,4").split(",")]
+    gms = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "1,2").split(",")]
+    cfg = wl.CONFIGS[3]
+    lmax = cfg["lmax"]
+    ctx = Context.get()
+    tel = TransitTelescope(wl.frequencies(nf), lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+    gen = torch.Generator(device=ctx.device).manual_seed(5)
+    shape = (lmax + 1, 2, nf, tel.npairs)
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs, allocate=False)
+    mm.attach("vis", torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen))
+    mm.attach("vis_weight", torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5)
+    es = 16 if dtype == "complex128" else 8
+    per_freq = sum(2 * tel.npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * es
+    dm = DirtyMapMaker(b_dtype=dtype, pool_bytes=nf * per_freq + (1 << 20))
+    dm.setup(SyntheticProvider(tel, seed=3003))
+    dm.make_alm(mm)
+    eng = dm._get_engine()
+    nbytes = nf * per_freq + nf * (lmax + 1) * 2 * tel.npairs * 24 + nf * sum(4 * (lmax + 1 - m) * 16 for m in range(lmax + 1))
     lib = _lib.lib
-
-    def run():
-        _lib.check(lib.dmm_dirty_run(job.slab.plan, ptr(job.slab.pool), mv.data_ptr(), mw.data_ptr(), job.alm.data_ptr()))
-
-    variants = [(v, g, st) for v in (0, 2, 3, 4) for g in (1, 2, 3) for st in (0, 1)]  # st = 1: static striding
-    times = {k: [] for k in variants}
-    for rnd in range(6):
-        for v, g, st in variants:
+    combos = [(v, g, st) for v in variants for g in gms for st in (0,)]
+    times = {k: [] for k in combos}
+    for rnd in range(7):
+        for v, g, st in combos:
             _lib.check(lib.dmm_ctx_set_option(ctx.handle, b"dirty_variant", v))
             _lib.check(lib.dmm_ctx_set_option(ctx.handle, b"grid_mult", g))
             _lib.check(lib.dmm_ctx_set_option(ctx.handle, b"dirty_static", st))
-            if rnd == 0:
-                run()
-                ctx.sync()
-            ctx.timer_start()
-            run()
-            times[(v, g, st)].append(ctx.timer_stop())
+            eng.launch_events = []
+            dm.make_alm(mm)
+            torch.cuda.synchronize()
+            times[(v, g, st)].append(sum(a.elapsed_time(b) for a, b, _, _ in eng.launch_events))
+            eng.launch_events = None
     res = []
     for (v, g, st), ts in times.items():
         ts = np.array(ts[1:])
-        res.append({"variant": v, "grid_mult": g, "static": st, "median_ms": float(np.median(ts)), "min_ms": float(ts.min()),
-                    "TBs_median": job.dirty_bytes / np.median(ts) / 1e9})
+        res.append({"dtype": dtype, "variant": v, "grid_mult": g, "static": st, "median_ms": float(np.median(ts)), "min_ms": float(ts.min()),
+                    "TBs_median": nbytes / np.median(ts) / 1e9, "frac_of_8TBs": nbytes / np.median(ts) / 1e9 / 8.0})
     res.sort(key=lambda r: r["median_ms"])
     for r in res:
         print(json.dumps(r))
