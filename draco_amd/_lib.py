@@ -41,6 +41,10 @@ class dmm_tile(C.Structure):
     _fields_ = [("b_off", C.c_int64), ("m", C.c_int32), ("f", C.c_int32)]
 
 
+class dmm_gemv_desc(C.Structure):
+    _fields_ = [("a_off", C.c_int64), ("x_off", C.c_int64), ("y_off", C.c_int64), ("nrow", C.c_int32), ("ncol", C.c_int32)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -85,6 +89,8 @@ _SIGS = {
     "dmm_mmode_fill0": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "dmm_ringmap_window": (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "dmm_synth_beam_fill": (_i, [_vp, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, C.c_uint64, _vp]),
+    "dmm_gemv_batch": (_i, [_vp, _vp, _i, C.POINTER(dmm_gemv_desc), _i64, _vp, _vp]),
+    "dmm_row_median": (_i, [_vp, _vp, _i64, _i64, _vp]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library disagree
@@ -108,6 +114,21 @@ def check(rc: int) -> None:
 
 _TILE_DTYPE = np.dtype([("b_off", np.int64), ("m", np.int32), ("f", np.int32)])
 assert _TILE_DTYPE.itemsize == C.sizeof(dmm_tile)
+
+
+_GEMV_DTYPE = np.dtype([("a_off", np.int64), ("x_off", np.int64), ("y_off", np.int64), ("nrow", np.int32), ("ncol", np.int32)])
+assert _GEMV_DTYPE.itemsize == C.sizeof(dmm_gemv_desc)
+
+
+def gemv_desc_array(a_off, x_off, y_off, nrow, ncol):
+    """Pack parallel sequences into a ctypes array of ``dmm_gemv_desc``."""
+    n = len(a_off)
+    rec = np.empty(n, dtype=_GEMV_DTYPE)
+    rec["a_off"], rec["x_off"], rec["y_off"], rec["nrow"], rec["ncol"] = a_off, x_off, y_off, nrow, ncol
+    arr = (dmm_gemv_desc * max(n, 1))()
+    if n:
+        C.memmove(arr, rec.ctypes.data, rec.nbytes)
+    return arr
 
 
 def tile_array(ms, fs, offs):

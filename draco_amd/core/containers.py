@@ -328,6 +328,29 @@ class SVDSpectrum(ContainerBase):
         return self.datasets["spectrum"]
 
 
+class SVDModes(MContainer, _VisMixin):
+    """SVD-projected m-modes: ``vis [m, mode]`` complex128, ``vis_weight [m, mode]`` float64, ``nmode [m]`` int32
+    (``containers.py:1196-1234``): per m the modes of every frequency packed back to back, ``nmode[m]`` of them."""
+
+    _axes = ("m", "msign", "mode")
+    _dataset_spec = {
+        "vis": {"axes": ["m", "mode"], "dtype": np.complex128},
+        "vis_weight": {"axes": ["m", "mode"], "dtype": np.float64},
+        "nmode": {"axes": ["m"], "dtype": np.int32},
+    }
+
+    def __init__(self, mode=None, **kwargs):
+        super().__init__(mode=mode, **kwargs)
+
+    @property
+    def nmode(self):
+        return self.datasets["nmode"]
+
+
+class KLModes(SVDModes):
+    """KL-projected m-modes, same layout (``containers.py:1237-1246``)."""
+
+
 class Map(ContainerBase, _FreqMixin):
     """``map [freq, pol, pixel]`` float64, HEALPix RING (``containers.py:470-486``, cora ``Map`` [3P])."""
 

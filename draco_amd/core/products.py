@@ -474,9 +474,101 @@ class ForeignProvider(BeamTransferProvider):
         return self._bt.beam_m(m, fi=fi)
 
 
-class ProductManager:
-    """Stand-in for ``drift.core.manager.ProductManager``: holds ``beamtransfer`` / ``telescope``."""
+class SVDBasisMixin:
+    """The SVD-basis part of the provider protocol (what ``SVDModeProject`` needs, ``fgfilter.py:53-146``).
 
-    def __init__(self, beamtransfer):
+    driftscan's ``BeamTransfer`` [3P] keeps, per (m, frequency), the matrix that takes telescope-space m-modes to its
+    reduced "SVD" degrees of freedom and one that takes them back; the reference reaches them through
+    ``bt.project_vector_telescope_to_svd(mi, vec[nfreq, ntel]) -> packed modes`` (:87) and
+    ``bt.project_vector_svd_to_telescope(mi, svec) -> [nfreq, 2, npairs]`` (:132), and sizes its containers with
+    ``bt.ndofmax`` (:80).  Here the matrices themselves are the hand-over (bulk, like ``beam_block`` for B):
+
+    * ``svd_len(m) -> int[nfreq]``            modes kept per frequency (their sum is ``<= ndofmax``)
+    * ``beam_ut(m, f) -> [n_f, ntel]``        telescope -> SVD modes of frequency f
+    * ``beam_ut_inv(m, f) -> [ntel, n_f]``    back (default: the conjugate transpose, exact for orthonormal rows)
+
+    The two reference-visible methods are served from them by the batched GEMV kernel (``dmm_gemv_batch``).  What the
+    matrices CONTAIN is driftscan's business: parity of that arithmetic is unpinned (driftscan absent).
+    """
+
+    ndofmax = 0
+
+    def svd_len(self, m):
+        raise NotImplementedError
+
+    def beam_ut(self, m, f):
+        raise NotImplementedError
+
+    def beam_ut_inv(self, m, f):
+        return np.conj(np.asarray(self.beam_ut(m, f))).T
+
+    def project_vector_telescope_to_svd(self, mi, vec):
+        from ..analysis import fgfilter
+
+        return fgfilter.project_one_m(self, "forward", int(mi), np.asarray(vec))
+
+    def project_vector_svd_to_telescope(self, mi, svec):
+        from ..analysis import fgfilter
+
+        return fgfilter.project_one_m(self, "backward", int(mi), np.asarray(svec))
+
+
+class SVDArrayProvider(SVDBasisMixin, ArrayProvider):
+    """:class:`ArrayProvider` + an SVD basis from memory: ``ut(m, f) -> [n_f, ntel]`` (and optionally ``ut_inv``)."""
+
+    def __init__(self, telescope, beams, ut, ndofmax, ut_inv=None):
+        ArrayProvider.__init__(self, telescope, beams)
+        self._ut, self._ut_inv = ut, ut_inv
+        self.ndofmax = int(ndofmax)
+
+    def beam_ut(self, m, f):
+        return np.asarray(self._ut(m, f))
+
+    def beam_ut_inv(self, m, f):
+        if self._ut_inv is None:
+            return super().beam_ut_inv(m, f)
+        return np.asarray(self._ut_inv(m, f))
+
+    def svd_len(self, m):
+        return np.array([self.beam_ut(m, f).shape[0] for f in range(self.telescope.nfreq)], dtype=np.int64)
+
+
+class KLTransform:
+    """A KL basis over the SVD modes, per m (driftscan ``KLTransform`` [3P] as the reference uses it,
+    ``fgfilter.py:193,229``): ``modes(m) -> (evals [nkl], evecs [nkl, nsvd_m], inv [nsvd_m, nkl])``.
+
+    ``project_vector_svd_to_kl(mi, vec, threshold)`` keeps the modes whose eigenvalue (signal-to-noise) is at least
+    ``threshold`` (all of them for ``None``) and applies their rows of ``evecs``; ``project_vector_kl_to_svd`` applies
+    the matching columns of ``inv``.  The selection rule and the matrices are driftscan's arithmetic [3P, recalled]:
+    parity unpinned.
+    """
+
+    def __init__(self, modes):
+        self._modes = modes
+
+    def modes(self, m):
+        ev, evecs, inv = self._modes(m)
+        return np.asarray(ev, dtype=np.float64), np.asarray(evecs), np.asarray(inv)
+
+    def kept(self, m, threshold):
+        ev = self.modes(m)[0]
+        return np.arange(ev.size) if threshold is None else np.flatnonzero(ev >= threshold)
+
+    def project_vector_svd_to_kl(self, mi, vec, threshold=None):
+        from ..analysis import fgfilter
+
+        return fgfilter.kl_one_m(self, "forward", int(mi), np.asarray(vec), threshold)
+
+    def project_vector_kl_to_svd(self, mi, vec, threshold=None):
+        from ..analysis import fgfilter
+
+        return fgfilter.kl_one_m(self, "backward", int(mi), np.asarray(vec), threshold)
+
+
+class ProductManager:
+    """Stand-in for ``drift.core.manager.ProductManager``: holds ``beamtransfer`` / ``telescope`` / ``kltransforms``."""
+
+    def __init__(self, beamtransfer, kltransforms=None):
         self.beamtransfer = beamtransfer
         self.telescope = beamtransfer.telescope
+        self.kltransforms = dict(kltransforms or {})

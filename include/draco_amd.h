@@ -268,6 +268,25 @@ int dmm_mmode_svd(dmm_ctx* ctx, void* mvis, const double* mweight, int n_m, int 
                   const void* fill0, int mode, double global_max, double global_thr, double local_thr, double* spectrum,
                   void* u_out, void* uha_out);
 
+/* ------------------------------------------------- basis projections of m-modes (fgfilter.py)
+ * SVDModeProject / KLModeProject (reference fgfilter.py:53-239) are, per m, matrix-vector products with a basis the
+ * beam-transfer products hold [driftscan, 3P]: bt.project_vector_telescope_to_svd (:87), project_vector_svd_to_telescope
+ * (:132), kl.project_vector_svd_to_kl (:193), project_vector_kl_to_svd (:229).  dmm_gemv_batch runs all of a
+ * container's products in one launch: task t computes y[y_off .. y_off+nrow) = A_t x[x_off .. x_off+ncol) with
+ * A_t = A[a_off ..], row-major [nrow, ncol], element type a_dtype (DMM_C64 / DMM_C128); x, y complex128.
+ * A, x, y: [dev]; desc: [host].  Offsets are in elements. */
+typedef struct {
+  int64_t a_off;
+  int64_t x_off;
+  int64_t y_off;
+  int32_t nrow;
+  int32_t ncol;
+} dmm_gemv_desc;
+int dmm_gemv_batch(dmm_ctx* ctx, const void* A, int a_dtype, const dmm_gemv_desc* desc, int64_t ntask, const void* x, void* y);
+/* out[r] = np.median(x[r, :]) for a [nrow, per_row] float64 array [dev] -- the weight the reference carries over to
+ * the projected container (fgfilter.py:94,141,200,236: `np.median(mmodes.weight[mi])`). */
+int dmm_row_median(dmm_ctx* ctx, const double* x, int64_t nrow, int64_t per_row, double* out);
+
 #ifdef __cplusplus
 }
 #endif

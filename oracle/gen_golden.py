@@ -1216,6 +1216,158 @@ def gen_mapmaker_process(mapmaker, out):
     np.savez_compressed(os.path.join(out, "mapmaker_process.npz"), **cases)
 
 
+class _ModeDS:
+    """[m, ...] dataset whose full slice answers ``enumerate`` (fgfilter.py:85,129,190,226)."""
+
+    def __init__(self, arr):
+        self.arr = np.asarray(arr)
+
+    def __getitem__(self, k):
+        r = self.arr[k]
+        return r.view(_EnumLocal) if isinstance(r, np.ndarray) else r
+
+    def __setitem__(self, k, v):
+        self.arr[k] = v
+
+    @property
+    def shape(self):
+        return self.arr.shape
+
+
+class FakeModeCont(_FakeCont):
+    """SVDModes / KLModes duck type: vis, weight [m, mode], nmode [m] (containers.py:1196-1246)."""
+
+    def __init__(self, mode=None, axes_from=None, attrs_from=None, vis=None, weight=None, nmode=None):
+        if vis is None:
+            n_m = axes_from.vis.shape[0]
+            vis, weight, nmode = np.zeros((n_m, mode), complex), np.zeros((n_m, mode)), np.zeros(n_m, np.int32)
+        self.vis, self.weight, self.nmode = _ModeDS(vis), _ModeDS(weight), _ModeDS(nmode)
+        self.attrs = {}
+
+
+class FakeFGMModes(_FakeCont):
+    def __init__(self, freq=None, prod=None, input=None, attrs_from=None, axes_from=None, vis=None, weight=None):
+        if vis is None:
+            n_m = axes_from.vis.shape[0]
+            vis = np.zeros((n_m, 2, len(freq), len(prod)), complex)
+            weight = np.zeros(vis.shape)
+            self.ctor = dict(freq=freq, prod=prod, input=input)
+        self.vis, self.weight = _ModeDS(vis), _ModeDS(weight)
+        self.attrs = {}
+
+
+def gen_fgfilter(out):
+    """``SVDModeProject`` / ``KLModeProject`` (fgfilter.py:53-239) run from the reference source against duck-typed
+    products: the four driftscan projections [3P] are plain basis-matrix products (what their call sites imply), so
+    the fixture pins the TASK logic -- packing of the per-frequency modes, nmode, zero padding, the median weight
+    rule, the axis order of the backward transform -- not driftscan's arithmetic."""
+    from draco.analysis import fgfilter
+
+    fgfilter.containers = type("C", (), {"SVDModes": FakeModeCont, "KLModes": FakeModeCont, "MModes": FakeFGMModes})
+    fgfilter.io.get_beamtransfer = lambda b: b
+    rng = np.random.default_rng(13013)
+    cases = {}
+    idx = 0
+    for n_m, nfreq, npairs, ndofmax in ((4, 3, 5, 20), (3, 2, 4, 16)):
+        ntel = 2 * npairs
+        lens = rng.integers(0, min(ntel, ndofmax // nfreq) + 1, size=(n_m, nfreq))
+        lens[0, 0] = 0  # a frequency that keeps no mode
+        ut = {(m, f): crandn(rng, (int(lens[m, f]), ntel)) for m in range(n_m) for f in range(nfreq)}
+        uinv = {k: crandn(rng, (ntel, v.shape[0])) for k, v in ut.items()}
+
+        class BT:
+            pass
+
+        bt = BT()
+        bt.ndofmax = ndofmax
+        bt.telescope = type("T", (), {})()
+        bt.telescope.nfreq, bt.telescope.npairs, bt.telescope.nfeed = nfreq, npairs, 3
+        bt.telescope.frequencies = 400.0 + 5.0 * np.arange(nfreq)
+        bt.telescope.uniquepairs = np.array([(0, d) for d in range(npairs)])
+
+        def t2s(mi, vec, ut=ut, nfreq=nfreq):
+            return np.concatenate([ut[(mi, f)] @ vec[f] for f in range(nfreq)])
+
+        def s2t(mi, svec, uinv=uinv, lens=lens, nfreq=nfreq, npairs=npairs):
+            b = np.concatenate([[0], np.cumsum(lens[mi])])
+            return np.stack([(uinv[(mi, f)] @ svec[b[f] : b[f + 1]]).reshape(2, npairs) for f in range(nfreq)])
+
+        bt.project_vector_telescope_to_svd, bt.project_vector_svd_to_telescope = t2s, s2t
+        mv = crandn(rng, (n_m, 2, nfreq, npairs))
+        mw = rng.uniform(0.5, 1.5, mv.shape)
+        mw[rng.uniform(size=mw.shape) < 0.2] = 0.0
+        c = f"c{idx}_"
+        cases[c + "dims"] = np.array([n_m, nfreq, npairs, ndofmax])
+        cases[c + "lens"] = lens
+        for (m, f), a in ut.items():
+            cases[c + f"ut_{m}_{f}"], cases[c + f"uinv_{m}_{f}"] = a, uinv[(m, f)]
+        cases[c + "mvis"], cases[c + "mweight"] = mv, mw
+        t = fgfilter.SVDModeProject.__new__(fgfilter.SVDModeProject)
+        t.setup(bt)
+        t.mode = "forward"
+        sv = t.process(FakeFGMModes(vis=mv.copy(), weight=mw.copy()))
+        cases[c + "svd_vis"], cases[c + "svd_weight"], cases[c + "svd_nmode"] = sv.vis.arr, sv.weight.arr, sv.nmode.arr
+        t.mode = "backward"
+        sv_in = FakeModeCont(vis=sv.vis.arr.copy(), weight=rng.uniform(0.5, 1.5, sv.weight.arr.shape), nmode=sv.nmode.arr.copy())
+        cases[c + "back_in_weight"] = sv_in.weight.arr.copy()
+        mm = t.process(sv_in)
+        cases[c + "back_vis"], cases[c + "back_weight"] = mm.vis.arr, mm.weight.arr
+        cases[c + "back_in_nmode_after"] = sv_in.nmode.arr
+        cases[c + "back_freq_centre"], cases[c + "back_freq_width"] = mm.ctor["freq"]["centre"], mm.ctor["freq"]["width"]
+        cases[c + "back_input"] = np.asarray(mm.ctor["input"])
+        t.mode = "filter"
+        mf = t.process(FakeFGMModes(vis=mv.copy(), weight=mw.copy()))
+        cases[c + "filter_vis"], cases[c + "filter_weight"] = mf.vis.arr, mf.weight.arr
+        # KL on top of the SVD modes
+        nsvd = sv.nmode.arr
+        evals = {m: np.sort(rng.uniform(0.0, 10.0, size=max(int(nsvd[m]) - 1, 0))) for m in range(n_m)}
+        evecs = {m: crandn(rng, (len(evals[m]), int(nsvd[m]))) for m in range(n_m)}
+        kinv = {m: crandn(rng, (int(nsvd[m]), len(evals[m]))) for m in range(n_m)}
+
+        class KL:
+            def project_vector_svd_to_kl(self, mi, vec, threshold=None):
+                keep = np.arange(len(evals[mi])) if threshold is None else np.flatnonzero(evals[mi] >= threshold)
+                return evecs[mi][keep] @ vec
+
+            def project_vector_kl_to_svd(self, mi, vec, threshold=None):
+                keep = np.arange(len(evals[mi])) if threshold is None else np.flatnonzero(evals[mi] >= threshold)
+                return kinv[mi][:, keep] @ vec
+
+        pm = type("PM", (), {})()
+        pm.beamtransfer, pm.kltransforms = bt, {"kl_a": KL()}
+        for m in range(n_m):
+            cases[c + f"kl_evals_{m}"], cases[c + f"kl_evecs_{m}"], cases[c + f"kl_inv_{m}"] = evals[m], evecs[m], kinv[m]
+        for thr_name, thr in (("none", None), ("thr", 4.0)):
+            k = fgfilter.KLModeProject.__new__(fgfilter.KLModeProject)
+            k.setup(pm)
+            k.klname, k.threshold = "kl_a", thr
+            k.mode = "forward"
+            kin = FakeModeCont(vis=sv.vis.arr.copy(), weight=sv.weight.arr.copy(), nmode=sv.nmode.arr.copy())
+            km = k.process(kin)
+            cases[c + f"kl_{thr_name}_vis"], cases[c + f"kl_{thr_name}_weight"], cases[c + f"kl_{thr_name}_nmode"] = km.vis.arr, km.weight.arr, km.nmode.arr
+            k.mode = "backward"
+            sb = k.process(FakeModeCont(vis=km.vis.arr.copy(), weight=km.weight.arr.copy(), nmode=km.nmode.arr.copy()))
+            cases[c + f"klback_{thr_name}_vis"], cases[c + f"klback_{thr_name}_nmode"] = sb.vis.arr, sb.nmode.arr
+        # a KL basis that is not there: backward raises RuntimeError (:213-217); forward trips over `self.kname` (:180)
+        k.klname = "missing"
+        k.mode = "backward"
+        try:
+            k.process(kin)
+            err_b = "none"
+        except Exception as e:
+            err_b = type(e).__name__
+        k.mode = "forward"
+        try:
+            k.process(kin)
+            err_f = "none"
+        except Exception as e:
+            err_f = type(e).__name__
+        cases[c + "missing_errors"] = np.array([err_f, err_b])
+        idx += 1
+    cases["ncase"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "fgfilter.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -1242,6 +1394,8 @@ def main():
         gen_expand(GOLDEN)
     if not only or "--only-svd" in only:
         gen_svd(GOLDEN)
+    if not only or "--only-fgfilter" in only:
+        gen_fgfilter(GOLDEN)
     if not only or "--only-simulate" in only:
         gen_stream_simulate(GOLDEN)
     if not only or "--only-process" in only:

@@ -304,3 +304,37 @@ def test_mapmaker_process(golden_dir):
             assert np.abs(out - ref).max() <= 1e-9 * np.abs(ref).max(), (i, kind)
             mm_eff = min(tel_mmax, n_m - 1)
             assert not ref[..., mm_eff + 1 :].any()  # padded m columns stay zero (:108)
+
+
+def _fg_case(g, i):
+    c = f"c{i}_"
+    n_m, nfreq, npairs, ndofmax = (int(x) for x in g[c + "dims"])
+    ut = lambda m, f: g[c + f"ut_{m}_{f}"]  # noqa: E731
+    uinv = lambda m, f: g[c + f"uinv_{m}_{f}"]  # noqa: E731
+    return c, n_m, nfreq, npairs, ndofmax, ut, uinv
+
+
+def test_fgfilter_projections(golden_dir):
+    """oracle.fgfilter vs the reference's SVDModeProject / KLModeProject run from source (fgfilter.py:53-239)."""
+    from oracle import fgfilter as ofg
+
+    g = _load(golden_dir, "fgfilter.npz")
+    for i in range(int(g["ncase"])):
+        c, n_m, nfreq, npairs, ndofmax, ut, uinv = _fg_case(g, i)
+        vis, weight, nmode = ofg.svd_forward(g[c + "mvis"], g[c + "mweight"], ut, ndofmax)
+        np.testing.assert_array_equal(nmode, g[c + "svd_nmode"])
+        np.testing.assert_allclose(vis, g[c + "svd_vis"], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(weight, g[c + "svd_weight"])
+        mv, mw = ofg.svd_backward(g[c + "svd_vis"], g[c + "back_in_weight"], uinv, lambda m: g[c + "lens"][m], nfreq, npairs)
+        np.testing.assert_allclose(mv, g[c + "back_vis"], rtol=0, atol=1e-11)
+        np.testing.assert_array_equal(mw, g[c + "back_weight"])
+        np.testing.assert_array_equal(g[c + "back_in_nmode_after"], ndofmax)  # the reference overwrites its input's nmode
+        for name, thr in (("none", None), ("thr", 4.0)):
+            keep = lambda m: (np.arange(len(g[c + f"kl_evals_{m}"])) if thr is None else np.flatnonzero(g[c + f"kl_evals_{m}"] >= thr))  # noqa: E731
+            out, wout, nout = ofg.kl_apply(g[c + "svd_vis"], g[c + "svd_weight"], g[c + "svd_nmode"], lambda m: g[c + f"kl_evecs_{m}"][keep(m)], ndofmax)
+            np.testing.assert_array_equal(nout, g[c + f"kl_{name}_nmode"])
+            np.testing.assert_allclose(out, g[c + f"kl_{name}_vis"], rtol=0, atol=1e-11)
+            np.testing.assert_array_equal(wout, g[c + f"kl_{name}_weight"])
+            back, _, nb = ofg.kl_apply(g[c + f"kl_{name}_vis"], g[c + f"kl_{name}_weight"], g[c + f"kl_{name}_nmode"], lambda m: g[c + f"kl_inv_{m}"][:, keep(m)], ndofmax)
+            np.testing.assert_array_equal(nb, g[c + f"klback_{name}_nmode"])
+            np.testing.assert_allclose(back, g[c + f"klback_{name}_vis"], rtol=0, atol=1e-10)
