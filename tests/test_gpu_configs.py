@@ -204,3 +204,161 @@ def test_cfg3_tile_ml_pseudo_inverse_property_and_sampled_oracle_svd():
         finally:
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
         assert _rel(a_eig, a_ref) < 1e-8, (m, _rel(a_eig, a_ref))
+
+
+def test_cfg4_slice_through_the_task_classes_and_frequency_shards():
+    """BASELINE config 4 (256 feeds -> 763 baselines, 2048 RA, lmax 1024, nside 512; 512 frequencies over 8 GPUs) at its
+    real tile / stream / map sizes on a 4-frequency slice: MModeTransform + DirtyMapMaker through the task classes,
+    oracle on the whole stream and on sampled (m, f), exact read-back of EVERY (m, f), and the two halves of the slice
+    processed as two ranks' frequency shards (``parallel.shard_freq``) giving bit-identical a_lm and maps -- what makes
+    the 8-GPU form of this config correct by construction (no collective before the final gather)."""
+    import torch
+
+    from draco_amd import parallel
+    from draco_amd.analysis import _solve
+    from draco_amd.analysis.mapmaker import DirtyMapMaker
+    from draco_amd.analysis.transform import MModeTransform
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+
+    _solve.release_pools()
+    c = osyn.CONFIGS[4]
+    nfreq = 4
+    tel = _tel(4, nfreq)
+    npairs, nra, lmax = tel.npairs, c["nra"], tel.lmax
+    assert (tel.nfeed, npairs, nra, lmax, c["nside"]) == (256, 763, 2048, 1024, 512)
+    seed = 3004
+    bt = SyntheticProvider(tel, seed=seed)
+    vis, w = osyn.sidereal_inputs(4, nfreq, npairs, nra)
+    ss = containers.SiderealStream(freq=tel.frequencies, ra=nra, stack=npairs)
+    ss.vis[:] = vis
+    ss.weight[:] = w
+    tr = MModeTransform()
+    tr.setup(bt)
+    mm = tr.process(ss)
+    mv_ref, mw_ref = otr.mmode_transform(vis, w, mmax=tel.mmax)
+    mv = mm.vis[:]
+    assert mv.shape == (1025, 2, 4, 763)
+    assert _rel(mv, mv_ref) < 2e-6
+    np.testing.assert_allclose(mm.weight[:], mw_ref, rtol=2e-6)
+
+    dm = DirtyMapMaker(nside=c["nside"])
+    dm.setup(bt)
+    out = dm.process(mm)  # 2 slabs (one frequency's tiles are 51 GB)
+    assert out.map.shape == (4, 4, 12 * 512 * 512)
+    alm_d = dm.make_alm(mm)
+    alm = alm_d.cpu().numpy()  # [f, 4, m, l]
+    rng = np.random.default_rng(4)
+    mw_dev = mm.weight[:]
+    for m, f in ((0, 0), (3, 2), (500, 1), (1000, 3), (1024, 0)):
+        a_ref = omm.dirty_solve(osyn.beam_tile(seed, m, f, npairs, 4, lmax), mv[m, :, f], mw_dev[m, :, f])
+        assert _rel(alm[f, :, m, :], a_ref) < 1e-12, (m, f)
+    # every (m, f): unit data vector on a row that differs per (m, f)
+    rows = (np.arange(1025)[:, None] * 37 + np.arange(nfreq)[None, :] * 211) % (2 * npairs)
+    e = np.zeros((1025, 2, nfreq, npairs), np.complex128)
+    mi, fi = np.meshgrid(np.arange(1025), np.arange(nfreq), indexing="ij")
+    e[mi, rows // npairs, fi, rows % npairs] = 1.0
+    mm_e = containers.MModes(mmax=1024, freq=tel.frequencies, stack=npairs)
+    mm_e.vis[:] = e
+    mm_e.weight[:] = 1.0
+    back = dm.make_alm(mm_e).cpu().numpy()
+    for m in range(1025):
+        for f in range(nfreq):
+            assert np.array_equal(back[f, :, m, :], np.conj(osyn.beam_row(seed, m, f, rows[m, f], npairs, 4, lmax))), (m, f)
+    # two ranks' shards of the same data: each rank's slab alone gives exactly its rows of the full result
+    full_map = out.map[:]
+    for rank in range(2):
+        ss_r = parallel.shard_freq(ss, rank=rank, world=2)
+        assert len(ss_r.index_map["freq"]) == 2
+        mm_r = tr.process(ss_r)
+        dm_r = DirtyMapMaker(nside=c["nside"])
+        dm_r.setup(bt)  # the provider knows all frequencies; find_keys maps the shard's two
+        out_r = dm_r.process(mm_r)
+        assert np.array_equal(out_r.map[:], full_map[2 * rank : 2 * rank + 2])
+        del out_r, mm_r, dm_r
+    del out, alm_d, back
+    torch.cuda.empty_cache()
+    _solve.release_pools()
+
+
+def test_cfg5_slice_simulate_noise_transform_wiener_round_trip():
+    """BASELINE config 5 (CHIME-pathfinder scale: 763 baselines, lmax 1023, odd nra 2047, nside 512; 1024 frequencies
+    over 8 GPUs) at its real sizes on ONE frequency: SimulateSidereal -> GaussianNoise -> MModeTransform ->
+    WienerMapMaker through the task classes.  Checked on sampled m against oracle-generated tiles: the simulated
+    m-modes are B_m a_m of the sky's a_lm, the Wiener a_lm satisfy the normal equations of mapmaker.py:260-272 with the
+    noisy data and their weights, and the recovered map correlates with the input sky.
+    (The Wishart task SampleNoise needs a positive-definite expectation per (freq, RA), which a random synthetic B does
+    not give; it is covered on its own reference vectors in tests/test_noise.py.)"""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis import _solve
+    from draco_amd.analysis.mapmaker import WienerMapMaker
+    from draco_amd.analysis.transform import MModeTransform
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context, ptr
+    from draco_amd.synthesis.noise import GaussianNoise
+    from draco_amd.synthesis.stream import SimulateSidereal
+
+    _solve.release_pools()
+    ctx = Context.get()
+    c = osyn.CONFIGS[5]
+    tel = _tel(5, 1)
+    npairs, lmax, nside = tel.npairs, tel.lmax, c["nside"]
+    assert (tel.nfeed, npairs, lmax, c["nra"], nside) == (256, 763, 1023, 2047, 512) and 2 * tel.mmax + 1 == c["nra"]
+    seed = 3005
+    bt = SyntheticProvider(tel, seed=seed)
+    # sky of SURVEY 8d: band-limited Gaussian, C_l = (l+1)^-2, seed 4005, made on the device through alm2map
+    gen = torch.Generator(device=ctx.device).manual_seed(4005)
+    alm = torch.randn((1, 4, lmax + 1, lmax + 1), dtype=torch.complex128, device=ctx.device, generator=gen)  # [f, pol, m, l]
+    ll = torch.arange(lmax + 1, device=ctx.device)
+    alm = alm * ((ll.double() + 1.0) ** -1.0)[None, None, None, :] * (ll[None, :] >= ll[:, None]).to(alm.dtype)[None, None]
+    alm[:, :, 0] = alm[:, :, 0].real.to(alm.dtype)
+    alm[:, 1:3, :, :2] = 0
+    alm = alm.contiguous()
+    sky = ctx.empty((1, 4, 12 * nside * nside), np.float64)
+    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), 1, 4, lmax, lmax, nside, ptr(sky)))
+    mp = containers.Map(nside=nside, freq=tel.frequencies, allocate=False)
+    mp.attach("map", sky)
+
+    sim = SimulateSidereal()
+    sim.setup(bt)
+    ss = sim.process(mp)
+    assert ss.vis.shape == (1, npairs, 2047) and ss.vis.dtype == np.complex64
+    tr = MModeTransform()
+    tr.setup(bt)
+    mm_clean = tr.process(ss).vis[:]  # [1024, 2, 1, 763]
+    a_sky = alm.cpu().numpy()[0]  # [pol, m, l]: band-limited at lmax = 2 nside, map2alm (3 iterations) recovers it to ~1e-4
+    for m in (1, 400, 1023):
+        B = osyn.beam_tile(seed, m, 0, npairs, 4, lmax).reshape(2 * npairs, -1)
+        v_ref = (B @ a_sky[:, m, :].reshape(-1)).reshape(2, npairs)
+        assert _rel(mm_clean[m, :, 0], v_ref) < 2e-3, (m, _rel(mm_clean[m, :, 0], v_ref))  # the forward SHT's quadrature error at lmax = 2 nside
+
+    gn = GaussianNoise(seed=5, ndays=733.0, recv_temp=50.0)
+    gn.setup(tel)
+    ss = gn.process(ss)
+    mm = tr.process(ss)
+    mv, mw = mm.vis[:], mm.weight[:]
+    assert np.all(mw[:, :, 0] > 0) and mm.attrs["oddra"]
+    wm = WienerMapMaker(nside=nside, prior_amp=1.0, prior_tilt=0.5)
+    wm.setup(bt)
+    a_w = wm.make_alm(mm).cpu().numpy()[0]  # [pol, m, l]
+    assert np.all(np.isfinite(a_w))
+    for m in (0, 400, 1023):
+        B = osyn.beam_tile(seed, m, 0, npairs, 4, lmax)[..., m:].reshape(2 * npairs, -1)
+        nv, vv = mw[m, :, 0].reshape(-1), mv[m, :, 0].reshape(-1)
+        x = a_w[:, m, m:].reshape(-1)
+        S = omm.wiener_prior(lmax, m, 1.0, 0.5)
+        lhs = x / S + B.conj().T @ (nv * (B @ x))
+        rhs = B.conj().T @ (nv * vv)
+        assert _rel(lhs, rhs) < 1e-9, (m, _rel(lhs, rhs))
+        assert np.all(a_w[:, m, :m] == 0)
+    out = wm.process(mm)
+    rec, inp = out.map[:][0, 0], sky.cpu().numpy()[0, 0]
+    assert out.map.shape == (1, 4, 12 * 512 * 512) and np.all(np.isfinite(rec))
+    corr = np.corrcoef(rec, inp)[0, 1]
+    assert corr > 0.5, corr  # a Wiener-filtered estimate of the sky that went in
+    del out, mp, sky
+    torch.cuda.empty_cache()
+    _solve.release_pools()
