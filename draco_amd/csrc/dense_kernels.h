@@ -299,9 +299,12 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // t/4, columns k+1 + t%4, +4, ...  The inverse of the factor is a forward substitution per column, four adjacent lanes
 // per column sharing the inner sum (no barrier: a column's lanes sit in one wave).
 __global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
+  // ONE 64 x 65 LDS image: the factor in the lower triangle, its inverse -- also lower triangular -- transposed into
+  // the strictly upper triangle (the inverse's diagonal is dinv[]).  Half the LDS of two images: two blocks per CU, and
+  // a batch of up to 512 matrices is one round of blocks instead of two (the kernel is latency bound: 64 dependent
+  // column steps).
   extern __shared__ __align__(16) unsigned char smem_cd[];
   double2(*a)[TB + 1] = reinterpret_cast<double2(*)[TB + 1]>(smem_cd);
-  double2(*li)[TB + 1] = a + TB;
   const int mat = blockIdx.x;
   const int J0 = p.J * TB;
   double2* Ablk = p.A + ((int64_t)mat * p.Np + J0) * p.Np + J0;
@@ -346,13 +349,13 @@ __global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
   if (threadIdx.x < TB) dinv[threadIdx.x] = fast_rcp(a[threadIdx.x][threadIdx.x].x);
   __syncthreads();
   {
+    // li(i, j), i > j, lives at a[j][i]; li(j, j) = dinv[j]
     const int j = threadIdx.x >> 2, g = threadIdx.x & 3;
-    for (int i = g; i < j; i += 4) li[i][j] = make_double2(0.0, 0.0);
-    if (g == 0) li[j][j] = make_double2(dinv[j], 0.0);
     for (int i = j + 1; i < TB; ++i) {
       double sx = 0.0, sy = 0.0;
       for (int q = j + g; q < i; q += 4) {
-        const double2 l = a[i][q], x = li[q][j];
+        const double2 l = a[i][q];
+        const double2 x = q == j ? make_double2(dinv[j], 0.0) : a[j][q];
         sx += l.x * x.x - l.y * x.y;
         sy += l.x * x.y + l.y * x.x;
       }
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
       sx += __shfl_xor(sx, 2);
       sy += __shfl_xor(sy, 2);
       const double inv = dinv[i];
-      if (g == 0) li[i][j] = make_double2(-sx * inv, -sy * inv);
+      if (g == 0) a[j][i] = make_double2(-sx * inv, -sy * inv);
       __builtin_amdgcn_wave_barrier();  // (compiler only: the other lanes of the column read it next round)
     }
   }
@@ -369,8 +372,9 @@ __global__ __launch_bounds__(kThreads) void k_chol_diag(DenseParams p) {
   double2* Lout = p.Linv + ((int64_t)mat * p.T + p.J) * TB * TB;
   for (int idx = threadIdx.x; idx < TB * TB; idx += kThreads) {
     const int i = idx >> 6, j = idx & 63;
-    Ablk[(int64_t)i * p.Np + j] = a[i][j];  // upper part zeroed
-    Lout[idx] = li[i][j];
+    const double2 zero = make_double2(0.0, 0.0);
+    Ablk[(int64_t)i * p.Np + j] = j <= i ? a[i][j] : zero;  // upper part zeroed
+    Lout[idx] = j < i ? a[j][i] : (j == i ? make_double2(dinv[i], 0.0) : zero);
   }
 }
 

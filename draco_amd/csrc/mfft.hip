@@ -329,7 +329,8 @@ __global__ __launch_bounds__(kThreads) void k_mifft_unpack(MifftParams p) {
 // weight: ws[r] = nra^2 * inz(sum_ra inz(w[r, ra])); out[m, s, r] = ws[r] * wscale[m].
 // One wave per row; the broadcast over (m, s) is written by the same block with
 // consecutive threads on consecutive rows.
-constexpr int kWRows = 16;  // rows per block (4 waves x 4 rows each)
+constexpr int kWRows = 64;  // rows per block (16 waves x 4 rows each): every (m, +/-) slot is one 512-byte store segment
+                            // (16 rows = 128-byte segments ran at 4.2 TB/s: tools/stage_timings.py)
 __global__ __launch_bounds__(kThreads) void k_mmode_weight(const float* __restrict__ w, int64_t nrow,
                                                            int nra, double* __restrict__ out, int mmax,
                                                            const double* __restrict__ wscale) {
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kThreads) void k_mmode_weight(const float* __restri
     if (r0 + rr >= nrow) continue;
     double v = ws[rr];
     if (wscale) v *= wscale[ms >> 1];
-    out[(int64_t)ms * nrow + r0 + rr] = v;
+    __builtin_nontemporal_store(v, &out[(int64_t)ms * nrow + r0 + rr]);  // written once, read by a later kernel
   }
 }
 

@@ -387,7 +387,7 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   }
   const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
-  const size_t diag_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
+  const size_t diag_lds = (size_t)TB * (TB + 1) * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
 
   std::vector<dmm_tile> tiles_c;
@@ -513,7 +513,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     if (rc) return rc;
   }
   const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);
-  const size_t diag_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
+  const size_t diag_lds = (size_t)TB * (TB + 1) * sizeof(double2);
   const size_t sub_lds = (size_t)2 * TB * (TB + 1) * sizeof(double2);
   const size_t fil_lds = (size_t)2 * L.Np * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
