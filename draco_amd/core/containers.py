@@ -140,6 +140,50 @@ class ContainerBase:
     def redistribute(self, axis):  # single process: nothing to move
         return None
 
+    # ---- stage outputs on disk (the reference's `save` / `output_root` task parameters write every task's output
+    # container to HDF5, and a pipeline resumes by loading it, doc/pipeline_params.yaml:12-13, examples/test.yaml:10-13
+    # [caput, 3P]).  h5py is not in this image: the same round trip through one .npz per container.
+    def save(self, path):
+        """Write axes, attributes, reverse maps and datasets (copied back from the device if need be) to ``path``."""
+        blob = {"__class__": np.array(type(self).__name__)}
+        for k, v in self.index_map.items():
+            blob["index_map/" + k] = np.asarray(v)
+        for k, v in self.reverse_map.items():
+            blob["reverse_map/" + k] = np.asarray(v)
+        for k, v in self.attrs.items():
+            blob["attrs/" + k] = np.asarray(v)
+        for k, ds in self.datasets.items():
+            blob["dataset/" + k] = np.asarray(ds.host())
+        with open(path, "wb") as fh:  # (np.savez would append ".npz" to a bare name)
+            np.savez(fh, **blob)
+
+    @classmethod
+    def load(cls, path):
+        """Rebuild a container written by :meth:`save` (host resident)."""
+        with np.load(path, allow_pickle=False) as z:
+            name = str(z["__class__"])
+            if name != cls.__name__ and cls is not ContainerBase:
+                raise TypeError(f"{path} holds a {name}, not a {cls.__name__}")
+            klass = cls if cls is not ContainerBase else next(c for c in _all_containers() if c.__name__ == name)
+            out = klass.__new__(klass)
+            out.index_map, out.reverse_map, out.attrs, out.datasets, out.comm = {}, {}, {}, {}, None
+            if hasattr(klass, "_optional_spec"):
+                out._dataset_spec = dict(klass._dataset_spec)
+            for key in z.files:
+                kind, _, k = key.partition("/")
+                if kind == "index_map":
+                    out.index_map[k] = z[key]
+                elif kind == "reverse_map":
+                    out.reverse_map[k] = z[key]
+                elif kind == "attrs":
+                    v = z[key]
+                    out.attrs[k] = v.item() if v.ndim == 0 else v
+                elif kind == "dataset":
+                    if k not in out._dataset_spec and k in getattr(klass, "_optional_spec", {}):
+                        out._dataset_spec[k] = klass._optional_spec[k]
+                    out.datasets[k] = Dataset(host=z[key])
+        return out
+
     def dataset_shape(self, name):
         return tuple(len(self.index_map[a]) for a in self._dataset_spec[name]["axes"])
 
@@ -371,3 +415,13 @@ class Map(ContainerBase, _FreqMixin):
     @property
     def nside(self):
         return int(round((len(self.index_map["pixel"]) // 12) ** 0.5))
+
+
+def _all_containers():
+    found, todo = [], [ContainerBase]
+    while todo:
+        c = todo.pop()
+        for sub in c.__subclasses__():
+            found.append(sub)
+            todo.append(sub)
+    return found

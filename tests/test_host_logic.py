@@ -143,3 +143,32 @@ def test_oracle_is_imported_only_where_it_may_be():
         if isinstance(node, ast.FunctionDef) and node.name == "smoke":
             allowed.update(range(node.lineno, node.end_lineno + 1))
     assert all(ln in allowed for ln in oracle_imports(root / "__graft_entry__.py"))
+
+
+def test_container_save_load_round_trip(tmp_path):
+    """Stage outputs can be written and read back (the reference's save / resume-from-file pattern)."""
+    from draco_amd.core import containers
+
+    rng = np.random.default_rng(0)
+    prod = np.array([(0, 0), (0, 1), (1, 1)], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+    ss = containers.SiderealStream(freq=[400.0, 410.0], ra=6, prod=prod, input=2)
+    ss.vis[:] = (rng.standard_normal(ss.vis.shape) + 1j * rng.standard_normal(ss.vis.shape)).astype(np.complex64)
+    ss.weight[:] = rng.uniform(size=ss.weight.shape).astype(np.float32)
+    ss.attrs["tag"] = "day 12"
+    f = tmp_path / "sstream.npz"
+    ss.save(f)
+    back = containers.SiderealStream.load(f)
+    assert np.array_equal(back.vis[:], ss.vis[:]) and back.vis.dtype == np.complex64
+    assert np.array_equal(back.weight[:], ss.weight[:]) and back.attrs["tag"] == "day 12"
+    assert np.array_equal(back.index_map["freq"]["centre"], [400.0, 410.0]) and np.array_equal(back.index_map["prod"], prod)
+    mm = containers.MModes(mmax=3, oddra=True, freq=[400.0], stack=2)
+    mm.vis[:] = 1.5 - 2j
+    g = tmp_path / "mmodes"
+    mm.save(g)
+    any_back = containers.ContainerBase.load(g)  # class recovered from the file
+    assert isinstance(any_back, containers.MModes) and any_back.oddra and any_back.mmax == 3
+    assert np.array_equal(any_back.vis[:], mm.vis[:])
+    import pytest
+
+    with pytest.raises(TypeError):
+        containers.Map.load(g)

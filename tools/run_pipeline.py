@@ -77,6 +77,7 @@ def main():
     pool = int(args.pool_gb * 1e9) if args.pool_gb > 0 else None
     sim = SimulateSidereal(pool_bytes=pool)
     sim.setup(bt)
+    timed("SimulateSidereal_first_call(incl. B block allocation)", lambda: sim.process(mp))
     ss = timed("SimulateSidereal", lambda: sim.process(mp))
     if args.noise:
         gn = GaussianNoise(seed=1, ndays=733.0, recv_temp=50.0)
