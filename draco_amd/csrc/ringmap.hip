@@ -10,15 +10,13 @@
 //     weight = 1 / (0.5 sum_m (sqrt(sum (w|b|)^2 var) win norm / ((mmax+1) C))^2)
 // All HBM-bound elementwise / small-reduction work plus one length-nra inverse FFT per
 // (pol, freq, el):
-//   k_rm_reduce  lanes across el (coalesced 512-byte row pieces of hv / bv), the (+/-, ew)
-//                sums in registers, results transposed through LDS to rows contiguous in m;
-//   k_rm_fft     RB rows per block in LDS; the point-source normalisation 1/mean_m(dirty_m) is formed
-//                from the row at hand (k_rm_norm supplies the reference-elevation one if the
-//                deconvolution is skipped); the Hermitian spectra of the (complex) map modes
-//                and of the (real) dirty-beam modes are packed into ONE complex sequence
-//                z = X_map + i X_dirty, so a single inverse FFT yields both real outputs;
-//                powers of two run the in-LDS radix passes, other lengths Bluestein
-//                (shared machinery, fft_lds.h); also the dirty-beam power and the map weight;
+//   k_rm_reduce  lanes across el (coalesced 512-byte row pieces of hv / bv), the (+/-, ew) sums in registers, the modes transposed through LDS to rows contiguous in m, and the
+//                block's share of the three per-row sums over m the next stage needs (normalisation, noise weight,
+//                dirty-beam power by Parseval), so that every mode is read ONCE downstream;
+//   k_rm_fft     one inverse FFT per TWO rows: the Hermitian spectra of two rows' map modes are packed into one
+//                complex sequence z = X_map(row0) + i X_map(row1) (when the RA-space dirty beam is asked for:
+//                z = X_map + i X_dirty of one row); powers of two run the in-LDS radix passes, other lengths
+//                Bluestein (shared machinery, fft_lds.h);
 //   k_rm_store   tiled transpose [el][ra] -> the reference's [ra][el] layout.
 // float64 arithmetic throughout (the reference mixes float32 and float64 by weight scheme).
 #include <math.h>
@@ -35,14 +33,16 @@ struct RmParams {
   int nm, nm_beam, npol, nfreq, new_, nel, nra, mmax;
   int mode;   // 0: w = wt[ew] (normalised table); 1: inverse variance normalised over ew; 2: inverse variance raw
   int skip, iref;
+  int nchunk;         // number of m chunks of k_rm_reduce (ceil(nm / MT))
   const float2* hv;   // [nm, 2, npol, nfreq, new, nel]
   const float* hw;    // [nm, 2, npol, nfreq, new]
   const float2* bv;   // [nm_beam, 2, npol, nfreq, new, nel]
   const double* wt;   // [new] weight table (mode 0) or keep-mask (modes 1, 2)
   const double* eps;  // [nfreq, nm]
   const float* window;  // [nfreq, nm, nel] or null
-  double4* s1;        // [npol*nfreq][nel][nm] {map_re, map_im, dirty, q}
-  double* norm;       // [npol*nfreq][nel]
+  double2* s_map;     // [npol*nfreq][nel][nm] map modes (re, im)
+  double* s_dirty;    // [npol*nfreq][nel][nm] dirty-beam modes (real)
+  double4* psum;      // [npol*nfreq][nchunk][nel] partial sums over the chunk's m: {dirty, q^2, c_m dirty^2, -}
   double* tmp_map;    // [npol*nfreq][nel][nra]
   double* tmp_db;     // same or null
   double* dbp;        // [npol*nfreq][nel]   -> dirty_beam_power [1, npol, nfreq, nel]
@@ -54,30 +54,49 @@ struct RmParams {
 
 constexpr int MT = 16;  // m per block in k_rm_reduce
 
+// One (el tile, 16 m, pol x freq) per block; EPL elevations per lane (1 is what ships).
+// Per (m, el): the (+/-, ew) sums, the map / dirty-beam modes (to s_map / s_dirty, transposed through LDS so that
+// rows are contiguous in m) and the block's share of three sums over m that the FFT stage needs per row -- dirty
+// (point-source normalisation), q^2 (noise weight) and c_m dirty^2 (dirty-beam power by Parseval) -- so that the FFT
+// stage reads every mode once.
+template <int EPL>
 __global__ __launch_bounds__(kThreads) void k_rm_reduce(RmParams p) {
-  __shared__ double4 tile[MT][65];
+  constexpr int ET = 64 * EPL;
+  __shared__ double2 tmap[MT][ET + 1];
+  __shared__ double tdirty[MT][ET + 1];
+  __shared__ double wsum[3][kThreads / 64][ET];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int el0 = blockIdx.x * 64, m0 = blockIdx.y * MT, pf = blockIdx.z;
+  const int el0 = blockIdx.x * ET, m0 = blockIdx.y * MT, pf = blockIdx.z;
   const int pol = pf / p.nfreq, f = pf - pol * p.nfreq;
-  const int el = el0 + lane;
+  const int N = p.nra;
+  double acc_d[EPL], acc_q[EPL], acc_p[EPL];
+#pragma unroll
+  for (int u = 0; u < EPL; ++u) acc_d[u] = acc_q[u] = acc_p[u] = 0.0;
   for (int mi = wave; mi < MT; mi += kThreads / 64) {
     const int m = m0 + mi;
-    double sw = 0.0, mre = 0.0, mim = 0.0, sg = 0.0;
+    double sw[EPL], mre[EPL], mim[EPL], sg[EPL];
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) sw[u] = mre[u] = mim[u] = sg[u] = 0.0;
+    const int el = el0 + EPL * lane;
     if (m < p.nm && el < p.nel) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int64_t wbase = ((((int64_t)m * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_;
-        double wsum = 0.0;
+        double wsumv = 0.0;
         if (p.mode == 1)
-          for (int e = 0; e < p.new_; ++e) wsum += (double)p.hw[wbase + e] * p.wt[e];
-        const double wnorm = wsum != 0.0 ? 1.0 / wsum : 0.0;
+          for (int e = 0; e < p.new_; ++e) wsumv += (double)p.hw[wbase + e] * p.wt[e];
+        const double wnorm = wsumv != 0.0 ? 1.0 / wsumv : 0.0;
         const float2* hrow = p.hv + wbase * p.nel + el;
         const float2* brow = p.bv + wbase * p.nel + el;  // same [m, s, pol, f, ew] prefix: the beam only has more m rows
 #pragma unroll 4
         for (int e = 0; e < p.new_; ++e) {
           // loads are unconditional (no branch on the weight): the compiler batches them
-          const float2 h = hrow[(int64_t)e * p.nel];
-          const float2 b = brow[(int64_t)e * p.nel];
+          float2 h[EPL], b[EPL];
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) {
+            h[u] = hrow[(int64_t)e * p.nel + u];
+            b[u] = brow[(int64_t)e * p.nel + u];
+          }
           double iv = (double)p.hw[wbase + e];
           double w;
           if (p.mode == 0) {
@@ -88,43 +107,67 @@ __global__ __launch_bounds__(kThreads) void k_rm_reduce(RmParams p) {
             if (!(iv > 0.0)) w = 0.0;
           }
           const double var = iv > 0.0 ? 1.0 / iv : 0.0;
-          const double br = b.x, bi = b.y, hr = h.x, hi = h.y;
-          const double b2 = br * br + bi * bi;
-          sw = fma(w, b2, sw);
-          mre = fma(w, br * hr + bi * hi, mre);  // conj(b) * h
-          mim = fma(w, br * hi - bi * hr, mim);
-          sg = fma(w * w * b2, var, sg);
+#pragma unroll
+          for (int u = 0; u < EPL; ++u) {
+            const double br = b[u].x, bi = b[u].y, hr = h[u].x, hi = h[u].y;
+            const double b2 = br * br + bi * bi;
+            sw[u] = fma(w, b2, sw[u]);
+            mre[u] = fma(w, br * hr + bi * hi, mre[u]);  // conj(b) * h
+            mim[u] = fma(w, br * hi - bi * hr, mim[u]);
+            sg[u] = fma(w * w * b2, var, sg[u]);
+          }
         }
       }
     }
-    double4 r = make_double4(0.0, 0.0, 0.0, 0.0);
-    if (m < p.nm && el < p.nel) {
-      const double cinv = p.skip ? 1.0 : p.eps[(int64_t)f * p.nm + m] + sw;
-      const double ic = cinv != 0.0 ? 1.0 / cinv : 0.0;
-      const double win = p.window ? (double)p.window[((int64_t)f * p.nm + m) * p.nel + el] : 1.0;
-      const double c2 = (double)(p.mmax + 1) * cinv;
-      r = make_double4(win * mre * ic, win * mim * ic, win * sw * ic, sqrt(sg) * win * (c2 != 0.0 ? 1.0 / c2 : 0.0));
+#pragma unroll
+    for (int u = 0; u < EPL; ++u) {
+      double2 rm = make_double2(0.0, 0.0);
+      double rd = 0.0;
+      if (m < p.nm && el + u < p.nel) {
+        const double cinv = p.skip ? 1.0 : p.eps[(int64_t)f * p.nm + m] + sw[u];
+        const double ic = cinv != 0.0 ? 1.0 / cinv : 0.0;
+        const double win = p.window ? (double)p.window[((int64_t)f * p.nm + m) * p.nel + el + u] : 1.0;
+        const double c2 = (double)(p.mmax + 1) * cinv;
+        rm = make_double2(win * mre[u] * ic, win * mim[u] * ic);
+        rd = win * sw[u] * ic;
+        const double qv = sqrt(sg[u]) * win * (c2 != 0.0 ? 1.0 / c2 : 0.0);
+        acc_d[u] += rd;
+        acc_q[u] += qv * qv;
+        // weight of mode m in sum_k X_ext(k)^2 of the Hermitian extension to N bins: DC and (even N) Nyquist once
+        acc_p[u] += ((m == 0 || 2 * m == N) ? 1.0 : 2.0) * rd * rd;
+      }
+      tmap[mi][EPL * lane + u] = rm;
+      tdirty[mi][EPL * lane + u] = rd;
     }
-    tile[mi][lane] = r;
+  }
+#pragma unroll
+  for (int u = 0; u < EPL; ++u) {
+    wsum[0][wave][EPL * lane + u] = acc_d[u];
+    wsum[1][wave][EPL * lane + u] = acc_q[u];
+    wsum[2][wave][EPL * lane + u] = acc_p[u];
   }
   __syncthreads();
-  // transposed store: rows (el) contiguous in m
-  for (int idx = threadIdx.x; idx < 64 * MT; idx += kThreads) {
-    const int e = idx / MT, mi = idx - e * MT;
-    if (el0 + e < p.nel && m0 + mi < p.nm) p.s1[((int64_t)pf * p.nel + el0 + e) * p.nm + m0 + mi] = tile[mi][e];
+  // this block's share of the per-row sums, waves added in a fixed order
+  for (int e = threadIdx.x; e < ET; e += kThreads) {
+    if (el0 + e < p.nel) {
+      double4 t = make_double4(wsum[0][0][e], wsum[1][0][e], wsum[2][0][e], 0.0);
+#pragma unroll
+      for (int w2 = 1; w2 < kThreads / 64; ++w2) {
+        t.x += wsum[0][w2][e];
+        t.y += wsum[1][w2][e];
+        t.z += wsum[2][w2][e];
+      }
+      p.psum[((int64_t)pf * p.nchunk + blockIdx.y) * p.nel + el0 + e] = t;
+    }
   }
-}
-
-// skip_deconvolution only: norm[pf][iref] = inz(mean_m dirty_m) at the reference elevation; one wave per (pol, freq)
-__global__ void k_rm_norm(RmParams p) {
-  const int pf = blockIdx.x;
-  const double4* row = p.s1 + ((int64_t)pf * p.nel + p.iref) * p.nm;
-  double acc = 0.0;
-  for (int m = threadIdx.x; m < p.nm; m += 64) acc += row[m].z;
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (threadIdx.x == 0) {
-    const double mean = acc / (double)p.nm;
-    p.norm[(int64_t)pf * p.nel + p.iref] = mean != 0.0 ? 1.0 / mean : 0.0;
+  // transposed store: rows (el) contiguous in m
+  for (int idx = threadIdx.x; idx < ET * MT; idx += kThreads) {
+    const int e = idx / MT, mi = idx - e * MT;
+    if (el0 + e < p.nel && m0 + mi < p.nm) {
+      const int64_t o = ((int64_t)pf * p.nel + el0 + e) * p.nm + m0 + mi;
+      p.s_map[o] = tmap[mi][e];
+      p.s_dirty[o] = tdirty[mi][e];
+    }
   }
 }
 
@@ -135,6 +178,25 @@ struct RmFft {
   const double2* bfilt;
 };
 
+// Hermitian extension to N bins of a row's map modes (complex) or dirty-beam modes (real, `d` only): what
+// np.fft.irfft(x, n=N) transforms.  Bins 1..half are plain, N/2 (even N) is the real Nyquist bin.
+__device__ __forceinline__ void rm_spec(const RmParams& p, int64_t row, int k, int N, int half, bool dirty, double& xr, double& xi) {
+  xr = xi = 0.0;
+  const int kk = k <= half || 2 * k == N ? k : N - k;
+  if (kk >= p.nm) return;
+  if (dirty) {
+    xr = p.s_dirty[row * p.nm + kk];
+    return;
+  }
+  const double2 v = p.s_map[row * p.nm + kk];
+  xr = v.x;
+  if (k != 0 && 2 * k != N) xi = k <= half ? v.y : -v.y;
+}
+
+// PAIR = 2: two rows per complex transform (z = X_map(row0) + i X_map(row1)); the dirty beam is not transformed at
+// all -- its power comes from the modes by Parseval.  PAIR = 1 (the dirty beam is wanted in RA space): z = X_map + i
+// X_dirty of one row, as before.  Either way a single inverse FFT yields two real outputs.
+template <int PAIR>
 __global__ __launch_bounds__(kThreads) void k_rm_fft(RmParams p, RmFft q) {
   extern __shared__ __align__(16) unsigned char smem[];
   C<double>* buf = reinterpret_cast<C<double>*>(smem);
@@ -142,40 +204,24 @@ __global__ __launch_bounds__(kThreads) void k_rm_fft(RmParams p, RmFft q) {
   const C<double>* tw = q.tw_in_lds ? twl : reinterpret_cast<const C<double>*>(q.tw);
   const int N = p.nra, M = q.M, RB = q.RB, P = q.P;
   const int64_t nrow = (int64_t)p.npol * p.nfreq * p.nel;
-  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int64_t t0 = (int64_t)blockIdx.x * RB;  // first transform of the block; transform t holds rows PAIR t (, +1)
   if (q.tw_in_lds)
     for (int k = threadIdx.x; k < (M >> 1); k += kThreads) twl[k] = {q.tw[k].x, q.tw[k].y};
-  const int half = (N - 1) / 2;  // bins 1..half are plain; N/2 (even N) is the real Nyquist bin
+  const int half = (N - 1) / 2;
   for (int idx = threadIdx.x; idx < RB * M; idx += kThreads) {
     const int r = idx / M, k = idx - r * M;
     C<double> v = {0.0, 0.0};
-    if (k < N && r0 + r < nrow) {
-      const double4* row = p.s1 + (r0 + r) * p.nm;
-      double xr = 0.0, xi = 0.0, xd = 0.0;  // X_map = xr + i xi, X_dirty = xd (real)
-      if (k == 0) {
-        xr = row[0].x;
-        xd = row[0].z;
-      } else if (k <= half) {
-        if (k < p.nm) {
-          xr = row[k].x;
-          xi = row[k].y;
-          xd = row[k].z;
-        }
-      } else if (2 * k == N) {
-        if (k < p.nm) {
-          xr = row[k].x;
-          xd = row[k].z;
-        }
+    const int64_t row0 = (t0 + r) * PAIR;
+    if (k < N && row0 < nrow) {
+      double ar, ai, br = 0.0, bi = 0.0;
+      rm_spec(p, row0, k, N, half, false, ar, ai);
+      if (PAIR == 2) {
+        if (row0 + 1 < nrow) rm_spec(p, row0 + 1, k, N, half, false, br, bi);
       } else {
-        const int kk = N - k;
-        if (kk < p.nm) {
-          xr = row[kk].x;
-          xi = -row[kk].y;
-          xd = row[kk].z;
-        }
+        rm_spec(p, row0, k, N, half, true, br, bi);
       }
-      // z = X_map + i X_dirty = (xr) + i (xi + xd); we load conj(z)
-      v = {xr, -(xi + xd)};
+      // z = A + i B = (ar - bi) + i (ai + br); we load conj(z)
+      v = {ar - bi, -(ai + br)};
       if (q.blue) v = dmm_fft::cmul<double>(v, {q.chirp[k].x, q.chirp[k].y});
     }
     buf[r * P + (q.blue ? k : dmm_fft::bitrev(k, q.logM))] = v;
@@ -192,64 +238,72 @@ __global__ __launch_bounds__(kThreads) void k_rm_fft(RmParams p, RmFft q) {
   } else {
     dmm_fft::fft_dit<double, false, kThreads>(buf, tw, RB, M, q.logM, P);
   }
-  // finish: y = conj(result) / N; map = Re y * norm, dirty = Im y * norm
+  // finish: y = conj(result) / N; first output = Re y, second = Im y, each times its row's normalisation
   __shared__ double red[kThreads];
+  __shared__ double s_nrm[2], s_q2[2], s_p2[2];
   for (int r = 0; r < RB; ++r) {
-    const int64_t row = r0 + r;
-    if (row >= nrow) break;  // uniform
-    const int64_t pf = row / p.nel;
-    (void)0;
-    const double4* srow = p.s1 + row * p.nm;
-    double nrm;
-    if (p.skip) {
-      nrm = p.norm[pf * p.nel + p.iref];  // normalised at the reference declination (k_rm_norm)
-    } else {  // 1 / mean_m(dirty_m) of this row
-      double dsum = 0.0;
-      for (int m = threadIdx.x; m < p.nm; m += kThreads) dsum += srow[m].z;
-      red[threadIdx.x] = dsum;
+    const int64_t row0 = (t0 + r) * PAIR;
+    if (row0 >= nrow) break;  // uniform
+    // per-row sums over m from the reduce stage's chunk partials (fixed order): wave w < PAIR serves row0 + w
+    if ((threadIdx.x >> 6) < PAIR) {  // lanes over the chunks, then a butterfly: the same order every time
+      const int w2 = threadIdx.x >> 6, ln = threadIdx.x & 63;
+      const int64_t row = row0 + w2;
+      double d = 0.0, q2 = 0.0, p2 = 0.0;
+      if (row < nrow) {
+        const int64_t pf = row / p.nel;
+        const int el = (int)(row - pf * p.nel);
+        const int eln = p.skip ? p.iref : el;  // skip_deconvolution: normalised at the reference declination
+        for (int c = ln; c < p.nchunk; c += 64) {
+          d += p.psum[(pf * p.nchunk + c) * p.nel + eln].x;
+          const double4 t = p.psum[(pf * p.nchunk + c) * p.nel + el];
+          q2 += t.y;
+          p2 += t.z;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        d += __shfl_xor(d, o, 64);
+        q2 += __shfl_xor(q2, o, 64);
+        p2 += __shfl_xor(p2, o, 64);
+      }
+      if (ln == 0) {
+        const double mean = d / (double)p.nm;
+        s_nrm[w2] = (row < nrow && mean != 0.0) ? 1.0 / mean : 0.0;
+        s_q2[w2] = q2;
+        s_p2[w2] = p2;
+      }
+    }
+    __syncthreads();
+    const double sc0 = s_nrm[0] / (double)N, sc1 = s_nrm[PAIR - 1] / (double)N;
+    double pw = 0.0;
+    for (int n = threadIdx.x; n < N; n += kThreads) {
+      C<double> v = buf[r * P + n];
+      if (q.blue) v = dmm_fft::cmul<double>(v, {q.chirp[n].x, q.chirp[n].y});
+      p.tmp_map[row0 * N + n] = v.x * sc0;
+      if (PAIR == 2) {
+        if (row0 + 1 < nrow) p.tmp_map[(row0 + 1) * N + n] = -v.y * sc1;
+      } else {
+        const double dbv = -v.y * sc0;
+        if (p.tmp_db) p.tmp_db[row0 * N + n] = dbv;
+        pw += dbv * dbv;
+      }
+    }
+    if (PAIR == 1) {  // dirty-beam power from the RA-space beam
+      red[threadIdx.x] = pw;
       __syncthreads();
       for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
         if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
         __syncthreads();
       }
-      const double mean = red[0] / (double)p.nm;
-      nrm = mean != 0.0 ? 1.0 / mean : 0.0;
-      __syncthreads();
     }
-    const double sc = nrm / (double)N;
-    double pw = 0.0;
-    for (int n = threadIdx.x; n < N; n += kThreads) {
-      C<double> v = buf[r * P + n];
-      if (q.blue) v = dmm_fft::cmul<double>(v, {q.chirp[n].x, q.chirp[n].y});
-      const double mp = v.x * sc, dbv = -v.y * sc;
-      p.tmp_map[row * N + n] = mp;
-      if (p.tmp_db) p.tmp_db[row * N + n] = dbv;
-      pw += dbv * dbv;
-    }
-    // variance sum over m (q column of s1) rides the same reduction
-    double vs = 0.0;
-    for (int m = threadIdx.x; m < p.nm; m += kThreads) {
-      const double t = srow[m].w * nrm;
-      vs += t * t;
-    }
-    red[threadIdx.x] = pw;
-    __syncthreads();
-    for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
-      if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
-      __syncthreads();
-    }
-    const double pw_tot = red[0];
-    __syncthreads();
-    red[threadIdx.x] = vs;
-    __syncthreads();
-    for (int s2 = kThreads / 2; s2 > 0; s2 >>= 1) {
-      if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      p.dbp[row] = pw_tot / (double)N;
-      const double sv = 0.5 * red[0];
-      p.wv[row] = sv != 0.0 ? 1.0 / sv : 0.0;
+    if (threadIdx.x < PAIR && row0 + threadIdx.x < nrow) {
+      const int w2 = threadIdx.x;
+      const double nrm = s_nrm[w2];
+      // Parseval: sum_n d(n)^2 = (1/N) sum_k X_ext(k)^2 for d = irfft(X); the beam is scaled by nrm
+      const double pw_tot = PAIR == 1 ? red[0] : nrm * nrm * s_p2[w2] / (double)N;
+      p.dbp[row0 + w2] = pw_tot / (double)N;
+      const double sv = 0.5 * nrm * nrm * s_q2[w2];
+      p.wv[row0 + w2] = sv != 0.0 ? 1.0 / sv : 0.0;
     }
     __syncthreads();
   }
@@ -344,11 +398,14 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   const size_t lds = rb * row_b + (q.tw_in_lds ? tw_b : 0);
 
   const int64_t nrow = (int64_t)npol * nfreq * nel;
-  const size_t b_s1 = (size_t)nrow * nm * sizeof(double4);
+  const int nchunk = (nm + MT - 1) / MT;
+  const size_t b_map = (size_t)nrow * nm * sizeof(double2);
+  const size_t b_dirty = ((size_t)nrow * nm * sizeof(double) + 255) / 256 * 256;
+  const size_t b_psum = (size_t)npol * nfreq * nchunk * nel * sizeof(double4);
   const size_t b_vec = ((size_t)nrow * sizeof(double) + 255) / 256 * 256;
   const size_t b_tmp = (size_t)nrow * nra * sizeof(double);
   void* scratch = nullptr;
-  rc = dmm_get_scratch(ctx, b_s1 + 3 * b_vec + (dirty_beam ? 2 : 1) * b_tmp + 1024, &scratch);
+  rc = dmm_get_scratch(ctx, b_map + b_dirty + b_psum + b_vec + (dirty_beam ? 2 : 1) * b_tmp + 1024, &scratch);
   if (rc) return rc;
   unsigned char* sp = (unsigned char*)scratch;
   RmParams p;
@@ -363,19 +420,21 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   p.mode = weight_mode;
   p.skip = skip_deconvolution;
   p.iref = iref;
+  p.nchunk = nchunk;
   p.hv = (const float2*)hv;
   p.hw = hw;
   p.bv = (const float2*)bv;
   p.wt = ew_table;
   p.eps = eps;
   p.window = window;
-  p.s1 = (double4*)sp;
-  sp += b_s1;
-  p.norm = (double*)sp;
-  sp += b_vec;
+  p.s_map = (double2*)sp;
+  sp += b_map;
+  p.s_dirty = (double*)sp;
+  sp += b_dirty;
+  p.psum = (double4*)sp;
+  sp += b_psum;
   p.dbp = dirty_beam_power;
   p.wv = (double*)sp;
-  sp += b_vec;
   sp += b_vec;
   p.tmp_map = (double*)sp;
   sp += b_tmp;
@@ -384,10 +443,17 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   p.weight = weight;
   p.db = dirty_beam;
 
-  hipLaunchKernelGGL(k_rm_reduce, dim3((nel + 63) / 64, (nm + MT - 1) / MT, npol * nfreq), dim3(kThreads), 0, ctx->stream, p);
-  if (skip_deconvolution) hipLaunchKernelGGL(k_rm_norm, dim3(npol * nfreq), dim3(64), 0, ctx->stream, p);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_rm_fft, dim3((unsigned)((nrow + rb - 1) / rb)), dim3(kThreads), lds, ctx->stream, p, q);
+  // (two elevations per lane with 16-byte loads were tried: 715 instead of 630 us for this kernel at the CHIME-like
+  // shape -- half as many resident waves; the kernel is latency bound on its 16 loads per m)
+  hipLaunchKernelGGL(k_rm_reduce<1>, dim3((nel + 63) / 64, nchunk, npol * nfreq), dim3(kThreads), 0, ctx->stream, p);
+  if (dirty_beam) {
+    DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fft<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_rm_fft<1>, dim3((unsigned)((nrow + rb - 1) / rb)), dim3(kThreads), lds, ctx->stream, p, q);
+  } else {
+    const int64_t ntrans = (nrow + 1) / 2;
+    DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fft<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_rm_fft<2>, dim3((unsigned)((ntrans + rb - 1) / rb)), dim3(kThreads), lds, ctx->stream, p, q);
+  }
   hipLaunchKernelGGL(k_rm_store, dim3((nra + 31) / 32, (nel + 31) / 32, npol * nfreq), dim3(kThreads), 0, ctx->stream, p);
   DMM_HIP(hipGetLastError());
   return DMM_OK;
