@@ -53,6 +53,7 @@ struct RmParams {
 };
 
 constexpr int MT = 16;  // m per block in k_rm_reduce
+constexpr int kTermBatch = 8;  // (sign, EW) terms whose hv / bv loads are in flight together
 
 // One (el tile, 16 m, pol x freq) per block; EPL elevations per lane (1 is what ships).
 // Per (m, el): the (+/-, ew) sums, the map / dirty-beam modes (to s_map / s_dirty, transposed through LDS so that
@@ -78,44 +79,66 @@ __global__ __launch_bounds__(kThreads) void k_rm_reduce(RmParams p) {
 #pragma unroll
     for (int u = 0; u < EPL; ++u) sw[u] = mre[u] = mim[u] = sg[u] = 0.0;
     const int el = el0 + EPL * lane;
-    if (m < p.nm && el < p.nel) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int64_t wbase = ((((int64_t)m * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_;
-        double wsumv = 0.0;
-        if (p.mode == 1)
-          for (int e = 0; e < p.new_; ++e) wsumv += (double)p.hw[wbase + e] * p.wt[e];
-        const double wnorm = wsumv != 0.0 ? 1.0 / wsumv : 0.0;
-        const float2* hrow = p.hv + wbase * p.nel + el;
-        const float2* brow = p.bv + wbase * p.nel + el;  // same [m, s, pol, f, ew] prefix: the beam only has more m rows
-#pragma unroll 4
-        for (int e = 0; e < p.new_; ++e) {
-          // loads are unconditional (no branch on the weight): the compiler batches them
-          float2 h[EPL], b[EPL];
-#pragma unroll
-          for (int u = 0; u < EPL; ++u) {
-            h[u] = hrow[(int64_t)e * p.nel + u];
-            b[u] = brow[(int64_t)e * p.nel + u];
-          }
+    if (m < p.nm) {  // (uniform over the wave)
+      // The weights of the 2 x new (sign, EW separation) terms do not depend on the elevation: lane s * new + e works
+      // out w and w^2 var once -- two float64 divisions -- and the row loop picks them up by shuffles, instead of every
+      // lane repeating the divisions for every term (they were 40 % of the kernel's vector instructions).
+      const int nterm = 2 * p.new_;
+      double w_l = 0.0, g_l = 0.0;
+      for (int t0 = 0; t0 < nterm; t0 += 64) {  // (one round unless there are more than 32 EW separations)
+        const int t = t0 + lane;
+        double w = 0.0, g = 0.0;
+        if (t < nterm) {
+          const int s = t / p.new_, e = t - s * p.new_;
+          const int64_t wbase = ((((int64_t)m * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_;
           double iv = (double)p.hw[wbase + e];
-          double w;
           if (p.mode == 0) {
             w = iv > 0.0 ? p.wt[e] : 0.0;
           } else {
             iv *= p.wt[e];  // the reference zeroes the excluded cylinders inside inv_var itself
-            w = p.mode == 1 ? iv * wnorm : iv;
+            if (p.mode == 1) {
+              double wsumv = 0.0;
+              for (int e2 = 0; e2 < p.new_; ++e2) wsumv += (double)p.hw[wbase + e2] * p.wt[e2];
+              w = iv * (wsumv != 0.0 ? 1.0 / wsumv : 0.0);
+            } else {
+              w = iv;
+            }
             if (!(iv > 0.0)) w = 0.0;
           }
-          const double var = iv > 0.0 ? 1.0 / iv : 0.0;
+          g = w * w * (iv > 0.0 ? 1.0 / iv : 0.0);
+        }
+        w_l = w;
+        g_l = g;
+        const int tend = nterm - t0 < 64 ? nterm - t0 : 64;
+        const int elc = el < p.nel ? el : p.nel - EPL;  // lanes past the last elevation load a valid address
+        for (int tt = 0; tt < tend; tt += kTermBatch) {  // a batch of terms: loads issued together, then consumed
+          float2 h[kTermBatch][EPL], b[kTermBatch][EPL];
+          double w2[kTermBatch], g2[kTermBatch];
 #pragma unroll
-          for (int u = 0; u < EPL; ++u) {
-            const double br = b[u].x, bi = b[u].y, hr = h[u].x, hi = h[u].y;
-            const double b2 = br * br + bi * bi;
-            sw[u] = fma(w, b2, sw[u]);
-            mre[u] = fma(w, br * hr + bi * hi, mre[u]);  // conj(b) * h
-            mim[u] = fma(w, br * hi - bi * hr, mim[u]);
-            sg[u] = fma(w * w * b2, var, sg[u]);
+          for (int k = 0; k < kTermBatch; ++k) {
+            const bool live = tt + k < tend;
+            const int tg = t0 + (live ? tt + k : tend - 1), s = tg / p.new_, e = tg - s * p.new_;
+            const double wk = __shfl(w_l, live ? tt + k : 0, 64), gk = __shfl(g_l, live ? tt + k : 0, 64);
+            w2[k] = live ? wk : 0.0;
+            g2[k] = live ? gk : 0.0;
+            const int64_t rbase = (((((int64_t)m * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_ + e) * p.nel + (elc < 0 ? 0 : elc);
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+              h[k][u] = p.hv[rbase + u];
+              b[k][u] = p.bv[rbase + u];
+            }
           }
+#pragma unroll
+          for (int k = 0; k < kTermBatch; ++k)
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+              const double br = b[k][u].x, bi = b[k][u].y, hr = h[k][u].x, hi = h[k][u].y;
+              const double b2 = br * br + bi * bi;
+              sw[u] = fma(w2[k], b2, sw[u]);
+              mre[u] = fma(w2[k], br * hr + bi * hi, mre[u]);  // conj(b) * h
+              mim[u] = fma(w2[k], br * hi - bi * hr, mim[u]);
+              sg[u] = fma(g2[k], b2, sg[u]);
+            }
         }
       }
     }
@@ -127,10 +150,9 @@ __global__ __launch_bounds__(kThreads) void k_rm_reduce(RmParams p) {
         const double cinv = p.skip ? 1.0 : p.eps[(int64_t)f * p.nm + m] + sw[u];
         const double ic = cinv != 0.0 ? 1.0 / cinv : 0.0;
         const double win = p.window ? (double)p.window[((int64_t)f * p.nm + m) * p.nel + el + u] : 1.0;
-        const double c2 = (double)(p.mmax + 1) * cinv;
         rm = make_double2(win * mre[u] * ic, win * mim[u] * ic);
         rd = win * sw[u] * ic;
-        const double qv = sqrt(sg[u]) * win * (c2 != 0.0 ? 1.0 / c2 : 0.0);
+        const double qv = sqrt(sg[u]) * win * ic / (double)(p.mmax + 1);  // 1 / ((mmax + 1) C): one division serves all
         acc_d[u] += rd;
         acc_q[u] += qv * qv;
         // weight of mode m in sum_k X_ext(k)^2 of the Hermitian extension to N bins: DC and (even N) Nyquist once
