@@ -314,6 +314,7 @@ class SolveEngine:
                     )
                 )
             elif kind == "ml":
+                self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = torch.empty(max(int(lib.dmm_ml_workspace_bytes(slab.plan)), 16), dtype=torch.uint8, device=self.ctx.device)
                 _lib.check(
                     lib.dmm_ml_run(
@@ -327,6 +328,15 @@ class SolveEngine:
                 on_freqs_done(alm, f_done, issued // n_m)
                 f_done = issued // n_m
         return alm
+
+    def _offer_workspace(self, option, cap_mib):
+        """Let the dense solvers size their sub-batches for the HBM that is actually free (B block, m-modes and a_lm
+        are allocated by now): half of it, at most ``cap_mib``.  The ML eigen pass pays a fixed cost per Householder
+        column; with 64 GiB (1400 cfg-3 matrices per half-batch instead of 357) that cost is shared four times wider."""
+        free, _ = torch.cuda.mem_get_info(self.ctx.device)
+        mib = min(int(cap_mib), int(free * 0.5) >> 20)
+        if mib >= 1024:
+            _lib.check(_lib.lib.dmm_ctx_set_option(self.ctx.handle, option, mib))
 
     def project(self, alm_d, freq_ind, mmax):
         """``vis [mmax+1, 2, nfreq, npairs] = B_m[f] a_m[f]`` (``stream.py:109-112``)."""

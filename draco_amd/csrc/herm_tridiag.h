@@ -74,7 +74,12 @@ __device__ __forceinline__ void wave_sums(double (&x)[NV], int lane) {
     const bool up = (lane >> bit) & 1;
 #pragma unroll
     for (int k = 0; k < h; ++k) {
-      const double keep = up ? x[h + k] : x[k], send = up ? x[k] : x[h + k];
+      // (the two operands are pinned in registers first: left alone, the compiler turns the selects into ONE dynamically
+      // indexed read of x[] -- a compare-and-select chain through all NV registers per value, 200 of the 370
+      // instructions of the sweep kernel's reduction block)
+      double lo = x[k], hi = x[h + k];
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      const double keep = up ? hi : lo, send = up ? lo : hi;
       x[k] = keep + __shfl_xor(send, 1 << bit);
     }
   }
@@ -383,16 +388,16 @@ __global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
 #pragma unroll
               for (int u = 0; u < NP; ++u) {
                 const double2 vpi = s_vp[u][d], wpi = s_wp[u][d];
-                x.x -= vpi.x * cw[u][kk].x - vpi.y * cw[u][kk].y + wpi.x * cv[u][kk].x - wpi.y * cv[u][kk].y;
-                x.y -= vpi.x * cw[u][kk].y + vpi.y * cw[u][kk].x + wpi.x * cv[u][kk].y + wpi.y * cv[u][kk].x;
+                x.x = fma(-vpi.x, cw[u][kk].x, fma(vpi.y, cw[u][kk].y, fma(-wpi.x, cv[u][kk].x, fma(wpi.y, cv[u][kk].y, x.x))));
+                x.y = fma(-vpi.x, cw[u][kk].y, fma(-vpi.y, cw[u][kk].x, fma(-wpi.x, cv[u][kk].y, fma(-wpi.y, cv[u][kk].x, x.y))));
               }
               row[q][cb] = x;
             }
-            acc[2 * q] += x.x * v[kk].x - x.y * v[kk].y;
-            acc[2 * q + 1] += x.x * v[kk].y + x.y * v[kk].x;
+            acc[2 * q] = fma(x.x, v[kk].x, fma(-x.y, v[kk].y, acc[2 * q]));
+            acc[2 * q + 1] = fma(x.x, v[kk].y, fma(x.y, v[kk].x, acc[2 * q + 1]));
             if (cb > d) {  // conj(a) v_r
-              col[kk].x += x.x * vr.x + x.y * vr.y;
-              col[kk].y += x.x * vr.y - x.y * vr.x;
+              col[kk].x = fma(x.x, vr.x, fma(x.y, vr.y, col[kk].x));
+              col[kk].y = fma(x.x, vr.y, fma(-x.y, vr.x, col[kk].y));
             }
           }
         }

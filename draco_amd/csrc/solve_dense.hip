@@ -290,7 +290,12 @@ constexpr size_t kTargetWs = (size_t)6 << 30, kTargetWsMl = (size_t)20 << 30;
 int64_t workspace_bytes(const dmm_plan* pl, int aux_slots) {
   if (!pl) return 0;
   const Layout L = layout_of(pl, aux_slots);
-  size_t nmat = (aux_slots >= 2 ? kTargetWsMl : kTargetWs) / (L.per_mat + L.per_mat_extra);
+  size_t target = aux_slots >= 2 ? kTargetWsMl : kTargetWs;
+  // the caller may offer more (or less): "ml_workspace_mib" / "wiener_workspace_mib" (dmm_ctx_set_option).  The eigen
+  // pass pays a fixed cost per Householder column and launch -- the more matrices share it, the better
+  const int64_t opt = aux_slots >= 2 ? pl->ctx->opt_ml_ws_mib : pl->ctx->opt_wiener_ws_mib;
+  if (opt > 0) target = (size_t)opt << 20;
+  size_t nmat = target / (L.per_mat + L.per_mat_extra);
   if (nmat < 1) nmat = 1;
   if (nmat > (size_t)pl->ntile) nmat = pl->ntile > 0 ? pl->ntile : 1;
   return (int64_t)(L.header + nmat * (L.per_mat + L.per_mat_extra) + 1024);

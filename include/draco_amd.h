@@ -74,7 +74,9 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * "ml_shortcut" (0 = on; 2 = always eigen-decompose; 3 = telescope-side systems only),
  * "ml_eigen" (eigen path of the ML solve: 0 = chosen by batch size; 4 = Householder tridiagonalisation + QL kept
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give
- * up on every other matrix, which exercises the Jacobi fallback) */
+ * up on every other matrix, which exercises the Jacobi fallback),
+ * "ml_workspace_mib" / "wiener_workspace_mib" (size dmm_ml_workspace_bytes / dmm_wiener_workspace_bytes report,
+ * i.e. the matrices solved per sub-batch; 0 = 20 GiB / 6 GiB) */
 int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
 /* diagnostics counters, cumulative per context: "ml_tiles_direct" (tiles whose pseudo-inverse was
  * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed) */
