@@ -307,6 +307,7 @@ class SolveEngine:
                     e1.record()
                     self.launch_events.append((e0, e1, slab.b_bytes, slab.ntile))
             elif kind == "wiener":
+                self._offer_workspace(b"wiener_workspace_mib", 24 << 10)  # 0.0649 -> 0.0620 ms per cfg-3 solve against 6 GiB
                 ws = torch.empty(max(int(lib.dmm_wiener_workspace_bytes(slab.plan)), 16), dtype=torch.uint8, device=self.ctx.device)
                 _lib.check(
                     lib.dmm_wiener_run(
