@@ -551,6 +551,16 @@ def extras(args, cfg, job):
                 ctx.sync()
                 t_w = time.perf_counter() - t0
             extra[f"{kind}_ms_per_solve"] = t_w * 1e3 / (nf_w * (lmax + 1))
+            if kind == "wiener":
+                # FP64 flops of the sample: Hermitian Gram of the smaller side 8 k^2 K / 2 + Cholesky (8/3) k^3
+                ntel_ = 2 * tel.npairs
+                fl = 0.0
+                for m_ in range(lmax + 1):
+                    nsky_ = 4 * (lmax + 1 - m_)
+                    k_, K_ = min(ntel_, nsky_), max(ntel_, nsky_)
+                    fl += 4.0 * k_ * k_ * K_ + (8.0 / 3.0) * k_**3
+                extra["wiener_mfma"] = {"achieved": fl * nf_w / t_w / 1e12, "peak": 78.6, "unit": "TFLOP/s (FP64 MFMA, whole solve incl. factorisation and triangular solves)",
+                                        "frac": fl * nf_w / t_w / 1e12 / 78.6}
         extra["dense_sample"] = f"all {lmax + 1} m of {nf_w} frequencies, B resident"
         del eng2, mv1, mw1, vis1, w1
         _solve.release_pools()
