@@ -105,6 +105,38 @@ def test_vs_oracle_float64_inputs(nm, oddra, nel, new):
             assert err < 1e-11, (type(task).__name__, err)
 
 
+@pytest.mark.parametrize("nm,oddra,nel,new,npol,nfreq", [(33, False, 7, 3, 1, 1), (17, True, 65, 2, 1, 3), (9, False, 3, 40, 1, 1), (65, True, 129, 4, 2, 1)])
+def test_vs_oracle_without_dirty_beam_output(nm, oddra, nel, new, npol, nfreq):
+    """The default path (RA-space dirty beam not kept): two rows share one inverse FFT and the dirty-beam power comes from
+    the modes by Parseval.  Odd row counts (a transform with a lone row), elevation counts that are not multiples of the
+    tile, more than 64 (sign, EW) terms (the weights are handed round the wave in two rounds), every weight scheme."""
+    from draco_amd.analysis.ringmapmaker import TikhonovRingMapMaker, WienerRingMapMaker
+
+    rng = np.random.default_rng(nm * 7 + nel)
+    freq = np.linspace(500.0, 700.0, nfreq)
+    ew = 22.0 * np.arange(new)
+    el = np.linspace(-0.9, 0.9, nel)
+    shp = (nm, 2, npol, nfreq, new, nel)
+    hv = (rng.standard_normal(shp) + 1j * rng.standard_normal(shp)).astype(np.complex64)
+    bv = (rng.standard_normal(shp) + 1j * rng.standard_normal(shp)).astype(np.complex64)
+    hw = rng.uniform(0.5, 1.5, shp[:-1]).astype(np.float32)
+    hw[rng.uniform(size=hw.shape) < 0.1] = 0
+    v, b = _containers(hv, hw, bv, freq, ew, el, oddra)
+    args = dict(hv=hv.astype(np.complex128), hw=hw.astype(np.float64), bv=bv.astype(np.complex128), freq=freq, el=el, ew=ew, oddra=oddra)
+    for task, okw in (
+        (TikhonovRingMapMaker(weight_ew="inverse_variance", inv_SN=1e-2), dict(kind="tikhonov", weight_ew="inverse_variance", inv_SN=1e-2)),
+        (TikhonovRingMapMaker(weight_ew="uniform", inv_SN=1e-3), dict(kind="tikhonov", weight_ew="uniform", inv_SN=1e-3)),
+        (WienerRingMapMaker(), dict(kind="wiener")),
+        (TikhonovRingMapMaker(weight_ew="natural", inv_SN=1e-4, skip_deconvolution=True), dict(kind="tikhonov", weight_ew="natural", inv_SN=1e-4, skip_deconvolution=True)),
+    ):
+        task.setup()
+        rm = task.process(v, b)
+        rmm, rmw, rmbp, _ = orm.deconvolve(**args, **okw)
+        for ds, ref in ((rm.map, rmm), (rm.weight, rmw), (rm.dirty_beam_power, rmbp)):
+            err = np.abs(ds[:] - ref).max() / np.abs(ref).max()
+            assert err < 1e-11, (type(task).__name__, err)
+
+
 def test_validation_errors():
     from draco_amd.analysis.ringmapmaker import TikhonovRingMapMaker
 
