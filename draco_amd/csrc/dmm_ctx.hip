@@ -88,6 +88,7 @@ int dmm_ctx_destroy(dmm_ctx* c) {
   for (hipEvent_t e : c->aux_ev)
     if (e) (void)hipEventDestroy(e);
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+  if (c->aux_stream_b) (void)hipStreamDestroy(c->aux_stream_b);
   if (c->aux_pinned) (void)hipHostFree(c->aux_pinned);
   delete c;
   return DMM_OK;
@@ -128,7 +129,8 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
 int dmm_ctx_sync(dmm_ctx* c) {
   DMM_REQUIRE(c != nullptr, "dmm_ctx_sync: ctx is NULL");
   DMM_HIP(hipStreamSynchronize(c->stream));
-  if (c->aux_stream) DMM_HIP(hipStreamSynchronize(c->aux_stream));  // both streams: host-side reuse of any buffer is safe
+  if (c->aux_stream) DMM_HIP(hipStreamSynchronize(c->aux_stream));  // every stream: host-side reuse of any buffer is safe
+  if (c->aux_stream_b) DMM_HIP(hipStreamSynchronize(c->aux_stream_b));
   return DMM_OK;
 }
 

@@ -21,6 +21,7 @@ struct dmm_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t aux_stream = nullptr;        // library-owned second stream (ML eigen path: QL of one half-batch under the reduction of the next)
+  hipStream_t aux_stream_b = nullptr;      // and a third: the QL launches of the two chunk slots are latency bound and run side by side
   hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int* aux_pinned = nullptr;               // pinned host words for flags read back on the second stream
   size_t aux_pinned_n = 0;
@@ -78,6 +79,7 @@ struct dmm_aux_scope {
   dmm_aux_scope& operator=(const dmm_aux_scope&) = delete;
   ~dmm_aux_scope() {
     if (c && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c && c->aux_stream_b) (void)hipStreamSynchronize(c->aux_stream_b);
   }
 };
 

@@ -541,9 +541,22 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   // eigen path runs on well filled batches at the end
   std::vector<int64_t> tel_deferred;
   std::map<int, std::vector<int64_t>> sky_deferred;
-  auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky, bool eigen_only) -> int {
+  // `off`: first matrix slot of the workspace this batch may use (0, or capE = the second half while the first half
+  // still belongs to an eigen chunk in flight on the second stream)
+  auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky, bool eigen_only, int off = 0) -> int {
+    double2* const Vb = Vbuf + (size_t)off * 2 * L.Np * L.Np;
+    double2* const Wb = Whbuf + (size_t)off * (L.Np / 64) * TB * TB;
+    dmm_tile* const tiles_b = tiles_d + off;
+    int32_t* const work_b = work_d + off + (off ? 1 : 0);  // (nmat + 1 entries per user: the halves stay disjoint)
+    int* const flag_b = flag_d + (size_t)off * (L.Np / 64);
+    double* const scale_b = scale_d + off;
+    double* const theta_b = theta_d + off;
+    int* const fail_b = fail_d + off;
+    int* const msel_b = msel_d + off;
     DenseParams p = base;
-    p.tiles = tiles_d;
+    p.A = base.A + (size_t)off * L.Np * L.Np;
+    p.wbuf = base.wbuf + (size_t)off * L.N;
+    p.tiles = tiles_b;
     p.tile0 = 0;
     p.nmat = nmat;
     p.sky = sky ? 1 : 0;
@@ -551,7 +564,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     p.Np = (p.N + TB - 1) / TB * TB;
     p.T = p.Np / TB;
     p.alm = (double2*)alm;
-    p.theta = theta_d;
+    p.theta = theta_b;
     // the batch's tiles (and, telescope side, the column-block prefix of the back-projection)
     tiles_c.resize(nmat);
     work_c.assign(nmat + 1, 0);
@@ -560,17 +573,17 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       const int ncol = pl->npol * (pl->lmax + 1 - tiles_c[i].m);
       work_c[i + 1] = work_c[i] + (ncol + pl->cols_per_block - 1) / pl->cols_per_block;
     }
-    DMM_HIP(hipMemcpyAsync(tiles_d, tiles_c.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, ctx->stream));
-    DMM_HIP(hipMemcpyAsync(work_d, work_c.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    DMM_HIP(hipMemcpyAsync(tiles_b, tiles_c.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, ctx->stream));
+    DMM_HIP(hipMemcpyAsync(work_b, work_c.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     DMM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors are reused by the next batch
     const int T = p.T;
     if (sky) {
       p.ldx = ntel;
-      p.X = Vbuf;
+      p.X = Vb;
     }
     auto form_gram = [&]() {
       if (sky) {
-        hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf);
+        hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
       } else {
         hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
@@ -582,11 +595,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     fail_h.assign(nmat, 1);
     if (shortcut && !eigen_only) {
       hipLaunchKernelGGL(k_rowsum, dim3(nmat), dim3(kThreads), 0, ctx->stream, p);
-      DMM_HIP(hipMemsetAsync(fail_d, 0, nmat * sizeof(int), ctx->stream));
+      DMM_HIP(hipMemsetAsync(fail_b, 0, nmat * sizeof(int), ctx->stream));
       DenseParams pc = p;  // factorisations run on a copy: A stays intact for the eigen path
-      pc.A = Vbuf;
-      pc.Linv = Whbuf;
-      pc.fail = fail_d;
+      pc.A = Vb;
+      pc.Linv = Wb;
+      pc.fail = fail_b;
       auto cholesky = [&]() {
         for (int J = 0; J < T; ++J) {
           pc.J = J;
@@ -596,14 +609,14 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         }
       };
       // certificate: G - tau I positive definite  <=>  no mode is cut
-      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf, 1, rcond * rcond, acond * acond);
+      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vb, 1, rcond * rcond, acond * acond);
       cholesky();
       // solve with G itself (certified tiles only write their result)
-      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vbuf, 0, 0.0, 0.0);
+      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vb, 0, 0.0, 0.0);
       cholesky();
       hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, pc);
       DMM_HIP(hipGetLastError());
-      DMM_HIP(hipMemcpyAsync(fail_h.data(), fail_d, nmat * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      DMM_HIP(hipMemcpyAsync(fail_h.data(), fail_b, nmat * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
     }
     msel_h.clear();
@@ -617,7 +630,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     ctx->ml_tiles_eigen += (int64_t)msel_h.size();
     if (!msel_h.empty()) {  // eigen-decomposition of the Gram matrices, reference's cut applied
       int nsel = (int)msel_h.size();
-      DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      DMM_HIP(hipMemcpyAsync(msel_b, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
       bool solved = false;
       // tridiagonalisation + QL in factored form (herm_tridiag.h) has a latency floor per launch (the serial QL
@@ -627,23 +640,23 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         const int n = p.Np;
         TdParams tp;
         tp.d = p;
-        tp.d.msel = msel_d;
-        tp.vec = Whbuf;
-        tp.log_cs = Vbuf;
+        tp.d.msel = msel_b;
+        tp.vec = Wb;
+        tp.log_cs = Vb;
         tp.log_stride = (int64_t)2 * L.Np * L.Np;
         const int runs = 16 * n;  // a chase per QL iteration: ~1.7 n in practice
         tp.run_cap = ctx->opt_ml_eigen == 3 ? -runs : runs;  // negative: every other matrix is made to give up (tests)
         tp.log_cap = (int)std::min<int64_t>(tp.log_stride - ((int64_t)3 * runs * sizeof(int) + 15) / 16, 0x7fffffff);
         tp.acond = acond;
         tp.rcond = rcond;
-        tp.fail = fail_d;
+        tp.fail = fail_b;
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
-        DMM_HIP(hipMemsetAsync(fail_d, 0, nsel * sizeof(int), ctx->stream));
+        DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
         td_reduce(tp, nsel, ctx->stream);
         td_solve(tp, nsel, ctx->stream);
         DMM_HIP(hipGetLastError());
         td_fail_h.assign(nsel, 0);
-        DMM_HIP(hipMemcpyAsync(td_fail_h.data(), fail_d, nsel * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DMM_HIP(hipMemcpyAsync(td_fail_h.data(), fail_b, nsel * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         DMM_HIP(hipStreamSynchronize(ctx->stream));
         // QL stalled or its log overflowed (not seen in practice): those matrices -- and only those, the others have
         // already replaced their right-hand side by the solution -- go through Jacobi on re-formed Gram matrices
@@ -654,7 +667,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         if (!solved) {
           msel_h = redo;
           nsel = (int)msel_h.size();
-          DMM_HIP(hipMemcpyAsync(msel_d, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+          DMM_HIP(hipMemcpyAsync(msel_b, msel_h.data(), nsel * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
           DMM_HIP(hipStreamSynchronize(ctx->stream));
           form_gram();
         }
@@ -664,17 +677,17 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       } else {
       JacobiParams jp;
       jp.d = p;
-      jp.d.msel = msel_d;
-      jp.V = Vbuf;
+      jp.d.msel = msel_b;
+      jp.V = Vb;
       jp.acond = acond;
       jp.rcond = rcond;
       jp.max_sweeps = max_sweeps;
       BjParams bp;
       bp.d = jp.d;
-      bp.V = Vbuf;
-      bp.Wh = Whbuf;
-      bp.flag = flag_d;
-      bp.scale = scale_d;
+      bp.V = Vb;
+      bp.Wh = Wb;
+      bp.flag = flag_b;
+      bp.scale = scale_b;
       bp.any_rot = any_rot_d;
       bp.inner_sweeps = inner_sweeps;
       bp.nb = p.Np / JB;
@@ -707,9 +720,9 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       }
     }
     if (!sky) {
-      int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_d, work_d, nmat, work_c[nmat], alm);
+      int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_b, work_b, nmat, work_c[nmat], alm);
       if (rc) return rc;
-      DMM_HIP(hipStreamSynchronize(ctx->stream));  // tiles_d / work_d are rewritten by the next batch
+      DMM_HIP(hipStreamSynchronize(ctx->stream));  // tiles_b / work_b are rewritten by the next batch
     }
     return DMM_OK;
   };
@@ -718,11 +731,15 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   // one half-batch run on the library's second stream (one wave per matrix, a latency floor that leaves the GPU
   // empty), the Gram matrices and the HBM-bound reduction of the next half-batch run on the caller's stream.
   const int capE = cap / 2;
+  // where chunk slot h starts and how many matrices it holds.  Normally the two halves; while direct (certificate)
+  // batches are still running the chunks of early-known rejects use two small slots at the END of the workspace instead
+  // and the batches keep the front (see the shortcut branch below).
+  int slot_off[2] = {0, capE}, slot_cap[2] = {capE, capE};
   struct Half {
     std::vector<dmm_tile> tiles;
     std::vector<int32_t> work;
     std::vector<int64_t> ids;
-    int nmat = 0;
+    int nmat = 0, off = 0;
     bool busy = false;
   } half[2];
   std::vector<int64_t> redo_tel;
@@ -731,13 +748,14 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   int redo_np[2] = {0, 0};
   auto pipe_ready = [&]() -> int {
     if (!ctx->aux_stream) DMM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux_stream_b) DMM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream_b, hipStreamNonBlocking));
     for (hipEvent_t& e : ctx->aux_ev)
       if (!e) DMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (ctx->aux_pinned_n < (size_t)2 * capE) {
+    if (ctx->aux_pinned_n < (size_t)cap + 1) {
       if (ctx->aux_pinned) DMM_HIP(hipHostFree(ctx->aux_pinned));
       ctx->aux_pinned = nullptr;
-      DMM_HIP(hipHostMalloc((void**)&ctx->aux_pinned, (size_t)2 * capE * sizeof(int), hipHostMallocDefault));
-      ctx->aux_pinned_n = (size_t)2 * capE;
+      DMM_HIP(hipHostMalloc((void**)&ctx->aux_pinned, ((size_t)cap + 1) * sizeof(int), hipHostMallocDefault));
+      ctx->aux_pinned_n = (size_t)cap + 1;
     }
     return DMM_OK;
   };
@@ -745,7 +763,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     Half& H = half[h];
     if (!H.busy) return DMM_OK;
     DMM_HIP(hipEventSynchronize(ctx->aux_ev[2 + h]));
-    const int* fl = ctx->aux_pinned + (size_t)h * capE;
+    const int* fl = ctx->aux_pinned + (size_t)H.off;
     for (int k = 0; k < H.nmat; ++k)
       if (fl[k]) (redo_is_sky[h] ? redo_sky[redo_np[h]] : redo_tel).push_back(H.ids[k]);
     H.busy = false;
@@ -755,8 +773,9 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     int rc = retire(h);
     if (rc) return rc;
     Half& H = half[h];
-    const size_t off = (size_t)h * capE;
-    hipStream_t S1 = ctx->stream, S2 = ctx->aux_stream;
+    const size_t off = (size_t)slot_off[h];
+    H.off = (int)off;
+    hipStream_t S1 = ctx->stream, S2 = h ? ctx->aux_stream_b : ctx->aux_stream;  // one stream per slot: the two QL launches overlap
     DenseParams p = base;
     p.A = base.A + off * L.Np * L.Np;
     p.wbuf = base.wbuf + off * L.N;
@@ -849,9 +868,12 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     }
     int rc = pipe_ready();
     if (rc) return rc;
-    for (size_t i0 = 0; i0 < list.size(); i0 += capE, ++chunk_no) {
-      rc = launch_chunk(chunk_no & 1, list, i0, (int)std::min<size_t>(capE, list.size() - i0), sky, np_sky);
+    for (size_t i0 = 0; i0 < list.size(); ++chunk_no) {
+      const int h = chunk_no & 1;
+      const int nm = (int)std::min<size_t>(slot_cap[h], list.size() - i0);
+      rc = launch_chunk(h, list, i0, nm, sky, np_sky);
       if (rc) return rc;
+      i0 += nm;
     }
     return DMM_OK;
   };
@@ -888,28 +910,85 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   // Certificate first; rejected tiles are deferred.  Trying the certificate costs a Gram matrix and two
   // factorisations per tile (about a fifth of a decomposition): where almost nothing passes -- ill-conditioned beam
   // transfers -- the batches go to the eigen pass directly, and every eighth batch probes again.
+  // (break-even: a certificate attempt costs ~0.10 ms per tile, a decomposition ~0.44: worth trying above ~0.25)
   double pass_rate = 1.0;
   int batch_no = 0;
-  auto certify = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky) -> int {
-    if (pass_rate < 0.2 && (++batch_no & 7) != 0) {
+  auto certify = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky, int off) -> int {
+    if (pass_rate < 0.3 && (++batch_no & 7) != 0) {
       std::vector<int64_t>& d = sky ? sky_deferred[np_sky] : tel_deferred;
       d.insert(d.end(), list.begin() + i0, list.begin() + i0 + nmat);
       return DMM_OK;
     }
     const int64_t before = ctx->ml_tiles_direct;
-    int rc = run_batch(list, i0, nmat, sky, np_sky, false);
+    int rc = run_batch(list, i0, nmat, sky, np_sky, false, off);
     pass_rate = (double)(ctx->ml_tiles_direct - before) / (double)nmat;
     return rc;
   };
-  for (size_t i0 = 0; i0 < tel_list.size(); i0 += cap) {
-    int rc = certify(tel_list, i0, (int)std::min<size_t>(cap, tel_list.size() - i0), false, 0);
-    if (rc) return rc;
+  // Rejects that are known while direct batches remain are decomposed EARLY, on two small chunk slots at the end of the
+  // workspace: Gram matrices and reduction on this stream, then the serial QL (a ~0.1 s latency floor whatever the
+  // count) on the slot's own stream, under the direct batches that follow in the front of the workspace.  Left to the
+  // end, as before, that floor had nothing to hide behind: a fifth of the whole ML pass for the forty-odd near-square
+  // tiles of a well-conditioned cfg-3 slab.  To know the rejects early the near-square tiles go FIRST: the sky-side orders
+  // from the largest down (their rejects to slot 1), then the telescope-side tiles by descending m (slot 0).
+  const int E = std::min(128, cap / 8);
+  int cap_direct = cap;
+  if (E >= 8) {
+    cap_direct = cap - 2 * E;
+    slot_off[0] = cap_direct;
+    slot_off[1] = cap_direct + E;
+    slot_cap[0] = slot_cap[1] = E;
   }
-  for (auto& kv : sky_lists)
-    for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
-      int rc = certify(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first);
+  bool early_used[2] = {false, false};
+  // launch a reject list in `slot` if that slot is free right now (never waits)
+  auto early = [&](std::vector<int64_t>& list, bool sky, int np_sky, int slot) -> int {
+    const int np = ((sky ? np_sky : ntel) + TB - 1) / TB * TB;
+    // (a list that does not fit one slot is the ill-conditioned regime: it belongs to the full-size pipeline at the end)
+    // and ONE early chunk per slot: a trickle of small chunks would each pay the per-column launch chain and the QL floor
+    if (cap_direct == cap || early_used[slot] || list.empty() || (int)list.size() > E || ctx->opt_ml_eigen != 0 || (double)list.size() * np < 12000.0) return DMM_OK;
+    early_used[slot] = true;
+    if (half[slot].busy) {
+      if (hipEventQuery(ctx->aux_ev[2 + slot]) != hipSuccess) return DMM_OK;  // its QL is still running: next time
+      int rc = retire(slot);
       if (rc) return rc;
     }
+    if ((chunk_no & 1) != slot) ++chunk_no;
+    int rc = eigen_list(list, sky, np_sky);  // one chunk, in slot `slot`
+    list.clear();
+    return rc;
+  };
+  for (auto it = sky_lists.rbegin(); it != sky_lists.rend(); ++it) {
+    const std::vector<int64_t>& list = it->second;
+    for (size_t i0 = 0; i0 < list.size(); i0 += cap_direct) {
+      int rc = certify(list, i0, (int)std::min<size_t>(cap_direct, list.size() - i0), true, it->first, 0);
+      if (rc) return rc;
+    }
+    if (!sky_deferred.empty() && (std::next(it) != sky_lists.rend() || !tel_list.empty())) {  // rejects of the orders so far (while direct work remains), decomposed together at the largest of their orders
+      std::vector<int64_t> all;
+      for (auto& kv : sky_deferred) all.insert(all.end(), kv.second.begin(), kv.second.end());
+      const int np_max = sky_deferred.rbegin()->first;
+      const size_t before = all.size();
+      int rc = early(all, true, np_max, 1);
+      if (rc) return rc;
+      if (all.size() != before) sky_deferred.clear();  // launched (all of it: a list goes whole or not at all); otherwise the
+                                                       // tiles stay filed under their own orders
+    }
+  }
+  // telescope side: the near-square tiles (high m) first, so that the rejects are known after the first batch and their
+  // chunk runs under the remaining batches
+  std::stable_sort(tel_list.begin(), tel_list.end(), [&](int64_t a, int64_t b) { return pl->tiles_h[a].m > pl->tiles_h[b].m; });
+  for (size_t i0 = 0; i0 < tel_list.size(); i0 += cap_direct) {
+    int rc = certify(tel_list, i0, (int)std::min<size_t>(cap_direct, tel_list.size() - i0), false, 0, 0);
+    if (!rc && i0 + cap_direct < tel_list.size()) rc = early(tel_deferred, false, 0, 0);  // (only while batches remain)
+    if (rc) return rc;
+  }
+  if (cap_direct < cap) {  // back to the two halves for whatever is left: nothing of the early chunks may still be in them
+    int rc = retire(0);
+    if (!rc) rc = retire(1);
+    if (rc) return rc;
+    slot_off[0] = 0;
+    slot_off[1] = capE;
+    slot_cap[0] = slot_cap[1] = capE;
+  }
   // A handful of rejected sky-side tiles spread over many padded orders would pay one launch chain (and its latency
   // floor) per order: they are decomposed together at the largest of their orders instead (order_of() keeps every
   // tile's own size; the padding is zeros).

@@ -1,25 +1,37 @@
-import csv, glob, sys
+#!/usr/bin/env python
+"""Timeline digest of an ML run traced with `rocprofv3 --kernel-trace --output-format csv`: where the serial QL
+launches (k_td_solve, second stream) sit relative to the rest of the pass.
+
+    python tools/ml_trace.py <rocprof output dir>
+"""
+import csv
+import glob
+import sys
+
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-sel = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Stream_Id", r.get("Queue_Id", "")), r["Grid_Size_X"] if "Grid_Size_X" in r else "") for r in rows]
-t0 = sel[0][1]
-# find eigen-pass region: first k_td_col
-tri = [(n, s, e, q, g) for n, s, e, q, g in sel if "k_td_trail_tri<3, 0" in n or "k_td_trail_tri<3, 4" in n or "k_td_solve" in n or "k_td_col" in n]
-print("n td kernels", len(tri))
-first_col = next(i for i, x in enumerate(tri) if "k_td_col" in x[0])
-# print the first 12 and, later, launches around the middle of 2nd half batch
-def show(lst):
-    for n, s, e, q, g in lst:
-        print(f"{(s-t0)/1e6:10.3f} ms  dur {(e-s)/1e3:9.1f} us  q={q} grid={g}  {n[:40]}")
-show(tri[first_col:first_col+14])
-print("...")
-# second half-batch start: find second occurrence where grid of tri<3,0 jumps back up
-big = [i for i, x in enumerate(tri) if "trail_tri<3, 0" in x[0] and (x[2]-x[1]) > 400e3]
-print("big read-only sweeps (>400us):", len(big))
-for i in big[:6] + big[-6:]:
-    n, s, e, q, g = tri[i]
-    print(f"{(s-t0)/1e6:10.3f} ms  dur {(e-s)/1e3:9.1f} us  q={q} grid={g}")
-sol = [x for x in tri if "k_td_solve" in x[0]]
-for n, s, e, q, g in sol[:8]:
-    print(f"solve {(s-t0)/1e6:10.3f} .. {(e-t0)/1e6:10.3f} ms q={q}")
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+ev = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "")) for r in rows]
+# the LAST pass of the run: from the last k_prior-less marker = last k_dirty<..., false, ...> (the sky-side right-hand sides) or first k_nt<0>
+starts = [i for i, e in enumerate(ev) if "k_rowsum" in e[0]]
+first = starts[len(starts) // 2] if starts else 0  # second half of the run = the timed pass
+t0 = ev[first][1]
+end = max(e[2] for e in ev[first:])
+print(f"pass length {(end - t0) / 1e6:.1f} ms")
+for n, s, e, q in ev[first:]:
+    if "k_td_solve" in n:
+        print(f"k_td_solve  {(s - t0) / 1e6:9.1f} .. {(e - t0) / 1e6:9.1f} ms  (queue {q})")
+busy = {}
+for n, s, e, q in ev[first:]:
+    busy.setdefault(q, []).append((s, e))
+for q, iv in busy.items():
+    tot = sum(e - s for s, e in iv)
+    print(f"queue {q}: {len(iv)} kernels, busy {tot / 1e6:.1f} ms, first {(min(s for s, _ in iv) - t0) / 1e6:.1f} last {(max(e for _, e in iv) - t0) / 1e6:.1f}")
+import collections
+tot = collections.Counter()
+cnt = collections.Counter()
+for n, s, e, q in ev[first:]:
+    key = n.split("(")[0][-40:] if "<" not in n else n[n.find("k_"):][:40]
+    tot[key] += e - s
+    cnt[key] += 1
+for k, v in tot.most_common(12):
+    print(f"{k:42} {cnt[k]:6d} {v / 1e6:9.1f} ms")
