@@ -41,6 +41,8 @@ struct DenseParams {
   const double2* mvis;
   const double* mweight;
   const double* Sl;        // [lmax+1] prior per l, or nullptr (S = 1)
+  const double* Sk;        // [lmax+1][sk_pitch] the same prior expanded per packed column k = pol*L + lrel of every m
+  int sk_pitch;            //   (zero beyond npol*L; rows 32-byte aligned), or nullptr: only Sl is used
   int add_identity;
   // storage
   double2* A;              // [nmat][Np][Np]
@@ -70,83 +72,36 @@ __device__ __forceinline__ int order_of(const DenseParams& p, const dmm_tile& t)
 }
 
 // Staging of rows [row0, row0+64) x complex columns [k0, k0+KC) of an operand, split in two so the
-// global loads of chunk k+1 fly under the MFMAs of chunk k: fetch() -> 4 complex values per thread in
+// global loads of chunk k+1 fly under the MFMAs of chunk k: fetch -> 4 complex values per thread in
 // registers, commit() -> LDS as doubles [64][LP] (re, im interleaved).
-// SRC: 0 = beam tile (gram), 1 = matrix A, 2 = Linv block.
-template <int SRC>
-__device__ __forceinline__ void fetch(double2 (&v)[CPT], const DenseParams& p, const dmm_tile& tile, int mat, int row0,
-                                      int k0, int K, bool scale_s) {
+//
+// General form of the beam-tile operand (any layout, any K): predicated element by element.  The Gram kernel uses it
+// only for full-layout B or npol*L not a multiple of 4; everything else goes through the lean staging inside k_nt.
+__device__ __forceinline__ void fetch_beam_general(double2 (&v)[CPT], const DenseParams& p, const dmm_tile& tile, int row0,
+                                                   int k0, int K, bool scale_s) {
   const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
   const int row = row0 + r;
-  if (SRC == 0) {
-    const int L = p.lmax + 1 - tile.m;
-    int k = k0 + c0;
-    if (!p.full_layout && (K & 3) == 0) {
-      // fast path (packed tiles, npol*L a multiple of 4): the row is contiguous in k and the thread's columns
-      // are inside or outside in groups of four -> 16-byte loads, one predicate per group
-      const bool rin = row < p.N;
-      if (p.b_c128) {
-        const double2* src = reinterpret_cast<const double2*>(p.B) + tile.b_off + (int64_t)row * K + k;
+  const int L = p.lmax + 1 - tile.m;
+  int k = k0 + c0;
+  const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+  const int64_t rbase = tile.b_off + (int64_t)row * p.npol * pol_stride + (p.full_layout ? tile.m : 0);
+  int pol = 0;  // pol = k / L without a division (npol is tiny)
+  for (int q = 1; q < p.npol; ++q) pol += (k >= q * L);
+  int lrel = k - pol * L;
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) v[c] = (rin && k + (c & ~3) < K) ? src[c] : make_double2(0.0, 0.0);
-      } else {  // complex64 storage: two values per 16-byte load (tiles start 16-byte aligned, k is a multiple of 4)
-        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(p.B) + tile.b_off + (int64_t)row * K + k);
-#pragma unroll
-        for (int c = 0; c < CPT; c += 2) {
-          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (rin && k + (c & ~3) < K) x = src[c >> 1];
-          v[c] = make_double2((double)x.x, (double)x.y);
-          v[c + 1] = make_double2((double)x.z, (double)x.w);
-        }
-      }
-      if (scale_s && p.Sl && rin) {
-        int lrel = k % L;
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-          const double sc = k + c < K ? p.Sl[tile.m + lrel] : 0.0;
-          v[c].x *= sc;
-          v[c].y *= sc;
-          if (++lrel == L) lrel = 0;
-        }
-      }
-    } else {
-      const int pol_stride = p.full_layout ? p.lmax + 1 : L;
-      const int64_t rbase = tile.b_off + (int64_t)row * p.npol * pol_stride + (p.full_layout ? tile.m : 0);
-      int pol = 0;  // pol = k / L without a division (npol is tiny)
-      for (int q = 1; q < p.npol; ++q) pol += (k >= q * L);
-      int lrel = k - pol * L;
-#pragma unroll
-      for (int c = 0; c < CPT; ++c, ++k) {
-        v[c] = make_double2(0.0, 0.0);
-        if (row < p.N && k < K) {
-          v[c] = load_bc(p.B, p.b_c128, rbase + (int64_t)pol * pol_stride + lrel);
-          if (scale_s && p.Sl) {
-            const double sc = p.Sl[tile.m + lrel];
-            v[c].x *= sc;
-            v[c].y *= sc;
-          }
-        }
-        if (++lrel == L) {
-          lrel = 0;
-          ++pol;
-        }
+  for (int c = 0; c < CPT; ++c, ++k) {
+    v[c] = make_double2(0.0, 0.0);
+    if (row < p.N && k < K) {
+      v[c] = load_bc(p.B, p.b_c128, rbase + (int64_t)pol * pol_stride + lrel);
+      if (scale_s && p.Sl) {
+        const double sc = p.Sl[tile.m + lrel];
+        v[c].x *= sc;
+        v[c].y *= sc;
       }
     }
-  } else if (SRC == 1) {
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      const int k = k0 + c0 + c;
-      v[c] = k < K ? p.A[((int64_t)mat * p.Np + row) * p.Np + k] : make_double2(0.0, 0.0);
-    }
-  } else if (SRC == 2) {
-#pragma unroll
-    for (int c = 0; c < CPT; ++c)
-      v[c] = p.Linv[(((int64_t)mat * p.T + p.J) * TB + (row - row0)) * TB + k0 + c0 + c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      const int k = k0 + c0 + c;
-      v[c] = (row < order_of(p, tile) && k < K) ? p.X[((int64_t)mat * p.Np + row) * p.ldx + k] : make_double2(0.0, 0.0);
+    if (++lrel == L) {
+      lrel = 0;
+      ++pol;
     }
   }
 }
@@ -161,6 +116,14 @@ __device__ __forceinline__ void commit(double* lds, const double2 (&v)[CPT]) {
 }
 
 // One 64x64 complex output tile C(I,J) per block; 4 waves, each a 32x32 quadrant = 2x2 MFMA tiles.
+//
+// The matrix pipe is shared with the vector ALU on this chip: every vector instruction between two MFMAs is MFMA time
+// lost (measured: pipe busy 0.63 at 4.8 other vector instructions per MFMA, 0.76 at 2.9).  So the staging of the hot
+// forms is kept to loads and stores: every thread owns one row pointer per operand, set up once -- rows beyond the
+// matrix are CLAMPED to its last row instead of predicated (their products are zeroed in the epilogue: d = 0 for the
+// beam Gram, explicitly for the staged Gram), full chunks are read without any predicate, only the last partial chunk
+// is checked element by element; the prior S_l arrives as a table already expanded per column (DenseParams::Sk), and
+// the sign of the imaginary-part operand is one XOR with a per-lane mask.
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
   __shared__ __align__(16) double xs[TB * LP];
@@ -186,11 +149,15 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
                 : MODE == MODE_GRAMX ? 2 * p.npairs
                 : MODE == MODE_UPDATE ? p.J * TB
                                       : TB;
-  const int kbase = MODE == MODE_PANEL ? J0 : 0;  // panel: X = A(I, J-block columns)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  // quadrant of this wave, rotated from block to block: see `dead` -- the idle wave must not always sit on the same SIMD
+  const int quad = (wave + blockIdx.x + blockIdx.y) & 3;
+  const int wr = quad >> 1, wc = quad & 1;
   const int lr = lane & 15, lk = lane >> 4;
+  // a diagonal tile is Hermitian: nobody reads its upper-right quadrant (the Cholesky kernels read the lower triangle,
+  // k_mirror rebuilds the upper one), so that wave only helps with the staging and leaves the pipe to the other blocks
+  const bool dead = bi == bj && wc > wr;
   v4d cre[2][2], cim[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -198,28 +165,9 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
     for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   double2 xr[CPT], yr[CPT];
-  auto fetch_chunk = [&](int k0) {
-    if (MODE == MODE_GRAM) {
-      fetch<0>(xr, p, tile, mat, I0, k0, K, false);
-      fetch<0>(yr, p, tile, mat, J0, k0, K, true);
-    } else if (MODE == MODE_GRAMX) {
-      fetch<3>(xr, p, tile, mat, I0, k0, K, false);
-      fetch<3>(yr, p, tile, mat, J0, k0, K, false);
-    } else if (MODE == MODE_UPDATE) {
-      fetch<1>(xr, p, tile, mat, I0, k0, K, false);
-      fetch<1>(yr, p, tile, mat, J0, k0, K, false);
-    } else {
-      fetch<1>(xr, p, tile, mat, I0, kbase + k0, kbase + K, false);
-      fetch<2>(yr, p, tile, mat, 0, k0, K, false);
-    }
-  };
-  if (K > 0) fetch_chunk(0);
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    __syncthreads();  // the previous chunk's MFMAs have read LDS
-    commit(xs, xr);
-    commit(ys, yr);
-    __syncthreads();
-    if (k0 + KC < K) fetch_chunk(k0 + KC);  // in flight under this chunk's MFMAs
+  auto mfma_chunk = [&]() {
+    if (dead) return;
+    const int sgn = (lk & 1) ? 0 : (int)0x80000000u;
 #pragma unroll
     for (int kk = 0; kk < 2 * KC; kk += 4) {
       double a[2], b[2], b2[2];
@@ -228,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
         a[t] = xs[(32 * wr + 16 * t + lr) * LP + kk + lk];
         b[t] = ys[(32 * wc + 16 * t + lr) * LP + kk + lk];
         const double o = ys[(32 * wc + 16 * t + lr) * LP + kk + (lk ^ 1)];
-        b2[t] = (lk & 1) ? o : -o;
+        b2[t] = __hiloint2double(__double2hiint(o) ^ sgn, __double2loint(o));  // (lk odd) ? o : -o
       }
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
@@ -238,9 +186,119 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
           cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b2[tj], cim[ti][tj], 0, 0, 0);
         }
     }
+  };
+  // fetch(k0): issue the loads of this thread's 4 columns of both operands for the chunk at k0; finish(): whatever has
+  // to be done to the loaded registers (conversion, prior scale) -- kept apart so that nothing waits for a load right
+  // after issuing it: the loads fly under the chunk's MFMAs and are first touched after the next barrier
+  auto pipeline = [&](auto&& fetch, auto&& finish) {
+    if (K > 0) fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+      __syncthreads();  // the previous chunk's MFMAs have read LDS
+      finish();
+      commit(xs, xr);
+      commit(ys, yr);
+      __syncthreads();
+      if (k0 + KC < K) fetch(k0 + KC);
+      mfma_chunk();
+    }
+  };
+
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * CPT;
+  if (MODE == MODE_GRAM && (p.full_layout || (K & 3) != 0)) {
+    pipeline(
+        [&](int k0) {
+          fetch_beam_general(xr, p, tile, I0, k0, K, false);
+          fetch_beam_general(yr, p, tile, J0, k0, K, true);
+        },
+        [&]() {});
+  } else if (MODE == MODE_GRAM && !p.b_c128) {
+    // packed complex64 tiles, rows 16-byte aligned: two values per load
+    const int rx = min(I0 + r, p.N - 1), ry = min(J0 + r, p.N - 1);
+    const float2* base = reinterpret_cast<const float2*>(p.B) + tile.b_off;
+    const float2* xp = base + (int64_t)rx * K + c0;
+    const float2* yp = base + (int64_t)ry * K + c0;
+    const double* sk = p.Sk ? p.Sk + (int64_t)tile.m * p.sk_pitch + c0 : nullptr;
+    float4 xraw[2], yraw[2];
+    double2 sraw[2];
+    bool in = true;
+    pipeline(
+        [&](int k0) {
+          in = k0 + c0 < K;  // (K a multiple of 4: the thread's four columns are inside or outside together)
+          const int ka = in ? k0 : 0;
+          xraw[0] = *reinterpret_cast<const float4*>(xp + ka);
+          xraw[1] = *reinterpret_cast<const float4*>(xp + ka + 2);
+          yraw[0] = *reinterpret_cast<const float4*>(yp + ka);
+          yraw[1] = *reinterpret_cast<const float4*>(yp + ka + 2);
+          if (sk) {
+            sraw[0] = *reinterpret_cast<const double2*>(sk + k0);
+            sraw[1] = *reinterpret_cast<const double2*>(sk + k0 + 2);
+          }
+        },
+        [&]() {
+          const double s0 = sk ? sraw[0].x : 1.0, s1 = sk ? sraw[0].y : 1.0, s2 = sk ? sraw[1].x : 1.0, s3 = sk ? sraw[1].y : 1.0;
+          const double z = in ? 1.0 : 0.0;  // (only ever 0 in the last, partial chunk)
+          xr[0] = make_double2(z * (double)xraw[0].x, z * (double)xraw[0].y);
+          xr[1] = make_double2(z * (double)xraw[0].z, z * (double)xraw[0].w);
+          xr[2] = make_double2(z * (double)xraw[1].x, z * (double)xraw[1].y);
+          xr[3] = make_double2(z * (double)xraw[1].z, z * (double)xraw[1].w);
+          yr[0] = make_double2(s0 * (double)yraw[0].x, s0 * (double)yraw[0].y);
+          yr[1] = make_double2(s1 * (double)yraw[0].z, s1 * (double)yraw[0].w);
+          yr[2] = make_double2(s2 * (double)yraw[1].x, s2 * (double)yraw[1].y);
+          yr[3] = make_double2(s3 * (double)yraw[1].z, s3 * (double)yraw[1].w);
+        });
+  } else {
+    // double-complex operands: the beam tile (packed), the matrix, its inverted diagonal block, the staged (D B)^H
+    const double2 *xp, *yp;
+    const double* sk = nullptr;
+    if (MODE == MODE_GRAM) {
+      const double2* base = reinterpret_cast<const double2*>(p.B) + tile.b_off;
+      xp = base + (int64_t)min(I0 + r, p.N - 1) * K + c0;
+      yp = base + (int64_t)min(J0 + r, p.N - 1) * K + c0;
+      if (p.Sk) sk = p.Sk + (int64_t)tile.m * p.sk_pitch + c0;
+    } else if (MODE == MODE_GRAMX) {
+      const int n = order_of(p, tile);
+      xp = p.X + ((int64_t)mat * p.Np + min(I0 + r, n - 1)) * p.ldx + c0;
+      yp = p.X + ((int64_t)mat * p.Np + min(J0 + r, n - 1)) * p.ldx + c0;
+    } else if (MODE == MODE_UPDATE) {
+      xp = p.A + ((int64_t)mat * p.Np + I0 + r) * p.Np + c0;
+      yp = p.A + ((int64_t)mat * p.Np + J0 + r) * p.Np + c0;
+    } else {  // panel: X = A(I, J-block columns), Y = Linv_J
+      xp = p.A + ((int64_t)mat * p.Np + I0 + r) * p.Np + J0 + c0;
+      yp = p.Linv + (((int64_t)mat * p.T + p.J) * TB + r) * TB + c0;
+    }
+    double2 sraw[2];
+    pipeline(
+        [&](int k0) {
+          if (MODE == MODE_UPDATE || MODE == MODE_PANEL || k0 + KC <= K) {  // (their K is a multiple of 64)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+              xr[c] = xp[k0 + c];
+              yr[c] = yp[k0 + c];
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+              const bool in = k0 + c0 + c < K;
+              xr[c] = in ? xp[k0 + c] : make_double2(0.0, 0.0);
+              yr[c] = in ? yp[k0 + c] : make_double2(0.0, 0.0);
+            }
+          }
+          if (MODE == MODE_GRAM && sk) {
+            sraw[0] = *reinterpret_cast<const double2*>(sk + k0);
+            sraw[1] = *reinterpret_cast<const double2*>(sk + k0 + 2);
+          }
+        },
+        [&]() {
+          if (MODE == MODE_GRAM && sk) {
+            yr[0].x *= sraw[0].x, yr[0].y *= sraw[0].x, yr[1].x *= sraw[0].y, yr[1].y *= sraw[0].y;
+            yr[2].x *= sraw[1].x, yr[2].y *= sraw[1].x, yr[3].x *= sraw[1].y, yr[3].y *= sraw[1].y;
+          }
+        });
   }
+  if (dead) return;
 
   // epilogue: lane holds rows (lk + 4*reg), column lr of each 16x16 tile
+  const int nx = MODE == MODE_GRAMX ? order_of(p, tile) : 0;
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -263,12 +321,14 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
           }
           re *= di * dj;
           im *= di * dj;
+          if (i >= p.N || j >= p.N) re = im = 0.0;  // (clamped rows carry copies of the last row, not zeros)
           if (i == j) {
             im = 0.0;  // Hermitian diagonal is real by construction; drop rounding dust
             if (p.add_identity) re += 1.0;  // padded rows (d = 0): unit diagonal for Cholesky, zero eigenvalue for ML
           }
           *dst = make_double2(re, im);
         } else if (MODE == MODE_GRAMX) {
+          if (i >= nx || j >= nx) re = im = 0.0;
           if (i == j) im = 0.0;
           *dst = make_double2(re, im);
         } else if (MODE == MODE_UPDATE) {

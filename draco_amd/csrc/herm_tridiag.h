@@ -561,13 +561,23 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     int nrot = 0, nrun = 0, fail = 0;
     const int run_cap = tp.run_cap >= 0 ? tp.run_cap : ((blockIdx.x & 1) ? 0 : -tp.run_cap);
     const double eps = 2.220446049250313e-16;
+    // A sub-diagonal is negligible relative to its two neighbours OR to the matrix (EISPACK tql2's test is of the second
+    // kind): inside a cluster of numerically zero eigenvalues -- a rank-deficient G, e.g. nsky < ntel or dead rows of
+    // B -- d and e are both rounding dust of the SAME size, the relative test alone never fires, QL runs into its
+    // iteration cap and the tile falls back to the Jacobi solver (8x slower).  The absolute floor costs nothing in
+    // accuracy: the reduction to tridiagonal form has already perturbed every eigenvalue by O(eps ||T||).
+    double anorm = 0.0;
+    for (int k = lane; k < n; k += 64) anorm = fmax(anorm, fabs(dl[k]) + fabs(el[k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) anorm = fmax(anorm, __shfl_xor(anorm, o));
+    const double tol_abs = eps * anorm;
     for (int l = 0; l < n && !fail; ++l) {
       int iter = 0;
       while (true) {
         int m = n - 1;  // first m >= l whose sub-diagonal is negligible
         for (int base = l; base < n - 1; base += 64) {
           const int k = base + lane;
-          const bool small = k < n - 1 && fabs(el[k]) <= eps * (fabs(dl[k]) + fabs(dl[k + 1]));
+          const bool small = k < n - 1 && fabs(el[k]) <= fmax(eps * (fabs(dl[k]) + fabs(dl[k + 1])), tol_abs);
           const unsigned long long mask = __ballot(small);
           if (mask) {
             m = base + __ffsll((long long)mask) - 1;

@@ -249,6 +249,12 @@ __global__ void k_prior(double* Sl, int lmax, double amp, double tilt) {
 }
 
 // Wiener, sky side: C^-1 = diag(1 / S_l) + B^H Ni B (mapmaker.py:267-270); padded rows get a unit diagonal
+// the prior per packed column of every m: Sk[m][k] = S_l(m + k mod L), L = lmax+1-m, zero beyond npol*L
+__global__ void k_prior_expand(const double* Sl, double* Sk, int lmax, int npol, int pitch) {
+  const int m = blockIdx.x, L = lmax + 1 - m, K = npol * L;
+  for (int k = threadIdx.x; k < pitch; k += blockDim.x) Sk[(int64_t)m * pitch + k] = k < K ? Sl[m + k % L] : 0.0;
+}
+
 __global__ void k_add_prior_diag(DenseParams p, const double* Sl) {
   const int mat = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.Np) return;
@@ -264,7 +270,9 @@ struct Layout {
   int N, Np, T;
   size_t per_mat;   // bytes per matrix (A + Linv/V + wbuf)
   size_t per_mat_extra;  // ML only: pair rotations W^H, flags, scale (kept behind the wbuf region)
-  size_t header;    // Sl table
+  size_t header;    // Sl table, then the table expanded per packed column (Wiener Gram)
+  size_t sl_bytes;  // offset of the expanded table inside the header
+  int sk_pitch;
 };
 
 // aux_slots: matrix-sized regions behind A: 1 = Wiener (X / Cholesky copy), 2 = ML (also the rotation log of the
@@ -279,7 +287,9 @@ Layout layout_of(const dmm_plan* pl, int aux_slots) {
   const size_t aux = ml ? (size_t)aux_slots * a : (size_t)L.T * TB * TB * sizeof(double2);
   L.per_mat = a + aux + (size_t)L.N * sizeof(double2);
   L.per_mat_extra = ml ? (size_t)(L.Np / 64) * TB * TB * sizeof(double2) + (size_t)(L.Np / 64) * sizeof(int) + 32 + 64 : 0;  // + theta, tile, work, fail, msel
-  L.header = ((size_t)(pl->lmax + 1) * sizeof(double) + 255) / 256 * 256;
+  L.sl_bytes = ((size_t)(pl->lmax + 1) * sizeof(double) + 255) / 256 * 256;
+  L.sk_pitch = (pl->npol * (pl->lmax + 1) + KC - 1) / KC * KC;
+  L.header = L.sl_bytes + ((size_t)(pl->lmax + 1) * L.sk_pitch * sizeof(double) + 255) / 256 * 256;
   return L;
 }
 
@@ -320,6 +330,8 @@ DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, cons
   p.mvis = (const double2*)mvis;
   p.mweight = mweight;
   p.Sl = nullptr;
+  p.Sk = nullptr;
+  p.sk_pitch = 0;
   p.add_identity = 0;
   unsigned char* q = ws + L.header;
   p.A = (double2*)q;
@@ -365,7 +377,9 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
   unsigned char* ws = (unsigned char*)workspace;
   double* Sl = (double*)ws;
+  double* Sk = (double*)(ws + L.sl_bytes);
   hipLaunchKernelGGL(k_prior, dim3(4), dim3(256), 0, ctx->stream, Sl, pl->lmax, prior_amp, prior_tilt);
+  hipLaunchKernelGGL(k_prior_expand, dim3(pl->lmax + 1), dim3(256), 0, ctx->stream, (const double*)Sl, Sk, pl->lmax, pl->npol, L.sk_pitch);
   const DenseParams base = make_params(pl, L, B, mvis, mweight, ws, cap);
   double2* const Xbuf = base.Linv;  // [cap] rows of (D B)^H for the sky-side Gram matrices
   unsigned char* extra = (unsigned char*)(base.wbuf + (size_t)cap * L.N);
@@ -427,6 +441,8 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
       hipLaunchKernelGGL(k_add_prior_diag, dim3((p.Np + 255) / 256, nmat), dim3(256), 0, ctx->stream, p, (const double*)Sl);
     } else {
       p.Sl = Sl;
+      p.Sk = Sk;
+      p.sk_pitch = L.sk_pitch;
       p.add_identity = 1;
       hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
     }
