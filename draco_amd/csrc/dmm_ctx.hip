@@ -122,6 +122,7 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   DMM_REQUIRE(c != nullptr && name != nullptr && value != nullptr, "dmm_ctx_get_counter: NULL argument");
   if (!strcmp(name, "ml_tiles_direct")) *value = c->ml_tiles_direct;
   else if (!strcmp(name, "ml_tiles_eigen")) *value = c->ml_tiles_eigen;
+  else if (!strcmp(name, "ml_tiles_ql_failed")) *value = c->ml_tiles_ql_failed;
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_get_counter: unknown counter '%s'", name);
   return DMM_OK;
 }

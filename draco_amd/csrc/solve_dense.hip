@@ -674,11 +674,12 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         td_fail_h.assign(nsel, 0);
         DMM_HIP(hipMemcpyAsync(td_fail_h.data(), fail_b, nsel * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         DMM_HIP(hipStreamSynchronize(ctx->stream));
-        // QL stalled or its log overflowed (not seen in practice): those matrices -- and only those, the others have
+        // QL stalled or its log overflowed (counted: "ml_tiles_ql_failed"): those matrices -- and only those, the others have
         // already replaced their right-hand side by the solution -- go through Jacobi on re-formed Gram matrices
         std::vector<int> redo;
         for (int k = 0; k < nsel; ++k)
           if (td_fail_h[k]) redo.push_back(msel_h[k]);
+        ctx->ml_tiles_ql_failed += (int64_t)redo.size();
         solved = redo.empty();
         if (!solved) {
           msel_h = redo;
@@ -781,7 +782,10 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipEventSynchronize(ctx->aux_ev[2 + h]));
     const int* fl = ctx->aux_pinned + (size_t)H.off;
     for (int k = 0; k < H.nmat; ++k)
-      if (fl[k]) (redo_is_sky[h] ? redo_sky[redo_np[h]] : redo_tel).push_back(H.ids[k]);
+      if (fl[k]) {
+        (redo_is_sky[h] ? redo_sky[redo_np[h]] : redo_tel).push_back(H.ids[k]);
+        ++ctx->ml_tiles_ql_failed;
+      }
     H.busy = false;
     return DMM_OK;
   };
@@ -898,7 +902,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     if (rc) return rc;
     rc = retire(1);
     if (rc) return rc;
-    // matrices whose QL gave up (not seen in practice): synchronous Jacobi batches
+    // matrices whose QL gave up (counted: "ml_tiles_ql_failed"): synchronous Jacobi batches
     const int saved = ctx->opt_ml_eigen;
     ctx->opt_ml_eigen = 1;
     for (size_t i0 = 0; i0 < redo_tel.size() && !rc; i0 += cap) {

@@ -463,3 +463,56 @@ def test_ml_ill_conditioned_tiles(variant):
     for m in range(lmax + 1):
         err = np.abs(out[..., m] - ref[..., m]).max() / np.abs(ref[..., m]).max()
         assert err < 1e-7, (m, err)
+
+
+def test_ml_rank_deficient_tiles_stay_on_the_tridiagonal_path():
+    """Beam transfers of rank ntel/2 (half of G's spectrum is a cluster of rounding-dust zeros: nsky < ntel, dead or
+    redundant baselines) against the oracle's SVD, every tile solved by the tridiagonal path itself.  (Small-order
+    companion of tests/test_gpu_fullsize.py::test_cfg3_ml_rank_deficient_telescope_side_stays_on_the_tridiagonal_path,
+    where clusters of hundreds of zeros made QL give up before its negligibility test got an absolute floor.)"""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import ArrayProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    nfreq, lmax = 1, 40
+    tel = _tel(nfreq, lmax, 2, 4)
+    npairs, ntel = tel.npairs, 2 * tel.npairs
+    rng = np.random.default_rng(78)
+    tiles = {}
+
+    def beam(m, f):
+        if m not in tiles:
+            nsky = 4 * (lmax + 1 - m)
+            k = max(1, min(ntel, nsky) // 2)
+            u, _ = np.linalg.qr(rng.standard_normal((ntel, k)) + 1j * rng.standard_normal((ntel, k)))
+            v, _ = np.linalg.qr(rng.standard_normal((nsky, k)) + 1j * rng.standard_normal((nsky, k)))
+            sig = np.linspace(1.0, 0.1, k)
+            b = np.zeros((2, npairs, 4, lmax + 1), dtype=np.complex128)
+            b[..., m:] = ((u * sig) @ v.conj().T).reshape(2, npairs, 4, lmax + 1 - m)
+            tiles[m] = b
+        return tiles[m]
+
+    bt = ArrayProvider(tel, beam)
+    shape = (lmax + 1, 2, nfreq, npairs)
+    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    mw = np.ones(shape)
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    ref = omm.solve_alm("ml", beam, mv, mw, lmax, tel.mmax, [0])
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 4))
+        e0, q0 = _counter(ctx, b"ml_tiles_eigen"), _counter(ctx, b"ml_tiles_ql_failed")
+        task = MaximumLikelihoodMapMaker()
+        task.setup(bt)
+        out = task.alm_square(task.make_alm(mm))
+        assert _counter(ctx, b"ml_tiles_eigen") - e0 == lmax + 1
+        assert _counter(ctx, b"ml_tiles_ql_failed") == q0
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
+    for m in range(lmax + 1):
+        err = np.abs(out[..., m] - ref[..., m]).max() / np.abs(ref[..., m]).max()
+        assert err < 1e-7, (m, err)

@@ -271,3 +271,47 @@ def test_ml_tridiagonal_path_at_other_orders(nfeed_cyl, np_expected):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
         assert np.all(np.isfinite(out[4]))
         assert _rel(out[4], out[1]) < 1e-9, (m, _rel(out[4], out[1]))
+
+
+def test_cfg3_ml_rank_deficient_telescope_side_stays_on_the_tridiagonal_path():
+    """One cfg-3 frequency with every system formed on the telescope side ("ml_shortcut" = 3): beyond m = 323 the order-758
+    Gram matrix has rank 4 (513 - m) < 758, i.e. up to 750 eigenvalues that are rounding dust.  QL must deflate inside
+    such a cluster (absolute floor of its negligibility test) instead of running into the iteration cap -- before, every
+    one of those tiles was redone by the Jacobi solver, 12x slower -- and the minimum-norm answer must agree with the
+    default route, which solves the same tiles on the sky side."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    tel = _tel(3, 1)
+    lmax = tel.lmax
+    bt = SyntheticProvider(tel, seed=32)
+    gen = torch.Generator(device=ctx.device).manual_seed(5)
+    shape = (lmax + 1, 2, 1, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) * 30.0 + 5.0
+    eng = SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED)
+
+    def counter(name):
+        import ctypes as C
+
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    ref = eng.solve("ml", mv, mw, [0], lmax).cpu().numpy()
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 3))
+        q0, e0 = counter(b"ml_tiles_ql_failed"), counter(b"ml_tiles_eigen")
+        out = eng.solve("ml", mv, mw, [0], lmax).cpu().numpy()
+        assert counter(b"ml_tiles_eigen") - e0 >= lmax - 323  # the rank-deficient tiles cannot pass the certificate
+        assert counter(b"ml_tiles_ql_failed") == q0
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+    assert np.all(np.isfinite(out))
+    for m in (0, 200, 330, 400, 480, 510):
+        assert _rel(out[..., m, :], ref[..., m, :]) < 1e-7, m
