@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void k_td_trail(TdParams tp) {
 // w, w+4, ... of the block's column range for ALL of its rows: the per-column operands and the transposed sums
 // stay in that wave's registers (no cross-wave reduction, this row block's partial vector is written straight from
 // them); the four waves' pieces of a row sum meet in LDS.
-template <int KK, int NP, int RI = (KK <= 3 && NP == 0 ? 4 : 2)>  // NP pending pairs applied by this sweep (0: read only); RI rows in flight
+template <int KK, int NP, int RI = (KK <= 3 ? 4 : 2)>  // NP pending pairs applied by this sweep (0: read only); RI rows in flight
 __global__ __launch_bounds__(kThreads) void k_td_trail_tri(TdParams tp) {
   constexpr int NPA = NP > 0 ? NP : 1;
   __shared__ double2 s_vp[NPA][kTdRows], s_wp[NPA][kTdRows], s_vr[kTdRows];
