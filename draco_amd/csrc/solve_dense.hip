@@ -921,9 +921,10 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   };
 
   if (!shortcut) {  // every tile through the eigen path
+    // largest systems first: the pass ends on the serial QL of its LAST chunk, which nothing is left to hide
     int rc = eigen_list(tel_list, false, 0);
-    for (auto& kv : sky_lists)
-      if (!rc) rc = eigen_list(kv.second, true, kv.first);
+    for (auto it = sky_lists.rbegin(); it != sky_lists.rend(); ++it)
+      if (!rc) rc = eigen_list(it->second, true, it->first);
     const int rc2 = drain();
     return rc ? rc : rc2;
   }
