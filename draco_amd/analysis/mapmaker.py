@@ -97,6 +97,7 @@ class BaseMapMaker(ContainerTask):
         ctx = Context.get()
         nside = int(self.nside)
         npix = 12 * nside**2
+        pending = None
         if user_hook or bt.telescope.num_pol_sky != 4:
             alm_d = self._host_loop(mmodes) if user_hook else self.make_alm(mmodes)
             nfreq, npol, n_m, nl = alm_d.shape
@@ -120,12 +121,21 @@ class BaseMapMaker(ContainerTask):
                 _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(out["maps"][f0:f1])))
 
             alm_d = self.make_alm(mmodes, on_freqs_done=sht_of)
-            side.join(main)
             maps = out.get("maps")
             if maps is None:  # no frequencies on this rank
                 maps = ctx.empty((alm_d.shape[0], 4, npix), np.float64)
+            else:
+                # the last slab's SHT is still running on the side stream.  Whoever reads the map is ordered behind
+                # it at that moment (Dataset's `pending`); work that does not -- the next day's transform and
+                # solves -- is not held up.  (`record_stream` guards the allocator meanwhile.)
+                done = torch.cuda.Event()
+                done.record(side.stream)
+                side.release_held()
+
+                def pending(dev=ctx.device, done=done):
+                    torch.cuda.current_stream(dev).wait_event(done)
         m = containers.Map(nside=self.nside, axes_from=mmodes, comm=mmodes.comm, allocate=False)
-        m.attach("map", maps)
+        m.attach("map", maps, pending=pending)
         return m
 
     def _host_loop(self, mmodes):

@@ -24,16 +24,32 @@ import numpy as np
 class Dataset:
     """An array that is valid on the host, on a device, or both."""
 
-    def __init__(self, host=None, dev=None, attrs=None):
+    def __init__(self, host=None, dev=None, attrs=None, pending=None):
         assert host is not None or dev is not None
         self._host = host
-        self._dev = dev
+        self._dev_t = dev
+        self._pending = pending
         self.attrs = dict(attrs or {})
+
+    # The device copy may still be in the making on another stream: `pending` is then the action that orders the
+    # caller's stream behind that work (a stream wait, not a host wait).  It runs once, at the first access to the
+    # data -- a producer that returns early (the map-maker's side-stream SHT) does not hold up work that never looks
+    # at its output (the next sidereal day's transform and solves).
+    @property
+    def _dev(self):
+        if self._pending is not None:
+            act, self._pending = self._pending, None
+            act()
+        return self._dev_t
+
+    @_dev.setter
+    def _dev(self, t):
+        self._dev_t = t
 
     # -- shape/dtype without forcing a copy
     @property
     def shape(self):
-        return tuple(self._host.shape) if self._host is not None else tuple(self._dev.shape)
+        return tuple(self._host.shape) if self._host is not None else tuple(self._dev_t.shape)
 
     @property
     def dtype(self):
@@ -47,12 +63,12 @@ class Dataset:
                 torch.complex128: np.complex128,
                 torch.float32: np.float32,
                 torch.float64: np.float64,
-            }[self._dev.dtype]
+            }[self._dev_t.dtype]
         )
 
     @property
     def on_device(self):
-        return self._dev is not None
+        return self._dev_t is not None
 
     def host(self) -> np.ndarray:
         if self._host is None:
@@ -187,12 +203,13 @@ class ContainerBase:
     def dataset_shape(self, name):
         return tuple(len(self.index_map[a]) for a in self._dataset_spec[name]["axes"])
 
-    def attach(self, name, dev_tensor):
-        """Attach a device tensor as dataset ``name`` (shape/dtype checked against the spec)."""
+    def attach(self, name, dev_tensor, pending=None):
+        """Attach a device tensor as dataset ``name`` (shape/dtype checked against the spec).  ``pending``: see
+        :class:`Dataset` -- run once before the first access to the data."""
         spec = self._dataset_spec[name]
         if tuple(dev_tensor.shape) != self.dataset_shape(name):
             raise ValueError(f"{name}: shape {tuple(dev_tensor.shape)} != {self.dataset_shape(name)}")
-        ds = Dataset(dev=dev_tensor, attrs={"axis": spec["axes"]})
+        ds = Dataset(dev=dev_tensor, attrs={"axis": spec["axes"]}, pending=pending)
         if ds.dtype != np.dtype(spec["dtype"]):
             raise ValueError(f"{name}: dtype {ds.dtype} != {np.dtype(spec['dtype'])}")
         self.datasets[name] = ds

@@ -111,6 +111,11 @@ class Context:
         # the references taken by `uses()` have done their job
         self._held.clear()
 
+    def release_held(self):
+        """Drop the references taken by `uses()` without ordering anything: for a caller that has recorded its own
+        event behind the work and relies on `record_stream` for the allocator."""
+        self._held.clear()
+
     def bind_stream(self):
         """Launch on torch's current stream of this device (so torch allocations/copies order with kernels)."""
         s = (self.stream if self.stream is not None else torch.cuda.current_stream(self.device)).cuda_stream

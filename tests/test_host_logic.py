@@ -172,3 +172,23 @@ def test_container_save_load_round_trip(tmp_path):
 
     with pytest.raises(TypeError):
         containers.Map.load(g)
+
+
+def test_dataset_pending_action_runs_once_at_first_data_access():
+    """A producer may hand out a dataset whose device copy is still being written on another stream, with the action
+    that orders the reader behind it (containers.Dataset `pending`): shape / dtype queries must not trigger it, the
+    first access to the data must, exactly once."""
+    import torch
+
+    from draco_amd.core import containers
+
+    calls = []
+    t = torch.arange(6, dtype=torch.float64).reshape(2, 3)
+    ds = containers.Dataset(dev=t, pending=lambda: calls.append(1))
+    assert ds.shape == (2, 3) and ds.dtype == np.float64 and ds.on_device
+    assert calls == []
+    assert ds[1, 2] == 5.0
+    assert calls == [1]
+    np.asarray(ds)
+    ds._dev
+    assert calls == [1]
