@@ -45,7 +45,12 @@ int get_geom(dmm_ctx* ctx, int nside, int lmax, int mmax, ShtGeom* out) {
   }
   const size_t bfo_ofs = coef_ofs + coef_rows * sizeof(Coef);
   const size_t bf_ofs = (bfo_ofs + bf_off.size() * sizeof(int64_t) + 63) / 64 * 64;
-  const size_t total = bf_ofs + (size_t)bf_total * sizeof(double2);
+  const size_t phase_ofs = (bf_ofs + (size_t)bf_total * sizeof(double2) + 63) / 64 * 64;
+  int tw_len = kMaxBlue;
+  while (tw_len < 4 * nside) tw_len <<= 1;
+  const size_t tw_ofs = phase_ofs + (size_t)nring * (mmax + 1) * sizeof(double2);
+  const size_t chirp_ofs = tw_ofs + (size_t)(tw_len / 2) * sizeof(double2);
+  const size_t total = chirp_ofs + (size_t)2 * blue_rmax * (blue_rmax + 1) * sizeof(double2);
   if (it == ctx->sht.end()) {
     std::vector<unsigned char> h(bytes);
     double* z = reinterpret_cast<double*>(h.data());
@@ -102,6 +107,13 @@ int get_geom(dmm_ctx* ctx, int nside, int lmax, int mmax, ShtGeom* out) {
         e = hipGetLastError();
       }
     }
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_fill_ring_tables, dim3(nring + 1 + blue_rmax), dim3(256), 0, ctx->stream,
+                         reinterpret_cast<const double*>(db) + 2 * (size_t)nring /* phi0 */, nring, mmax,
+                         reinterpret_cast<double2*>(db + phase_ofs), reinterpret_cast<double2*>(db + tw_ofs), tw_len,
+                         reinterpret_cast<double2*>(db + chirp_ofs));
+      e = hipGetLastError();
+    }
     if (e != hipSuccess) {
       (void)hipFree(d);
       return dmm_set_error((int)e, "sht geometry upload: %s", hipGetErrorString(e));
@@ -125,6 +137,10 @@ int get_geom(dmm_ctx* ctx, int nside, int lmax, int mmax, ShtGeom* out) {
   g.bf_off = reinterpret_cast<int64_t*>(gb + bfo_ofs);
   g.bfilt = reinterpret_cast<double2*>(gb + bf_ofs);
   g.blue_rmax = blue_rmax;
+  g.phase = reinterpret_cast<double2*>(gb + phase_ofs);
+  g.tw = reinterpret_cast<double2*>(gb + tw_ofs);
+  g.tw_len = tw_len;
+  g.chirp = reinterpret_cast<double2*>(gb + chirp_ofs);
   *out = g;
   return DMM_OK;
 }

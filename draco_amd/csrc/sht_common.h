@@ -26,6 +26,12 @@ struct ShtGeom {          // device tables for one (nside, lmax, mmax)
   double2* bfilt;         // Bluestein filter spectra of the cap rings, back to back (see k_build_bfilt)
   int64_t* bf_off;        // [blue_rmax+1] offset of cap ring number ir's spectrum in bfilt
   int blue_rmax;          // cap ring numbers 1..blue_rmax have a spectrum (FFT length <= kMaxBlue)
+  // trigonometric tables of the ring stages (built once per geometry: an f64 sincos costs ~100 instructions, and the
+  // ring kernels used to spend more of them on these factors than on their FFT butterflies)
+  double2* phase;         // [nring][mmax+1] (cos, sin)(m phi0_ring)
+  double2* tw;            // [tw_len / 2] exp(-2 pi i k / tw_len); a transform of length M reads every (tw_len / M)-th
+  int tw_len;
+  double2* chirp;         // cap ring number ir (1..blue_rmax): exp(-i pi k^2 / (4 ir)), k < 4 ir, at offset 2 ir (ir - 1)
   void* block;            // the single allocation behind all of the above
 };
 

@@ -94,26 +94,57 @@ struct RingLds {
   dmm_fft::C<double>* chirp;  // [N]       (Bluestein only)
 };
 
+// (twiddles and chirp are copied from the geometry's tables: same values as computing them here, none of the cost)
 template <int NROW, bool BLUE>
-__device__ __forceinline__ RingLds ring_lds(unsigned char* smem, int N, int M) {
+__device__ __forceinline__ RingLds ring_lds(unsigned char* smem, const ShtGeom& g, int N, int M) {
   RingLds l;
   l.buf = reinterpret_cast<dmm_fft::C<double>*>(smem);
   l.tw = l.buf + NROW * (M + 1);
   l.chirp = l.tw + (M >> 1);
+  const int stride = g.tw_len / M;
   for (int k = threadIdx.x; k < (M >> 1); k += kFftThreads) {
-    double sn, cs;
-    sincospi(-2.0 * (double)k / (double)M, &sn, &cs);
-    l.tw[k] = {cs, sn};
+    const double2 t = g.tw[k * stride];
+    l.tw[k] = {t.x, t.y};
   }
   if (BLUE) {
+    const int ir = N >> 2;
+    const double2* src = g.chirp + (int64_t)2 * ir * (ir - 1);
     for (int k = threadIdx.x; k < N; k += kFftThreads) {
-      const int k2 = (int)(((int64_t)k * k) % (2 * (int64_t)N));  // exact phase reduction
-      double sn, cs;
-      sincospi(-(double)k2 / (double)N, &sn, &cs);
-      l.chirp[k] = {cs, sn};
+      const double2 t = src[k];
+      l.chirp[k] = {t.x, t.y};
     }
   }
   return l;
+}
+
+// geometry build: block b < nring fills the phase row of ring b, block nring the twiddles, block nring + ir the chirp
+// of cap ring number ir.  The expressions are the ones the ring kernels evaluated in place before.
+__global__ void k_fill_ring_tables(const double* phi0, int nring, int mmax, double2* phase, double2* tw, int tw_len,
+                                   double2* chirp) {
+  const int b = blockIdx.x;
+  if (b < nring) {
+    const double p0 = phi0[b];
+    for (int m = threadIdx.x; m <= mmax; m += blockDim.x) {
+      double sn, cs;
+      sincos((double)m * p0, &sn, &cs);
+      phase[(int64_t)b * (mmax + 1) + m] = make_double2(cs, sn);
+    }
+  } else if (b == nring) {
+    for (int k = threadIdx.x; k < tw_len / 2; k += blockDim.x) {
+      double sn, cs;
+      sincospi(-2.0 * (double)k / (double)tw_len, &sn, &cs);
+      tw[k] = make_double2(cs, sn);
+    }
+  } else {
+    const int ir = b - nring, N = 4 * ir;
+    double2* dst = chirp + (int64_t)2 * ir * (ir - 1);
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+      const int k2 = (int)(((int64_t)k * k) % (2 * (int64_t)N));  // exact phase reduction
+      double sn, cs;
+      sincospi(-(double)k2 / (double)N, &sn, &cs);
+      dst[k] = make_double2(cs, sn);
+    }
+  }
 }
 
 // forward DFT_N of the NROW rows in l.buf (natural order, already multiplied by the chirp and
@@ -151,10 +182,10 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, Ri
   const int rb = blockIdx.z * NROW;
   const int ring = class_ring(rc, p.g, blockIdx.x), f = blockIdx.y;
   const int n = p.g.nphi[ring], M = rc.M, P = M + 1;
-  const RingLds l = ring_lds<NROW, BLUE>(smem, n, M);
+  const RingLds l = ring_lds<NROW, BLUE>(smem, p.g, n, M);
   if (BLUE) __syncthreads();  // the chirp is used by the load below
   const int nm = p.g.mmax + 1;
-  const double phi0 = p.g.phi0[ring];
+  const double2* phase = p.g.phase + (int64_t)ring * nm;  // e^{i m phi0} of this ring
   const double2 *browa[NROW], *browb[NROW];  // the two polarisations of transform r
 #pragma unroll
   for (int r = 0; r < NROW; ++r) {
@@ -167,8 +198,8 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, Ri
   C<double>* rot = l.chirp + (BLUE ? 4 * rc.r_hi : 0);  // [NROW][2][nm], present when the class has such rings
   if (aliased) {
     for (int m = threadIdx.x; m < nm; m += kFftThreads) {
-      double sn, cs;
-      sincos((double)m * phi0, &sn, &cs);
+      const double2 ph = phase[m];
+      const double cs = ph.x, sn = ph.y;
 #pragma unroll
       for (int r = 0; r < NROW; ++r) {
         const double2 va = browa[r][m];
@@ -208,8 +239,8 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, Ri
     } else if (k < n) {
       // direct terms m == k (mod n)
       for (int m = k; m < nm; m += n) {
-        double sn, cs;
-        sincos((double)m * phi0, &sn, &cs);
+        const double2 ph = phase[m];
+        const double cs = ph.x, sn = ph.y;
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
           const double2 va = browa[r][m];
@@ -227,8 +258,8 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, Ri
       }
       // mirrored terms m == -k (mod n), m >= 1: conj(H_a) + i conj(H_b)
       for (int m = (k == 0 ? n : n - k); m < nm; m += n) {
-        double sn, cs;
-        sincos((double)m * phi0, &sn, &cs);
+        const double2 ph = phase[m];
+        const double cs = ph.x, sn = ph.y;
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
           const double2 va = browa[r][m];
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, Rin
   const int rb = blockIdx.z * NROW;
   const int ring = class_ring(rc, p.g, blockIdx.x), f = blockIdx.y;
   const int n = p.g.nphi[ring], M = rc.M, P = M + 1;
-  const RingLds l = ring_lds<NROW, BLUE>(smem, n, M);
+  const RingLds l = ring_lds<NROW, BLUE>(smem, p.g, n, M);
   if (BLUE) __syncthreads();
   const int64_t base = p.g.start[ring];
   for (int k = threadIdx.x; k < M; k += kFftThreads) {
@@ -339,12 +370,12 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, Rin
   const double2* bfilt = BLUE ? p.g.bfilt + p.g.bf_off[rc.belt ? 0 : rc.r_lo + ((int)blockIdx.x >> 1)] : nullptr;
   ring_dft<NROW, BLUE>(l, bfilt, M, rc.logM);
   const int nm = p.g.mmax + 1;
-  const double phi0 = p.g.phi0[ring];
+  const double2* phase = p.g.phase + (int64_t)ring * nm;
   const double w = 4.0 * M_PI / (double)p.npix;
   for (int m = threadIdx.x; m < nm; m += kFftThreads) {
     const int k = m % n, k2 = (n - k) % n;
-    double s0, c0;
-    sincos(-(double)m * phi0, &s0, &c0);
+    const double2 ph = phase[m];
+    const double c0 = ph.x, s0 = -ph.y;  // e^{-i m phi0}
 #pragma unroll
     for (int r = 0; r < NROW; ++r) {
       const C<double> X = ring_dft_at<BLUE>(l, r, k, M, rc.logM), Y = ring_dft_at<BLUE>(l, r, k2, M, rc.logM);
