@@ -150,9 +150,58 @@ __global__ __launch_bounds__(kThreads) void k_rowsum(DenseParams p) {
   }
 }
 
+// The same bound from the LOWER triangle alone (the Gram kernels write only that): sum_j |A_ij| = the row's own part
+// plus the column part sum_{k>i} |A_ki|.  Wave w walks the rows w, w+4, ...; a lane only ever adds to the columns
+// j = lane (mod 64) of its wave's private LDS array, so there are no atomics and the sums are formed in a fixed order.
+// Dynamic LDS: 5 Np doubles (orders up to 1024 in 40 KB; larger ones mirror first and use k_rowsum).
+__global__ __launch_bounds__(kThreads) void k_rowsum_lower(DenseParams p) {
+  extern __shared__ __align__(16) unsigned char smem_rs[];
+  double* col = reinterpret_cast<double*>(smem_rs);  // [4][n]
+  const int mat = blockIdx.x, n = p.Np;
+  double* rowpart = col + 4 * n;                      // [n]
+  const int N = order_of(p, p.tiles[p.tile0 + mat]);
+  const double2* A = p.A + (int64_t)mat * n * n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < 5 * n; j += kThreads) col[j] = 0.0;
+  __syncthreads();
+  double* mine = col + wave * n;
+  for (int i = wave; i < N; i += kThreads / 64) {
+    double sum = 0.0;
+    for (int j = lane; j <= i; j += 64) {
+      const double2 v = A[(int64_t)i * n + j];
+      const double a = sqrt(v.x * v.x + v.y * v.y);
+      sum += a;
+      if (j < i) mine[j] += a;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) rowpart[i] = sum;
+  }
+  __syncthreads();
+  double best = 0.0;
+  for (int i = threadIdx.x; i < N; i += kThreads) best = fmax(best, rowpart[i] + ((col[i] + col[n + i]) + (col[2 * n + i] + col[3 * n + i])));
+  for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_xor(best, off, 64));
+  __syncthreads();
+  if (lane == 0) col[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) p.theta[mat] = fmax(fmax(col[0], col[1]), fmax(col[2], col[3]));
+}
+
+// the diagonal of A itself prepared for a factorisation in place: zero modes and padding pinned as k_shift_copy does
+__global__ void k_pin_diag(DenseParams p) {
+  const int mat = blockIdx.y, n = p.Np;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int N = order_of(p, p.tiles[p.tile0 + mat]);
+  double2* d = p.A + (int64_t)mat * n * n + (int64_t)i * n + i;
+  const double th = p.theta[mat];
+  if (i >= N || d->x == 0.0) *d = make_double2(th > 0.0 ? th : 1.0, 0.0);
+  else d->y = 0.0;
+}
+
 // C = A - shift*I with the zero modes pinned: rows that are exactly zero (and the padding) get the
 // diagonal theta.  shift = max(rcond2 * theta, acond2) when `shifted`, else 0.
-__global__ __launch_bounds__(kThreads) void k_shift_copy(DenseParams p, double2* C, int shifted, double rcond2, double acond2) {
+// `lower`: only the lower triangle is copied (all a Cholesky factorisation reads).
+__global__ __launch_bounds__(kThreads) void k_shift_copy(DenseParams p, double2* C, int shifted, double rcond2, double acond2, int lower = 0) {
   const int mat = blockIdx.y, n = p.Np;
   const int N = order_of(p, p.tiles[p.tile0 + mat]);
   const double2* A = p.A + (int64_t)mat * n * n;
@@ -163,6 +212,7 @@ __global__ __launch_bounds__(kThreads) void k_shift_copy(DenseParams p, double2*
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * n;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx / n), j = (int)(idx % n);
+    if (lower && j > i) continue;
     double2 v = A[idx];
     if (i == j) v = (i >= N || v.x == 0.0) ? make_double2(pin, 0.0) : make_double2(v.x - shift, 0.0);
     dst[idx] = v;
@@ -597,22 +647,29 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       p.ldx = ntel;
       p.X = Vb;
     }
-    auto form_gram = [&]() {
+    // A certificate batch defers its rejects (they get their Gram matrix again in the deferred pass), so nothing after
+    // the factorisations reads A: the upper triangle is never built there, the row sums come from the lower one and
+    // the second factorisation runs in place (k_mirror + 1.5 matrix copies per batch less: 8 % of the pass).
+    const bool cert_only = shortcut && !eigen_only;
+    const size_t rs_lds = (size_t)5 * p.Np * sizeof(double);
+    const bool lower_only = cert_only && rs_lds <= 40 * 1024;
+    auto form_gram = [&](bool mirror = true) {
       if (sky) {
         hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
       } else {
         hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
       }
-      hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
+      if (mirror) hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
     };
-    form_gram();
+    form_gram(!lower_only);
     DMM_HIP(hipGetLastError());
     fail_h.assign(nmat, 1);
-    if (shortcut && !eigen_only) {
-      hipLaunchKernelGGL(k_rowsum, dim3(nmat), dim3(kThreads), 0, ctx->stream, p);
+    if (cert_only) {
+      if (lower_only) hipLaunchKernelGGL(k_rowsum_lower, dim3(nmat), dim3(kThreads), rs_lds, ctx->stream, p);
+      else hipLaunchKernelGGL(k_rowsum, dim3(nmat), dim3(kThreads), 0, ctx->stream, p);
       DMM_HIP(hipMemsetAsync(fail_b, 0, nmat * sizeof(int), ctx->stream));
-      DenseParams pc = p;  // factorisations run on a copy: A stays intact for the eigen path
+      DenseParams pc = p;  // the certificate's factorisation runs on a copy, the solve's in A itself
       pc.A = Vb;
       pc.Linv = Wb;
       pc.fail = fail_b;
@@ -625,10 +682,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         }
       };
       // certificate: G - tau I positive definite  <=>  no mode is cut
-      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vb, 1, rcond * rcond, acond * acond);
+      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vb, 1, rcond * rcond, acond * acond, 1);
       cholesky();
       // solve with G itself (certified tiles only write their result)
-      hipLaunchKernelGGL(k_shift_copy, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p, Vb, 0, 0.0, 0.0);
+      hipLaunchKernelGGL(k_pin_diag, dim3((p.Np + 255) / 256, nmat), dim3(256), 0, ctx->stream, p);
+      pc.A = p.A;
       cholesky();
       hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, pc);
       DMM_HIP(hipGetLastError());
