@@ -408,6 +408,38 @@ int dmm_dirty_w_launch(dmm_plan* pl, const void* B, const double2* wbuf, const d
                        void* alm);
 int dmm_dirty_w_launch_list(dmm_plan* pl, const void* B, const double2* wbuf, const double* Sl, const dmm_tile* tiles_d,
                             const int32_t* work_d, int nmat, int64_t nwork, void* alm);
+int dmm_dirty_launch_list(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, const dmm_tile* tiles_d,
+                          const int32_t* work_d, int nmat, int64_t nwork, void* alm);
+
+namespace {
+// B^H Ni v of the sky-side tiles only -- the right-hand sides of their systems (the telescope-side tiles, most of the
+// bytes of B, get their a_lm from the back-projection): lists of at most `cap` tiles through the batch's device arrays
+int sky_rhs(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, void* alm,
+            const std::map<int, std::vector<int64_t>>& sky_lists, dmm_tile* tiles_d, int32_t* work_d, int cap) {
+  std::vector<int64_t> all;
+  for (auto& kv : sky_lists) all.insert(all.end(), kv.second.begin(), kv.second.end());
+  std::vector<dmm_tile> tiles_c;
+  std::vector<int32_t> work_c;
+  hipStream_t st = pl->ctx->stream;
+  for (size_t i0 = 0; i0 < all.size(); i0 += cap) {
+    const int nmat = (int)std::min<size_t>(cap, all.size() - i0);
+    tiles_c.resize(nmat);
+    work_c.assign(nmat + 1, 0);
+    for (int i = 0; i < nmat; ++i) {
+      tiles_c[i] = pl->tiles_h[all[i0 + i]];
+      const int ncol = pl->npol * (pl->lmax + 1 - tiles_c[i].m);
+      work_c[i + 1] = work_c[i] + (ncol + pl->cols_per_block - 1) / pl->cols_per_block;
+    }
+    DMM_HIP(hipMemcpyAsync(tiles_d, tiles_c.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, st));
+    DMM_HIP(hipMemcpyAsync(work_d, work_c.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    DMM_HIP(hipStreamSynchronize(st));  // the host vectors are reused
+    int rc = dmm_dirty_launch_list(pl, B, mvis, mweight, tiles_d, work_d, nmat, work_c[nmat], alm);
+    if (rc) return rc;
+    DMM_HIP(hipStreamSynchronize(st));  // tiles_d / work_d are rewritten by the next list and by the batches
+  }
+  return DMM_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -450,8 +482,8 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
     if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);
     else sky_lists[(nsky + TB - 1) / TB * TB].push_back(t);
   }
-  if (!sky_lists.empty()) {  // B^H Ni v of every tile: the right-hand side of the sky-side systems
-    int rc = dmm_dirty_run(pl, B, mvis, mweight, alm);
+  if (!sky_lists.empty()) {
+    int rc = sky_rhs(pl, B, mvis, mweight, alm, sky_lists, tiles_d, work_d, cap);
     if (rc) return rc;
   }
   const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);
@@ -579,8 +611,8 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);  // 3: telescope side only
     else sky_lists[(nsky + TB - 1) / TB * TB].push_back(t);  // tiles of one padded order share batches
   }
-  if (!sky_lists.empty()) {  // B^H Ni v of every tile: the right-hand side of the sky-side systems
-    int rc = dmm_dirty_run(pl, B, mvis, mweight, alm);
+  if (!sky_lists.empty()) {
+    int rc = sky_rhs(pl, B, mvis, mweight, alm, sky_lists, tiles_d, work_d, cap);
     if (rc) return rc;
   }
   const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);

@@ -523,6 +523,19 @@ int dmm_dirty_w_launch(dmm_plan* pl, const void* B, const double2* wbuf, const d
   return launch_dirty<true>(pl, p, B, nullptr, nullptr, (double2*)alm);
 }
 
+// a = B^H (Ni o v) for an arbitrary (compact) list of the plan's tiles (the right-hand sides of the sky-side systems of
+// the dense solvers): `tiles_d` / `work_d` as below.
+int dmm_dirty_launch_list(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, const dmm_tile* tiles_d,
+                          const int32_t* work_d, int nmat, int64_t nwork, void* alm) {
+  DMM_HIP(hipSetDevice(pl->ctx->device));
+  SolveParams p = base_params(pl);
+  p.tiles = tiles_d;
+  p.work_start = work_d;
+  p.ntile = nmat;
+  p.nwork = nwork;
+  return launch_dirty<false>(pl, p, B, (const double2*)mvis, mweight, (double2*)alm);
+}
+
 // Same for an arbitrary (compact) list of tiles: `tiles_d` / `work_d` are device arrays of nmat tiles and
 // their nmat+1 column-block prefix sums (host copy `work_h`), wbuf[i] belongs to tiles_d[i].
 int dmm_dirty_w_launch_list(dmm_plan* pl, const void* B, const double2* wbuf, const double* Sl, const dmm_tile* tiles_d,
