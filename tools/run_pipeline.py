@@ -66,10 +66,10 @@ def main():
     report = {"config": args.config, "nfeed": tel.nfeed, "npairs": tel.npairs, "nfreq": tel.nfreq, "lmax": lmax, "nside": nside}
 
     def timed(name, fn):
-        ctx.sync()
+        torch.cuda.synchronize()  # device-wide: a map-maker's last alm2map may still be running on the side stream
         t0 = time.perf_counter()
         out = fn()
-        ctx.sync()
+        torch.cuda.synchronize()
         report[name + "_s"] = round(time.perf_counter() - t0, 4)
         print(f"[run_pipeline] {name}: {report[name + '_s']} s", file=sys.stderr, flush=True)
         return out
