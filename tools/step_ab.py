@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """A/B of k_dirty variants INSIDE the bench step (alm2map on the side stream) and alone, interleaved in one process.
 
-    python tools/step_ab.py [complex128|complex64] [variants=0,7] [rounds=5]
+    python tools/step_ab.py [complex128|complex64] [variants=0,7] [rounds=5] [option=dirty_variant]
+
+    `option` is any dmm_ctx_set_option name (dirty_variant, grid_mult ...); `variants` its values.
 """
 import json
 import os
@@ -23,6 +25,7 @@ def main():
     dtype = sys.argv[1] if len(sys.argv) > 1 else "complex128"
     variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,7").split(",")]
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    option = (sys.argv[4] if len(sys.argv) > 4 else "dirty_variant").encode()
     job = bench.Job(wl.CONFIGS[3], 0, 1, "weak", dtype, 0)
     job.step()
     torch.cuda.synchronize()
@@ -31,7 +34,7 @@ def main():
     res = {v: {"step_ms": [], "launch_in_step_ms": [], "launch_alone_ms": []} for v in variants}
     for _ in range(rounds):
         for v in variants:
-            _lib.check(_lib.lib.dmm_ctx_set_option(job.ctx.handle, b"dirty_variant", v))
+            _lib.check(_lib.lib.dmm_ctx_set_option(job.ctx.handle, option, v))
             ms, n = job.timed_launches(job.to_alm)
             res[v]["launch_alone_ms"].append(ms)
             eng = job.dm._get_engine()
