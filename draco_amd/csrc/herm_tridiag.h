@@ -489,6 +489,13 @@ __device__ __forceinline__ void td_replay(double2* b, const double2* lcs, const 
 #else
 #define TD_T(k)
 #endif
+// PH = 0: the whole solve in one launch.  PH = 1, 2, 3: the same in three launches -- Q^H b (256 threads), the serial QL
+// (ONE wave per matrix), replays / cut / Q y / output (256 threads) -- handing z, the eigenvalues and the chase count
+// over in the matrix's two spare vector slots.  The QL phase lasts 0.1-0.35 s at order 768 and used to keep four
+// 80-register waves and 25 KB of LDS per matrix resident for all of it: with a thousand matrices in flight that left
+// the next chunk's sweep kernels, which share the CUs, a quarter of their waves (none at all for the 224-register
+// applying sweep on most SIMDs).  As its own launch the QL wave leaves the registers to them.
+template <int PH>
 __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
 #ifdef TD_TIMING
   long long td_t[6];
@@ -501,17 +508,37 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   const double2* A = p.A + (int64_t)mat * n * n;
-  const double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
+  double2* vbm = tp.vec + (int64_t)mat * td_slots(n) * n;
+  const double2* vb = vbm;
   const double2* tau = vb + 4 * n;
   const double* dd = reinterpret_cast<const double*>(vb + 5 * n);
   const double* ee = dd + n;
+  double2* zbuf = vbm;                                     // slot 0: z = Q^H b        (PH 1 -> 3)
+  double* lam = reinterpret_cast<double*>(vbm + n);        // slot 1: eigenvalues, ... (PH 2 -> 3)
+  int* nrun_g = reinterpret_cast<int*>(lam + n);           //         ... number of logged chases
   double2* lcs = tp.log_cs + (int64_t)mat * tp.log_stride;
   int* lrun = reinterpret_cast<int*>(lcs + tp.log_cap);
   double2* b = reinterpret_cast<double2*>(smem_td);       // [n] the vector, transformed in place
-  double* dl = reinterpret_cast<double*>(b + n);          // [n]
+  double* dl = PH == 2 ? reinterpret_cast<double*>(smem_td) : reinterpret_cast<double*>(b + n);  // [n]
   double* el = dl + n;                                    // [n]
   const int Lsky = p.lmax + 1 - tile.m, N = order_of(p, tile);
 
+  if (PH == 2) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      dl[i] = dd[i];
+      el[i] = i < n - 1 ? ee[i] : 0.0;
+    }
+  } else if (PH == 3) {
+    if (tp.fail[blockIdx.x]) return;  // QL gave up: the fallback owns this matrix
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+      b[i] = zbuf[i];
+      dl[i] = lam[i];
+    }
+    if (threadIdx.x == 0) {
+      s_nrot = *nrun_g;
+      s_fail = 0;
+    }
+  } else
   for (int i = threadIdx.x; i < n; i += kThreads) {
     double2 v = make_double2(0.0, 0.0);
     if (i < N) {
@@ -531,9 +558,10 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     el[i] = i < n - 1 ? ee[i] : 0.0;
   }
   TD_T(0);
-  if (threadIdx.x == 0) s_nrot = s_fail = 0;
+  if (PH != 3 && threadIdx.x == 0) s_nrot = s_fail = 0;
   __syncthreads();
   // ---- z = Q^H b = H_{n-2}^H ... H_0^H b,  H_j = I - tau_j v_j v_j^H,  v_j = (0.., 1 at j+1, row j of A beyond)
+  if (PH == 0 || PH == 1)
   for (int j = 0; j < n - 1; ++j) {
     const double2 t = tau[j];
     if (t.x == 0.0 && t.y == 0.0) continue;  // (uniform over the block)
@@ -554,9 +582,13 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     __syncthreads();
   }
   TD_T(1);
+  if (PH == 1) {
+    for (int i = threadIdx.x; i < n; i += kThreads) zbuf[i] = b[i];
+    return;
+  }
   // ---- implicit-shift QL on (dl, el).  One lane runs the (inherently serial) bulge chases and logs every rotation
   // (c, s) plus one header (l, m, first log position) per chase; the vector is not touched here.
-  if (threadIdx.x < 64) {  // wave 0: all lanes search for the split point, lane 0 chases the bulge
+  if (PH != 3 && threadIdx.x < 64) {  // wave 0: all lanes search for the split point, lane 0 chases the bulge
     const int lane = threadIdx.x;
     int nrot = 0, nrun = 0, fail = 0;
     const int run_cap = tp.run_cap >= 0 ? tp.run_cap : ((blockIdx.x & 1) ? 0 : -tp.run_cap);
@@ -659,6 +691,11 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   TD_T(2);
   if (s_fail) {
     if (threadIdx.x == 0) tp.fail[blockIdx.x] = 1;
+    return;
+  }
+  if (PH == 2) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lam[i] = dl[i];
+    if (threadIdx.x == 0) *nrun_g = s_nrot;
     return;
   }
   // ---- t = S^T z: the chases in order, each a chain of rotations on descending index pairs (i, i+1).  A chase may

@@ -86,8 +86,11 @@ void td_reduce(TdParams& tp, int nmat, hipStream_t st) {
 
 // QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
 void td_solve(const TdParams& tp, int nmat, hipStream_t st) {
-  const size_t sol_lds = (size_t)tp.d.Np * (sizeof(double2) + 2 * sizeof(double));
-  hipLaunchKernelGGL(k_td_solve, dim3(nmat), dim3(kThreads), sol_lds, st, tp);
+  const size_t n = tp.d.Np;
+  // three launches: the long serial QL phase runs as ONE 64-thread wave per matrix (see k_td_solve)
+  hipLaunchKernelGGL(k_td_solve<1>, dim3(nmat), dim3(kThreads), n * sizeof(double2), st, tp);
+  hipLaunchKernelGGL(k_td_solve<2>, dim3(nmat), dim3(64), n * 2 * sizeof(double), st, tp);
+  hipLaunchKernelGGL(k_td_solve<3>, dim3(nmat), dim3(kThreads), n * (sizeof(double2) + 2 * sizeof(double)), st, tp);
 }
 
 }  // namespace
@@ -629,7 +632,9 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_REQUIRE(td_vec <= 160 * 1024 && td_sol <= 160 * 1024, "dmm_ml_run: matrix order %d too large for the LDS", L.Np);
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_col, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_vec));
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_trail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_vec));
-    DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
+    DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
+    DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
+    DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
   }
 
   std::vector<dmm_tile> tiles_c;
