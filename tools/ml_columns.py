@@ -6,6 +6,7 @@ the first long run of alternating k_td_col / k_td_trail* launches (one chunk of 
     python tools/ml_columns.py <rocprof output dir> [step]
 """
 import csv
+import re
 import glob
 import sys
 
@@ -43,6 +44,6 @@ for ci, i in enumerate(cols):
     tot_sw += tsw
     tot_idle += idle
     if ci % step == 0 or ci % step == 1 or ci % step == 2 or ci % step == 3:
-        kinds = ",".join("A" if ", 4, 2>" in n else "r" for n, _, _ in sw)
+        kinds = ",".join("r" if re.search(r"k_td_trail_tri<\d+, 0,", n) else "A" for n, _, _ in sw)
         print(f"{ci:6d} {tcol:12.1f} {tsw:12.1f} ({kinds}) {idle:10.1f}")
 print(f"totals: k_td_col {tot_col / 1e3:.1f} ms, sweeps {tot_sw / 1e3:.1f} ms, idle {tot_idle / 1e3:.1f} ms")
