@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--pool-freqs", type=int, default=0, help="frequencies' worth of distinct B tiles resident (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
-    ap.add_argument("--no-overlap", action="store_true", help="(kept for compatibility; the product always overlaps alm2map with the solves)")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B switch: alm2map on the caller's stream between the slabs' solves (DirtyMapMaker.overlap_sht = False) instead of beside them")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --same-device: rehearse the N>1 code path on a one-GPU box")
@@ -209,7 +209,7 @@ def cpu_baseline(cfg, seconds):
 class Job:
     """One rank's share of the job, held as the product's own containers and task objects."""
 
-    def __init__(self, cfg, rank, world, scaling, b_dtype, pool_freqs, seed=3003):
+    def __init__(self, cfg, rank, world, scaling, b_dtype, pool_freqs, seed=3003, overlap_sht=None):
         import torch
 
         from draco_amd import parallel
@@ -268,6 +268,7 @@ class Job:
         self.mt = MModeTransform()
         self.mt.setup(self.bt)
         self.dm = DirtyMapMaker(nside=self.nside, b_dtype=b_dtype, pool_bytes=self.pool_bytes + (1 << 20))
+        self.dm.overlap_sht = overlap_sht
         self.dm.setup(self.bt)
         ntel = 2 * npairs
         ms = np.tile(np.arange(lmax + 1), pool_freqs)
@@ -350,7 +351,7 @@ def main():
     from draco_amd.analysis import _solve
 
     cfg = wl.CONFIGS[args.config]
-    job = Job(cfg, rank, world, args.scaling, args.b_dtype, args.pool_freqs)
+    job = Job(cfg, rank, world, args.scaling, args.b_dtype, args.pool_freqs, overlap_sht=False if args.no_overlap else None)
 
     def barrier():
         torch.cuda.synchronize()

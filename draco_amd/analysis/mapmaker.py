@@ -40,12 +40,16 @@ class BaseMapMaker(ContainerTask):
         float64).  Not a reference attribute.
     pool_bytes : int or None
         HBM budget for B tiles per slab (default: 60 % of free memory).
+    overlap_sht : bool or None
+        Run the inverse SHT of a finished slab on a side stream beside the next slab's solves (True) or on the
+        caller's stream between them (False).  None (default): beside them.  Not a reference attribute.
     """
 
     nside = 256
     b_dtype = "complex128"
     pool_bytes = None
-    _config_names = ("nside", "b_dtype", "pool_bytes")
+    overlap_sht = None
+    _config_names = ("nside", "b_dtype", "pool_bytes", "overlap_sht")
 
     bt_cache = None
     _kind = None
@@ -108,7 +112,8 @@ class BaseMapMaker(ContainerTask):
         else:
             # the inverse SHT (:112) of the frequencies a slab has finished runs on a side stream
             # beside the next slab's fill + solves: it is compute-bound, they are HBM/PCIe-bound
-            side = Context.side(ctx.device_index)
+            overlap = True if self.overlap_sht is None else bool(self.overlap_sht)
+            side = Context.side(ctx.device_index) if overlap else ctx
             main = torch.cuda.current_stream(ctx.device)
             out = {}
 
@@ -116,6 +121,9 @@ class BaseMapMaker(ContainerTask):
                 nfreq, _, n_m, _ = alm.shape  # the local frequencies
                 if "maps" not in out:
                     out["maps"] = ctx.empty((nfreq, 4, npix), np.float64)
+                if not overlap:
+                    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(out["maps"][f0:f1])))
+                    return
                 side.wait_for(main)
                 side.uses(alm, out["maps"])  # read / written on the side stream: held until side.sync()
                 _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(out["maps"][f0:f1])))
@@ -124,7 +132,7 @@ class BaseMapMaker(ContainerTask):
             maps = out.get("maps")
             if maps is None:  # no frequencies on this rank
                 maps = ctx.empty((alm_d.shape[0], 4, npix), np.float64)
-            else:
+            elif overlap:
                 # the last slab's SHT is still running on the side stream.  Whoever reads the map is ordered behind
                 # it at that moment (Dataset's `pending`); work that does not -- the next day's transform and
                 # solves -- is not held up.  (`record_stream` guards the allocator meanwhile.)
