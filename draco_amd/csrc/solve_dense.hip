@@ -1015,7 +1015,27 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     return rc;
   };
 
+  // Sky-side lists go through the eigen pass one padded order at a time, and every order pays a latency-bound launch
+  // chain (~0.08 ms per Householder column whatever the batch) that a few hundred matrices do not fill: short lists
+  // of NEIGHBOURING orders are decomposed together at the larger one (order_of() keeps each tile's own size, the
+  // padding is zeros).  At cfg 3 / 16 frequencies: eleven chains of 4224 columns become six of 2304.
+  auto pair_orders = [&](std::map<int, std::vector<int64_t>>& lists) {
+    std::map<int, std::vector<int64_t>> out;
+    for (auto it = lists.rbegin(); it != lists.rend(); ++it) {
+      auto nx = std::next(it);
+      if (nx != lists.rend() && it->second.size() < 600 && nx->second.size() < 600 && it->first - nx->first <= TB) {
+        std::vector<int64_t>& d = out[it->first];
+        d = it->second;
+        d.insert(d.end(), nx->second.begin(), nx->second.end());
+        it = nx;
+      } else {
+        out[it->first] = it->second;
+      }
+    }
+    lists.swap(out);
+  };
   if (!shortcut) {  // every tile through the eigen path
+    pair_orders(sky_lists);
     // largest systems first: the pass ends on the serial QL of its LAST chunk, which nothing is left to hide
     int rc = eigen_list(tel_list, false, 0);
     for (auto it = sky_lists.rbegin(); it != sky_lists.rend(); ++it)
@@ -1035,10 +1055,19 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       d.insert(d.end(), list.begin() + i0, list.begin() + i0 + nmat);
       return DMM_OK;
     }
+    // a probe (the rate was low last time) is a sample of the batch, not the batch: 128 tiles cost a hundredth of a
+    // pass, a full batch of rejects a twentieth
+    constexpr int kProbe = 128;
+    const bool probe = pass_rate < 0.3 && nmat > 2 * kProbe;
+    const int first = probe ? kProbe : nmat;
     const int64_t before = ctx->ml_tiles_direct;
-    int rc = run_batch(list, i0, nmat, sky, np_sky, false, off);
-    pass_rate = (double)(ctx->ml_tiles_direct - before) / (double)nmat;
-    return rc;
+    int rc = run_batch(list, i0, first, sky, np_sky, false, off);
+    pass_rate = (double)(ctx->ml_tiles_direct - before) / (double)first;
+    if (rc || first == nmat) return rc;
+    if (pass_rate >= 0.3) return run_batch(list, i0 + first, nmat - first, sky, np_sky, false, off);
+    std::vector<int64_t>& d = sky ? sky_deferred[np_sky] : tel_deferred;
+    d.insert(d.end(), list.begin() + i0 + first, list.begin() + i0 + nmat);
+    return DMM_OK;
   };
   // Rejects that are known while direct batches remain are decomposed EARLY, on two small chunk slots at the end of the
   // workspace: Gram matrices and reduction on this stream, then the serial QL (a ~0.1 s latency floor whatever the
@@ -1117,9 +1146,10 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     sky_deferred.clear();
     sky_deferred[np_max] = all;
   }
+  if (nsky_def > 128) pair_orders(sky_deferred);
   int rc = eigen_list(tel_deferred, false, 0);
-  for (auto& kv : sky_deferred)
-    if (!rc) rc = eigen_list(kv.second, true, kv.first);
+  for (auto it = sky_deferred.rbegin(); it != sky_deferred.rend(); ++it)  // (largest first, as in the eigen-only pass)
+    if (!rc) rc = eigen_list(it->second, true, it->first);
   const int rc2 = drain();
   return rc ? rc : rc2;
 }
