@@ -101,13 +101,15 @@ __device__ __forceinline__ double2 block_sum2(double2 v, double* red) {
   return make_double2(red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7]);
 }
 
-__global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
-  extern __shared__ __align__(16) unsigned char smem_td[];
+// The column step of matrix `mat`: finishes step j-1 and forms the reflector of column j.  One whole block; `smem`: 2 n
+// double2 of LDS.  Called by k_td_col, and by the LAST block of a sweep that finishes for its matrix (k_td_trail_tri
+// with tp.fuse: the sweep's results are then all in memory, and the column step of one matrix runs under the sweep
+// blocks of the others instead of as a launch of its own).
+__device__ __forceinline__ void td_col_step(const TdParams& tp, int mat, int j, int np_in, unsigned char* smem) {
   __shared__ double red[8];
   __shared__ double2 s_tau, s_scale;
   const DenseParams& p = tp.d;
-  const int n = p.Np, j = tp.j;
-  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  const int n = p.Np;
   double2* A = p.A + (int64_t)mat * n * n;
   double2* vb = tp.vec + (int64_t)mat * td_slots(n) * n;
   double2 *vcur = vb + 2 * n, *praw = vb + 3 * n, *tau = vb + 4 * n;
@@ -115,10 +117,10 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
   double* ee = dd + n;
   double2* pv = td_pend(tp, mat);
   double2* pw = pv + (int64_t)kTdPend * n;
-  double2* sv = reinterpret_cast<double2*>(smem_td);
+  double2* sv = reinterpret_cast<double2*>(smem);
   double2* sw = sv + n;
-  double2* sa = sw + n;
-  int np = tp.np;  // complete pending pairs; the stored matrix lacks their updates
+  double2* sa = sv;  // the new column overwrites v element by element (sv[i], sw[i] are read first, sv[j], sw[j] kept in registers)
+  int np = np_in;  // complete pending pairs; the stored matrix lacks their updates
 
   // ---- finish step j-1: w = p - (conj(tau)/2) (v^H p) v,  p = tau A v with A = stored matrix - pending updates:
   // A v = (stored) v - sum_q [ v_q (w_q^H v) + w_q (v_q^H v) ]
@@ -187,11 +189,17 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
   // ---- column j with the pending updates: a_i = conj(A[j][i]) - sum_q [ v_q,i conj(w_q,j) + w_q,i conj(v_q,j) ]
   // (the newest pair from LDS, the older ones from memory)
   double2 xn = make_double2(0.0, 0.0);
+  double2 svj = make_double2(0.0, 0.0), swj = svj;
+  if (j >= 1) {
+    svj = sv[j];
+    swj = sw[j];
+  }
+  __syncthreads();  // (sa aliases sv: everyone holds sv[j], sw[j] before sa[j] is written)
   for (int i = j + threadIdx.x; i < n; i += kThreads) {
     const double2 r = A[(int64_t)j * n + i];
     double2 a = make_double2(r.x, -r.y);
     if (j >= 1) {
-      const double2 u1 = cmulc(sv[i], sw[j]), u2 = cmulc(sw[i], sv[j]);
+      const double2 u1 = cmulc(sv[i], swj), u2 = cmulc(sw[i], svj);
       a.x -= u1.x + u2.x;
       a.y -= u1.y + u2.y;
     }
@@ -235,6 +243,12 @@ __global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
     }
     vcur[i] = v;
   }
+}
+
+__global__ __launch_bounds__(kThreads) void k_td_col(TdParams tp) {
+  extern __shared__ __align__(16) unsigned char smem_td[];
+  const int mat = tp.d.msel ? tp.d.msel[blockIdx.x] : blockIdx.x;
+  td_col_step(tp, mat, tp.j, tp.np, smem_td);
 }
 
 // rows [j+1, n) x columns [j+1, n):  A -= vp wp^H + wp vp^H (step j-1),  praw = A v (step j)

@@ -73,7 +73,7 @@ void td_launch_trail(TdParams& tp, int& np_pend, int nmat, hipStream_t st) {
 // Householder reduction of the launch's matrices to tridiagonal form: n column steps (k_td_col) and n-1 sweeps.
 void td_reduce(TdParams& tp, int nmat, hipStream_t st) {
   const int n = tp.d.Np;
-  const size_t col_lds = (size_t)3 * n * sizeof(double2);
+  const size_t col_lds = (size_t)2 * n * sizeof(double2);
   int np_pend = 0;
   for (int j = 0; j < n; ++j) {
     tp.j = j;
