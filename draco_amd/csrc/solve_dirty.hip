@@ -288,6 +288,93 @@ __global__ __launch_bounds__(kThreads) void k_project(SolveParams p, const BT* _
   }
 }
 
+// Row-group form of k_project: a wave works on RG rows of its task at once -- RG independent row pieces in flight per
+// lane, ONE LDS read of a_lm per RG loads, and the 2 RG row sums leave the wave through one reduce-scatter butterfly
+// (2 RG + 3 shuffles instead of 12 per row).
+template <int NV>
+__device__ __forceinline__ void proj_wave_sums(double (&x)[NV], int lane) {  // as wave_sums of herm_tridiag.h
+  int bit = 0;
+#pragma unroll
+  for (int h = NV / 2; h >= 1; h >>= 1, ++bit) {
+    const bool up = (lane >> bit) & 1;
+#pragma unroll
+    for (int k = 0; k < h; ++k) {
+      double lo = x[k], hi = x[h + k];
+      asm volatile("" : "+v"(lo), "+v"(hi));  // (keeps the selects from becoming one dynamically indexed register read)
+      const double keep = up ? hi : lo, send = up ? lo : hi;
+      x[k] = keep + __shfl_xor(send, 1 << bit);
+    }
+  }
+#pragma unroll
+  for (int o = NV; o < 64; o <<= 1) x[0] += __shfl_xor(x[0], o);
+}
+
+template <typename BT, bool NT, int RG>
+__global__ __launch_bounds__(kThreads) void k_project_rg(SolveParams p, const BT* __restrict__ B,
+                                                         const double2* __restrict__ alm,
+                                                         double2* __restrict__ vis) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* a = reinterpret_cast<double2*>(smem);  // [npol * L], packed (pol, l-m) order
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int kRowsPerWave = 64 / kWaves;
+  static_assert(kRowsPerWave % RG == 0, "row groups must tile a wave's rows");
+  for (int64_t work = blockIdx.x; work < p.nwork; work += gridDim.x) {
+    const int64_t t = find_tile(p.work_start, p.ntile, work);
+    const dmm_tile tile = p.tiles[t];
+    const int rb = (int)(work - p.work_start[t]);  // block of 64 rows
+    const int m = tile.m, f = tile.f;
+    const int L = p.lmax + 1 - m;
+    const int ncol = p.npol * L;
+    const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+    const int col0 = p.full_layout ? m : 0;
+    const int64_t row_stride = (int64_t)p.npol * pol_stride;
+    __syncthreads();
+    for (int j = threadIdx.x; j < ncol; j += kThreads) {
+      const int pol = j / L, lrel = j - pol * L;
+      a[j] = alm[(((int64_t)f * p.npol + pol) * p.n_m + m) * (p.lmax + 1) + m + lrel];
+    }
+    __syncthreads();
+    for (int g = 0; g < kRowsPerWave; g += RG) {
+      const int i0 = rb * 64 + wave * kRowsPerWave + g;
+      if (i0 >= p.ntel) break;
+      const BT* row[RG];
+      double acc[2 * RG];
+#pragma unroll
+      for (int k = 0; k < RG; ++k) {
+        const int i = i0 + k < p.ntel ? i0 + k : p.ntel - 1;  // (clamped duplicates are not stored)
+        row[k] = B + tile.b_off + (int64_t)i * row_stride + col0;
+        acc[2 * k] = acc[2 * k + 1] = 0.0;
+      }
+      for (int pol = 0; pol < p.npol; ++pol) {
+        const int64_t so = (int64_t)pol * pol_stride;
+        const double2* as = a + pol * L;
+        for (int lrel = lane; lrel < L; lrel += 64) {
+          const double2 av = as[lrel];
+          double br[RG], bi[RG];
+#pragma unroll
+          for (int k = 0; k < RG; ++k) load_b<BT, NT>(row[k] + so + lrel, br[k], bi[k]);
+#pragma unroll
+          for (int k = 0; k < RG; ++k) {
+            acc[2 * k] = fma(br[k], av.x, fma(-bi[k], av.y, acc[2 * k]));
+            acc[2 * k + 1] = fma(br[k], av.y, fma(bi[k], av.x, acc[2 * k + 1]));
+          }
+        }
+      }
+      proj_wave_sums<2 * RG>(acc, lane);
+      if (lane < 2 * RG) {  // lane holds value number bitrev(lane) = 2 k + (0: re, 1: im)
+        int idx = 0, nb = 0;
+        for (int q = 2 * RG; q > 1; q >>= 1) ++nb;
+        for (int bq = 0; bq < nb; ++bq) idx |= ((lane >> bq) & 1) << (nb - 1 - bq);
+        const int i = i0 + (idx >> 1);
+        if (i < p.ntel) {
+          const int s = i >= p.npairs, pp = i - s * p.npairs;
+          reinterpret_cast<double*>(&vis[(((int64_t)m * 2 + s) * p.nfreq + f) * p.npairs + pp])[idx & 1] = acc[0];
+        }
+      }
+    }
+  }
+}
+
 // tasks per tile: by column blocks (cols > 0) or by blocks of 64 rows (cols == 0)
 int make_work(const dmm_plan* pl, int cols, std::vector<int32_t>& ws, int64_t* nwork) {
   ws.resize(pl->ntile + 1);
@@ -483,7 +570,8 @@ int dmm_project_run(dmm_plan* pl, const void* B, const void* alm_in, void* vis_o
   const size_t lds = (size_t)p.npol * (p.lmax + 1) * sizeof(double2);
   if (lds > 160 * 1024)
     return dmm_set_error(DMM_E_UNSUPPORTED, "dmm_project_run: nsky=%d too large for the LDS stage", p.npol * (p.lmax + 1));
-  int64_t grid = (int64_t)ctx->num_cu * (ctx->opt_project_grid_mult > 0 ? ctx->opt_project_grid_mult : 16);
+  // (tools/project_timing.py: the row-group kernel is fastest with ONE block per CU, like the Dirty kernel: 6.26 TB/s)
+  int64_t grid = (int64_t)ctx->num_cu * (ctx->opt_project_grid_mult > 0 ? ctx->opt_project_grid_mult : 1);
   if (grid > p.nwork) grid = p.nwork;
   if (pl->b_dtype == DMM_C128) {
 #define DMM_LAUNCH_PROJECT(KERN)                                                                              \
@@ -493,14 +581,17 @@ int dmm_project_run(dmm_plan* pl, const void* B, const void* alm_in, void* vis_o
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const double2*)B,       \
                        (const double2*)alm_in, (double2*)vis_out);                                            \
   } while (0)
-    switch (ctx->opt_project_variant) {  // tools/project_timing.py: NT loads, 4 row pieces in flight win (6.07 vs 5.73 TB/s)
+    switch (ctx->opt_project_variant) {  // tools/project_timing.py: row groups of 8 with NT loads: 6.26 TB/s; one row per wave (4): 5.97
       case 1: DMM_LAUNCH_PROJECT((k_project<double2, false, 4>)); break;
       case 2: DMM_LAUNCH_PROJECT((k_project<double2, false, 8>)); break;
       case 3: DMM_LAUNCH_PROJECT((k_project<double2, true, 8>)); break;
-      default: DMM_LAUNCH_PROJECT((k_project<double2, true, 4>)); break;
+      case 4: DMM_LAUNCH_PROJECT((k_project<double2, true, 4>)); break;
+      case 5: DMM_LAUNCH_PROJECT((k_project_rg<double2, true, 4>)); break;
+      case 6: DMM_LAUNCH_PROJECT((k_project_rg<double2, false, 8>)); break;
+      default: DMM_LAUNCH_PROJECT((k_project_rg<double2, true, 8>)); break;
     }
   } else {
-    auto k = k_project<float2, true, 4>;
+    auto k = k_project_rg<float2, true, 8>;
     DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const float2*)B, (const double2*)alm_in, (double2*)vis_out);
   }
