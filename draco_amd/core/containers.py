@@ -124,6 +124,7 @@ class ContainerBase:
 
     def __init__(self, axes_from=None, attrs_from=None, comm=None, distributed=True, allocate=True, **axes):
         self.index_map = {}
+        self.index_attrs = {}
         self.attrs = {}
         self.comm = comm
         self.reverse_map = {}
@@ -142,8 +143,13 @@ class ContainerBase:
             elif isinstance(val, (int, np.integer)):
                 val = np.arange(int(val))
             self.index_map[ax] = np.asarray(val)
+        for ax in self.index_map:
+            self.index_attrs[ax] = {}
         if attrs_from is not None:
             self.attrs.update(attrs_from.attrs)
+            for ax, a in getattr(attrs_from, "index_attrs", {}).items():  # (caput: axis attributes travel too)
+                if ax in self.index_attrs:
+                    self.index_attrs[ax].update(a)
         self.datasets = {}
         for name, spec in self._dataset_spec.items():
             missing = [a for a in spec["axes"] if a not in self.index_map]
@@ -152,6 +158,28 @@ class ContainerBase:
             shape = tuple(len(self.index_map[a]) for a in spec["axes"])
             if allocate:  # allocate=False: the producing task attaches device tensors instead
                 self.datasets[name] = Dataset(host=np.zeros(shape, dtype=spec["dtype"]), attrs={"axis": spec["axes"]})
+                src = getattr(attrs_from, "datasets", {}).get(name) if attrs_from is not None else None
+                if src is not None:  # dataset attributes too, but never the receiving dataset's own axis tuple
+                    self.datasets[name].attrs.update({k: v for k, v in src.attrs.items() if k != "axis"})
+
+    def copy(self, shared=()):
+        """A copy with its own datasets, except those named in ``shared``, which are the SAME objects (data and
+        attributes) as the original's -- caput's ``copy(shared=...)``.  Container and axis attributes are copied."""
+        import copy as _copy
+
+        out = type(self).__new__(type(self))
+        out.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("datasets", "attrs", "index_attrs", "index_map", "reverse_map")})
+        out.index_map = dict(self.index_map)
+        out.reverse_map = dict(self.reverse_map)
+        out.attrs = _copy.deepcopy(self.attrs)
+        out.index_attrs = _copy.deepcopy(self.index_attrs)
+        out.datasets = {}
+        for name, ds in self.datasets.items():
+            if name in shared:
+                out.datasets[name] = ds
+            else:
+                out.datasets[name] = Dataset(host=np.array(ds.host(), copy=True), attrs=_copy.deepcopy(ds.attrs))
+        return out
 
     def redistribute(self, axis):  # single process: nothing to move
         return None
@@ -183,6 +211,7 @@ class ContainerBase:
             klass = cls if cls is not ContainerBase else next(c for c in _all_containers() if c.__name__ == name)
             out = klass.__new__(klass)
             out.index_map, out.reverse_map, out.attrs, out.datasets, out.comm = {}, {}, {}, {}, None
+            out.index_attrs = {}
             if hasattr(klass, "_optional_spec"):
                 out._dataset_spec = dict(klass._dataset_spec)
             for key in z.files:

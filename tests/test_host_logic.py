@@ -192,3 +192,54 @@ def test_dataset_pending_action_runs_once_at_first_data_access():
     np.asarray(ds)
     ds._dev
     assert calls == [1]
+
+
+def _ss_container():
+    from draco_amd.core import containers
+
+    ss = containers.SiderealStream(stack=5, input=3, ra=16, freq=np.linspace(800.0, 750.0, 5))
+    ss.attrs["test_attr1"] = "hello"
+    ss.vis.attrs["test_attr2"] = "hello2"
+    ss.weight.attrs["test_attr3"] = "hello3"
+    ss.index_attrs["freq"]["alignment"] = 1
+    return ss
+
+
+def test_containers_attrs_from_like_the_reference():
+    """The reference's own test of the constructor protocol (test/test_containers.py:25-39), on the containers of this
+    path: container, dataset and axis attributes travel with ``attrs_from``; a dataset's ``axis`` tuple is its own."""
+    from draco_amd.core import containers
+
+    ss = _ss_container()
+    other = containers.SiderealStream(ra=10, axes_from=ss, attrs_from=ss)
+    assert len(other.attrs) == 1 and other.attrs["test_attr1"] == "hello"
+    assert other.vis.attrs["test_attr2"] == "hello2"
+    assert other.weight.attrs["test_attr3"] == "hello3"
+    assert other.index_attrs["freq"]["alignment"] == 1
+    assert len(other.vis.attrs) == 2 and len(other.weight.attrs) == 2
+    assert tuple(other.vis.attrs["axis"]) == ("freq", "stack", "ra")
+    assert tuple(other.weight.attrs["axis"]) == ("freq", "stack", "ra")
+    assert other.vis.shape == (5, 5, 10)
+    mm = containers.MModes(mmax=4, axes_from=ss, attrs_from=ss)  # another container class: attributes by dataset NAME
+    assert mm.attrs["test_attr1"] == "hello" and mm.vis.attrs["test_attr2"] == "hello2"
+    assert tuple(mm.vis.attrs["axis"]) == ("m", "msign", "freq", "stack")
+
+
+def test_containers_copy_shared_like_the_reference():
+    """test/test_containers.py:42-76 (the single-process part): ``copy(shared=("vis",))`` shares that dataset -- data and
+    attributes -- and copies the others."""
+    ss = _ss_container()
+    ss.vis[:] = np.arange(16)
+    ss.weight[:] = np.arange(16)
+    cp = ss.copy(shared=("vis",))
+    assert (cp.vis[:] == ss.vis[:]).all() and (cp.weight[:] == ss.weight[:]).all()
+    assert cp.attrs["test_attr1"] == "hello" and cp.vis.attrs["test_attr2"] == "hello2"
+    assert cp.weight.attrs["test_attr3"] == "hello3" and cp.index_attrs["freq"]["alignment"] == 1
+    ss.vis[:] = 1.0
+    ss.weight[:] = 2.0
+    ss.vis.attrs["test_attr4"] = "hello4"
+    ss.weight.attrs["test_attr5"] = "hello5"
+    assert (cp.vis[:] == 1.0).all()
+    assert (cp.weight[:] == np.arange(16)).all()
+    assert cp.vis.attrs["test_attr4"] == "hello4"
+    assert "test_attr5" not in cp.weight.attrs
