@@ -198,6 +198,12 @@ class ContainerBase:
             blob["attrs/" + k] = np.asarray(v)
         for k, ds in self.datasets.items():
             blob["dataset/" + k] = np.asarray(ds.host())
+            for ak, av in ds.attrs.items():
+                if ak != "axis":
+                    blob[f"dataset_attrs/{k}/{ak}"] = np.asarray(av)
+        for ax, a in getattr(self, "index_attrs", {}).items():
+            for ak, av in a.items():
+                blob[f"index_attrs/{ax}/{ak}"] = np.asarray(av)
         with open(path, "wb") as fh:  # (np.savez would append ".npz" to a bare name)
             np.savez(fh, **blob)
 
@@ -227,6 +233,19 @@ class ContainerBase:
                     if k not in out._dataset_spec and k in getattr(klass, "_optional_spec", {}):
                         out._dataset_spec[k] = klass._optional_spec[k]
                     out.datasets[k] = Dataset(host=z[key])
+            # second pass: attributes of the datasets and of the axes (the `axis` tuple of a dataset comes from its spec)
+            item = lambda v: v.item() if v.ndim == 0 else v  # noqa: E731
+            for k, ds in out.datasets.items():
+                if k in out._dataset_spec:
+                    ds.attrs["axis"] = out._dataset_spec[k]["axes"]
+            for ax in out.index_map:
+                out.index_attrs.setdefault(ax, {})
+            for key in z.files:
+                parts = key.split("/")
+                if parts[0] == "dataset_attrs" and parts[1] in out.datasets:
+                    out.datasets[parts[1]].attrs["/".join(parts[2:])] = item(z[key])
+                elif parts[0] == "index_attrs":
+                    out.index_attrs.setdefault(parts[1], {})["/".join(parts[2:])] = item(z[key])
         return out
 
     def dataset_shape(self, name):

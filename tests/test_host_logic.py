@@ -243,3 +243,22 @@ def test_containers_copy_shared_like_the_reference():
     assert (cp.weight[:] == np.arange(16)).all()
     assert cp.vis.attrs["test_attr4"] == "hello4"
     assert "test_attr5" not in cp.weight.attrs
+
+
+def test_container_save_load_keeps_datasets_and_attributes_like_the_reference(tmp_path):
+    """The round trip of test/test_io.py::test_LoadBasicCont_simple (a stage output written and read back): datasets,
+    container attributes, dataset attributes and axis attributes survive."""
+    from draco_amd.core import containers
+
+    ss = _ss_container()
+    ss.vis[:] = (np.arange(5)[:, None, None] + 1j * np.arange(16)[None, None, :]).astype(np.complex64)
+    ss.weight[:] = np.arange(5)[None, :, None]
+    fname = str(tmp_path / "ss.npz")
+    ss.save(fname)
+    back = containers.SiderealStream.load(fname)
+    assert (back.vis[:] == ss.vis[:]).all() and (back.weight[:] == ss.weight[:]).all()
+    assert back.attrs["test_attr1"] == "hello"
+    assert back.vis.attrs["test_attr2"] == "hello2" and back.weight.attrs["test_attr3"] == "hello3"
+    assert back.index_attrs["freq"]["alignment"] == 1
+    assert tuple(back.vis.attrs["axis"]) == ("freq", "stack", "ra")
+    assert np.array_equal(back.freq, ss.freq)
