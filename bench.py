@@ -114,6 +114,16 @@ def _process_arm(nproc, npairs, nra, lmax, ms, budget):
                 os.environ[k] = v_
 
 
+def _blas_vendor():
+    """BLAS behind NumPy's dot ('print the core count and BLAS vendor')."""
+    try:
+        from threadpoolctl import threadpool_info
+
+        return "; ".join(f"{d.get('internal_api')} {d.get('version')} ({d.get('threading_layer', d.get('user_api'))})" for d in threadpool_info() if d.get("user_api") == "blas") or "unknown"
+    except Exception:
+        return "unknown"
+
+
 def cpu_baseline(cfg, seconds):
     """Oracle (NumPy restatement of the reference) timed on this box's host cores.
 
@@ -202,6 +212,7 @@ def cpu_baseline(cfg, seconds):
         "kind": "port",
         "sample": f"arm '{best_name}' (fastest of {list(arms)}): {best['solves']} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from RAM pools) + the FFT+pack of whole frequencies, {seconds:.0f}s of wall time over all arms, extrapolated linearly to {(lmax+1)*nfreq} solves + {nfreq} frequencies; alm2map not charged to the CPU time (the GPU step includes it)",
         "host_cores_visible": ncpu,
+        "blas": _blas_vendor(),
         "arms": arms,
     }
 
