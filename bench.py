@@ -573,6 +573,17 @@ def extras(args, cfg, job):
                     fl += 4.0 * k_ * k_ * K_ + (8.0 / 3.0) * k_**3
                 extra["wiener_mfma"] = {"achieved": fl * nf_w / t_w / 1e12, "peak": 78.6, "unit": "TFLOP/s (FP64 MFMA, whole solve incl. factorisation and triangular solves)",
                                         "frac": fl * nf_w / t_w / 1e12 / 78.6}
+        # ML with every tile eigen-decomposed ("ml_shortcut" = 2): what ill-conditioned beam transfers cost, where the
+        # full-rank certificate of the sample above does not pass
+        try:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+            ctx.sync()
+            t0 = time.perf_counter()
+            eng2.solve("ml", mv1, mw1, list(range(nf_w)), lmax)
+            ctx.sync()
+            extra["ml_eigen_ms_per_solve"] = (time.perf_counter() - t0) * 1e3 / (nf_w * (lmax + 1))
+        finally:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
         extra["dense_sample"] = f"all {lmax + 1} m of {nf_w} frequencies, B resident"
         del eng2, mv1, mw1, vis1, w1
         _solve.release_pools()
