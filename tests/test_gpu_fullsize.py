@@ -315,3 +315,47 @@ def test_cfg3_ml_rank_deficient_telescope_side_stays_on_the_tridiagonal_path():
     assert np.all(np.isfinite(out))
     for m in (0, 200, 330, 400, 480, 510):
         assert _rel(out[..., m, :], ref[..., m, :]) < 1e-7, m
+
+
+def test_cfg3_ml_low_pass_rate_scheduling_matches_the_eigen_only_pass():
+    """One cfg-3 frequency whose noise weights span eight decades: hardly any tile passes the full-rank certificate, so
+    the default options go through everything the scheduler has for that regime -- whole batches deferred, 128-tile
+    probes, deferred sky-side orders decomposed in pairs, largest first.  Every tile must be solved exactly once, and
+    the answer must be the one of the pass that decomposes every tile outright."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    tel = _tel(3, 1)
+    lmax = tel.lmax
+    bt = SyntheticProvider(tel, seed=33)
+    gen = torch.Generator(device=ctx.device).manual_seed(6)
+    shape = (lmax + 1, 2, 1, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    spread = torch.pow(10.0, -8.0 * torch.rand((1, 1, 1, tel.npairs), dtype=torch.float64, device=ctx.device, generator=gen))
+    mw = (torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) * 40.0 + 10.0) * spread
+    eng = SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED)
+
+    def counter(name):
+        import ctypes as C
+
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    d0, e0, q0 = counter(b"ml_tiles_direct"), counter(b"ml_tiles_eigen"), counter(b"ml_tiles_ql_failed")
+    out = eng.solve("ml", mv, mw, [0], lmax, acond=1e-4, rcond=1e-3).cpu().numpy()
+    nd, ne = counter(b"ml_tiles_direct") - d0, counter(b"ml_tiles_eigen") - e0
+    assert nd + ne == lmax + 1 and ne > nd  # every tile once; most of them decomposed
+    assert counter(b"ml_tiles_ql_failed") == q0
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+        ref = eng.solve("ml", mv, mw, [0], lmax, acond=1e-4, rcond=1e-3).cpu().numpy()
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+    assert np.all(np.isfinite(out))
+    assert _rel(out, ref) < 1e-8
