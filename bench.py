@@ -402,29 +402,36 @@ def main():
     # the north star's one collective, after the timed region: all-gather of the rank-local Maps over RCCL
     gather = None
     if world > 1 and not args.no_allgather:
-        _solve.release_pools()  # the gathered map of a weak-scaled job is N x 6.4 GB: make room first
-        shard_bytes = out_map.map._dev.numel() * 8
-        ts = []
-        for _ in range(2):
-            barrier()
-            t0 = time.perf_counter()
-            full = parallel.allgather_map(out_map)
-            barrier()
-            ts.append(time.perf_counter() - t0)
-            nfull = len(full.index_map["freq"])
-            del full
-        tg = allreduce_max(min(ts))
-        gather = {
-            "allgather_ms": tg * 1e3,
-            "shard_GB": shard_bytes / 1e9,
-            "gathered_GB": shard_bytes * world / 1e9,
-            "frequencies_gathered": nfull,
-            # every rank receives (N-1) shards; in a direct all-gather each arrives over its own xGMI link
-            "GBs_per_link": shard_bytes / tg / 1e9,
-            "GBs_per_gpu_in": shard_bytes * (world - 1) / tg / 1e9,
-            "backend": args.backend,
-            "note": "parallel.allgather_map (one all_gather_into_tensor; RCCL over xGMI under nccl) on the maps of the last timed day, outside the timed region; best of 2",
-        }
+
+        def measure_allgather():
+            _solve.release_pools()  # the gathered map of a weak-scaled job is N x 6.4 GB: make room first
+            shard_bytes = out_map.map._dev.numel() * 8
+            ts = []
+            for _ in range(2):
+                barrier()
+                t0 = time.perf_counter()
+                full = parallel.allgather_map(out_map)
+                barrier()
+                ts.append(time.perf_counter() - t0)
+                nfull = len(full.index_map["freq"])
+                del full
+            tg = allreduce_max(min(ts))
+            return {
+                "allgather_ms": tg * 1e3,
+                "shard_GB": shard_bytes / 1e9,
+                "gathered_GB": shard_bytes * world / 1e9,
+                "frequencies_gathered": nfull,
+                # every rank receives (N-1) shards; in a direct all-gather each arrives over its own xGMI link
+                "GBs_per_link": shard_bytes / tg / 1e9,
+                "GBs_per_gpu_in": shard_bytes * (world - 1) / tg / 1e9,
+                "backend": args.backend,
+                "note": "parallel.allgather_map (one all_gather_into_tensor; RCCL over xGMI under nccl) on the maps of the last timed day, outside the timed region; best of 2",
+            }
+
+        try:  # (never allowed to cost the headline line: a failure is recorded, not raised)
+            gather = measure_allgather()
+        except Exception as exc:  # noqa: BLE001
+            gather = {"error": f"{type(exc).__name__}: {exc}"[:400], "backend": args.backend}
 
     traffic = None
     try:  # HBM bytes per launch from the committed PMC profile of this same command, if it matches
