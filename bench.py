@@ -379,14 +379,35 @@ def main():
     eng = job.dm._get_engine()
     eng.launch_events = []
     barrier()
+    mem0 = torch.cuda.memory_stats()
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
+    day_issue_ms = []
     for _ in range(args.steps):
         out_map = job.step()
+        day_issue_ms.append((time.perf_counter() - t0) * 1e3)  # host clock when the day's launches were all queued
     barrier()
     elapsed = time.perf_counter() - t0
+    mem1 = torch.cuda.memory_stats()
+    free_now, total_hbm = torch.cuda.mem_get_info()
+    allocator = {
+        # what the caching allocator did INSIDE the timed region: a retry = it ran out, synchronised, freed its cache
+        # and asked the driver again (the GPU idles meanwhile); device_alloc = hipMalloc calls (each one synchronises)
+        "num_alloc_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
+        "num_ooms": int(mem1.get("num_ooms", 0) - mem0.get("num_ooms", 0)),
+        "num_device_alloc": int(mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0)),
+        "num_device_free": int(mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0)),
+        "reserved_peak_GB": mem1.get("reserved_bytes.all.peak", 0) / 1e9,
+        "allocated_peak_GB": mem1.get("allocated_bytes.all.peak", 0) / 1e9,
+        "hbm_total_GB": total_hbm / 1e9,
+        "host_issue_ms_per_day": [round(b - a, 2) for a, b in zip([0.0] + day_issue_ms[:-1], day_issue_ms)],
+    }
     ev = eng.launch_events
     eng.launch_events = None
     assert eng.fills == fills_before, "B was uploaded inside the timed region"
+    # a retry of the caching allocator inside the timed region = the GPU idled while torch freed and re-allocated its
+    # cache (what unbounded host run-ahead did to round 2's 20-step line): such a number is not the product's
+    assert allocator["num_alloc_retries"] == 0 and allocator["num_ooms"] == 0, f"caching allocator retried inside the timed region: {allocator}"
     if world > 1:
         elapsed = allreduce_max(elapsed)
     launch_ms = [a.elapsed_time(b) for a, b, _, _ in ev]
@@ -486,6 +507,7 @@ def main():
             },
         },
     }
+    out["allocator"] = allocator
     if gather is not None:
         out["allgather"] = gather
 

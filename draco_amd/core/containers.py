@@ -31,15 +31,21 @@ class Dataset:
         self._pending = pending
         self.attrs = dict(attrs or {})
 
-    # The device copy may still be in the making on another stream: `pending` is then the action that orders the
-    # caller's stream behind that work (a stream wait, not a host wait).  It runs once, at the first access to the
-    # data -- a producer that returns early (the map-maker's side-stream SHT) does not hold up work that never looks
-    # at its output (the next sidereal day's transform and solves).
+    # The device copy may still be in the making on another stream: `pending` is then what orders a reader behind
+    # that work -- an object with `done()` (has the producer finished? never blocks) and `order()` (make the CALLER's
+    # current stream wait for it: a stream wait, not a host wait).  EVERY access to the data orders the stream that is
+    # current at that moment, until the producer has finished -- readers on different streams (the caller's, a side
+    # context, the fill stream, the RCCL stream) are each ordered, whichever comes first.  A producer that returns
+    # early (the map-maker's side-stream SHT) does not hold up work that never looks at its output (the next sidereal
+    # day's transform and solves).
     @property
     def _dev(self):
-        if self._pending is not None:
-            act, self._pending = self._pending, None
-            act()
+        p = self._pending
+        if p is not None:
+            if p.done():
+                self._pending = None
+            else:
+                p.order()
         return self._dev_t
 
     @_dev.setter
@@ -253,7 +259,7 @@ class ContainerBase:
 
     def attach(self, name, dev_tensor, pending=None):
         """Attach a device tensor as dataset ``name`` (shape/dtype checked against the spec).  ``pending``: see
-        :class:`Dataset` -- run once before the first access to the data."""
+        :class:`Dataset` -- orders every reader behind the producer until the producer has finished."""
         spec = self._dataset_spec[name]
         if tuple(dev_tensor.shape) != self.dataset_shape(name):
             raise ValueError(f"{name}: shape {tuple(dev_tensor.shape)} != {self.dataset_shape(name)}")

@@ -160,6 +160,25 @@ class Context:
             pass
 
 
+class StreamDone:
+    """An event recorded behind work on one stream, in the form `containers.Dataset(pending=...)` takes: ``done()``
+    polls it, ``order()`` makes torch's current stream of the device wait for it (no host wait either way)."""
+
+    def __init__(self, stream, device):
+        self.device = device
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+
+    def done(self) -> bool:
+        return bool(self.event.query())
+
+    def order(self):
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+
+    def host_wait(self):
+        self.event.synchronize()
+
+
 def ptr(t) -> C.c_void_p:
     """Raw device pointer of a tensor (``None`` -> NULL)."""
     if t is None:

@@ -315,3 +315,45 @@ def test_back_to_back_days_without_synchronisation():
         outs = [task.process(mm) for mm in days]  # nothing reads a map, nothing synchronises
         for o, r in zip(outs, ref):
             assert np.array_equal(o.map[:], r)
+
+
+def test_host_run_ahead_is_bounded_and_the_allocator_reaches_a_steady_state():
+    """`process` never waits for its own day, but it may not get more than `days_in_flight` days ahead of the GPU: each
+    day in flight holds its own a_lm and maps, and a pipeline that only issues work would otherwise fill the HBM until
+    the caching allocator synchronises and frees its cache (380 instead of 256 ms per day over 20 days).
+    After the first days nothing may be allocated from the device any more."""
+    import torch
+
+    from draco_amd.analysis import mapmaker
+    from draco_amd.analysis.mapmaker import DirtyMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+
+    nfreq, lmax, nside = 8, 48, 64
+    tel = _tel(nfreq, lmax)
+    bt = SyntheticProvider(tel, seed=29)
+    rng = np.random.default_rng(29)
+    mv = rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs)) + 1j * rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs))
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = rng.uniform(0.5, 1.5, mv.shape)
+    per_f = sum(2 * tel.npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * 16
+    task = DirtyMapMaker(nside=nside, pool_bytes=int(2.2 * per_f))
+    task.setup(bt)
+    ref = task.process(mm).map[:].copy()
+    for _ in range(8):
+        task.process(mm)
+    torch.cuda.synchronize()
+    s0 = torch.cuda.memory_stats()
+    last = None
+    for _ in range(40):
+        last = task.process(mm)
+        q = mapmaker._IN_FLIGHT[0]
+        assert len(q) <= task.days_in_flight
+        # everything older than the days still listed has finished: the host is at most days_in_flight days ahead
+    s1 = torch.cuda.memory_stats()
+    assert s1["num_alloc_retries"] == s0["num_alloc_retries"]
+    # steady state: what the 40 days reserved on top of the warm-up is less than ONE more day's a_lm + maps
+    day_bytes = nfreq * 4 * ((lmax + 1) ** 2 * 16 + 12 * nside**2 * 8)
+    assert s1["reserved_bytes.all.current"] - s0["reserved_bytes.all.current"] < day_bytes, (s0["reserved_bytes.all.current"], s1["reserved_bytes.all.current"])
+    assert np.array_equal(last.map[:], ref)

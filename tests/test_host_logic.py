@@ -174,24 +174,38 @@ def test_container_save_load_round_trip(tmp_path):
         containers.Map.load(g)
 
 
-def test_dataset_pending_action_runs_once_at_first_data_access():
-    """A producer may hand out a dataset whose device copy is still being written on another stream, with the action
-    that orders the reader behind it (containers.Dataset `pending`): shape / dtype queries must not trigger it, the
-    first access to the data must, exactly once."""
+def test_dataset_pending_orders_every_reader_until_the_producer_has_finished():
+    """A producer may hand out a dataset whose device copy is still being written on another stream, with the object
+    that orders a reader behind it (containers.Dataset `pending`: `done()` / `order()`): shape / dtype queries must not
+    trigger it; EVERY access to the data orders the stream current at that moment while the producer is still running
+    (a second reader on another stream is ordered too), and none once it has finished."""
     import torch
 
     from draco_amd.core import containers
 
-    calls = []
+    class Producer:
+        finished = False
+        orders = 0
+
+        def done(self):
+            return self.finished
+
+        def order(self):
+            self.orders += 1
+
+    prod = Producer()
     t = torch.arange(6, dtype=torch.float64).reshape(2, 3)
-    ds = containers.Dataset(dev=t, pending=lambda: calls.append(1))
+    ds = containers.Dataset(dev=t, pending=prod)
     assert ds.shape == (2, 3) and ds.dtype == np.float64 and ds.on_device
-    assert calls == []
+    assert prod.orders == 0
+    ds._dev
+    ds._dev  # (a second reader, possibly on another stream)
+    assert prod.orders == 2
+    prod.finished = True
     assert ds[1, 2] == 5.0
-    assert calls == [1]
     np.asarray(ds)
     ds._dev
-    assert calls == [1]
+    assert prod.orders == 2 and ds._pending is None
 
 
 def _ss_container():
