@@ -123,6 +123,7 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   if (!strcmp(name, "ml_tiles_direct")) *value = c->ml_tiles_direct;
   else if (!strcmp(name, "ml_tiles_eigen")) *value = c->ml_tiles_eigen;
   else if (!strcmp(name, "ml_tiles_ql_failed")) *value = c->ml_tiles_ql_failed;
+  else if (!strcmp(name, "ml_early_chunks")) *value = c->ml_early_chunks;
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_get_counter: unknown counter '%s'", name);
   return DMM_OK;
 }

@@ -41,6 +41,7 @@ struct dmm_ctx {
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
   int64_t ml_tiles_ql_failed = 0;          // ... of the latter: QL gave up, the tile was redone by the Jacobi solver
+  int64_t ml_early_chunks = 0;             // reject chunks decomposed on the end-of-workspace slots under the direct batches
   unsigned long long* ticket = nullptr;    // ring of task counters for the dirty kernel's dynamic hand-out
   unsigned ticket_seq = 0;
   void* scratch = nullptr;                 // grow-only workspace (ring coefficients, Gram matrices ...)

@@ -592,8 +592,12 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   q += (size_t)cap * sizeof(double);
   dmm_tile* const tiles_d = (dmm_tile*)q;
   q += (size_t)cap * sizeof(dmm_tile);
+  // column-block prefix sums of the back-projections: nmat + 1 entries per user.  Users that can be in flight together
+  // get disjoint ranges: a synchronous / direct batch at slot offset `off` uses [off, off + nmat], the chunk in slot h
+  // [slot_off[h] + 1 + h, ... + nmat] -- with the early-reject layout (direct batches in [0, cap_direct), chunk slots
+  // behind) a FULL direct batch ends at work_d[cap_direct] and slot 0 starts one entry later: cap + 3 entries in all.
   int32_t* const work_d = (int32_t*)q;
-  q += (((size_t)cap + 2) & ~(size_t)1) * sizeof(int32_t);
+  q += (((size_t)cap + 4) & ~(size_t)1) * sizeof(int32_t);
   int* const fail_d = (int*)q;
   q += (((size_t)cap + 1) & ~(size_t)1) * sizeof(int);
   int* const msel_d = (int*)q;
@@ -895,7 +899,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     p.A = base.A + off * L.Np * L.Np;
     p.wbuf = base.wbuf + off * L.N;
     dmm_tile* const tiles_h = tiles_d + off;
-    int32_t* const work_h = work_d + off + h;
+    int32_t* const work_h = work_d + off + 1 + h;
     int* const fail_hd = fail_d + off;
     double2* const Vb = Vbuf + off * 2 * L.Np * L.Np;
     double2* const Wv = Whbuf + off * (L.Np / 64) * TB * TB;
@@ -1098,6 +1102,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     }
     if ((chunk_no & 1) != slot) ++chunk_no;
     int rc = eigen_list(list, sky, np_sky);  // one chunk, in slot `slot`
+    ++ctx->ml_early_chunks;
     list.clear();
     return rc;
   };

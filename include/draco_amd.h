@@ -80,7 +80,8 @@ int dmm_ctx_sync(dmm_ctx* ctx);
 int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
 /* diagnostics counters, cumulative per context: "ml_tiles_direct" (tiles whose pseudo-inverse was
  * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed), "ml_tiles_ql_failed"
- * (of those: tridiagonal QL did not converge, the tile was redone by the blocked Jacobi solver) */
+ * (of those: tridiagonal QL did not converge, the tile was redone by the blocked Jacobi solver), "ml_early_chunks"
+ * (chunks of early-known rejects decomposed beside the remaining certificate batches) */
 int dmm_ctx_get_counter(dmm_ctx* ctx, const char* name, int64_t* value);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
 int dmm_timer_start(dmm_ctx* ctx);

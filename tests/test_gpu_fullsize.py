@@ -359,3 +359,59 @@ def test_cfg3_ml_low_pass_rate_scheduling_matches_the_eigen_only_pass():
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
     assert np.all(np.isfinite(out))
     assert _rel(out, ref) < 1e-8
+
+
+def test_cfg3_ml_early_reject_chunk_runs_beside_full_direct_batches():
+    """The certificate pass decomposes early-known rejects on two small chunk slots at the END of the workspace while
+    the remaining direct batches keep the front.  Each user of the workspace writes nmat + 1 column-block prefix sums
+    for its back-projection; a FULL direct batch (nmat == cap_direct) ends exactly where chunk slot 0 begins, and the
+    two once shared that entry: the chunk's back-projection, which runs on the second stream after its
+    ~0.1 s QL, then read the batch's total instead of its own zero and wrote tile 0's a_lm to the wrong place.
+    Two cfg-3 frequencies with an 8 GiB workspace (cap ~ 280 matrices, slots of ~35, direct batches of ~210: three
+    full ones for the 648 telescope-side tiles); the weights of ten m near the square tiles span eight decades, so
+    those 20 tiles are rejected in the FIRST direct batch and go to slot 0 under the full batches that follow.  The
+    answer must be the one of the pass that decomposes every tile."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    tel = _tel(3, 2)
+    lmax = tel.lmax
+    bt = SyntheticProvider(tel, seed=34)
+    gen = torch.Generator(device=ctx.device).manual_seed(8)
+    shape = (lmax + 1, 2, 2, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) * 30.0 + 5.0
+    spread = torch.pow(10.0, -8.0 * torch.rand((10, 1, 1, tel.npairs), dtype=torch.float64, device=ctx.device, generator=gen))
+    mw[290:300] *= spread  # ten ill-conditioned m inside the first telescope-side batch (m = 323 downwards)
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    class FixedWorkspace(SolveEngine):
+        def _offer_workspace(self, option, cap_mib):  # (the engine would offer half of the free HBM)
+            _lib.check(_lib.lib.dmm_ctx_set_option(self.ctx.handle, option, 8192))
+
+    eng = FixedWorkspace(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED)
+    try:
+        c0, e0, d0 = counter(b"ml_early_chunks"), counter(b"ml_tiles_eigen"), counter(b"ml_tiles_direct")
+        out = eng.solve("ml", mv, mw, [0, 1], lmax, acond=1e-4, rcond=1e-3).cpu().numpy()
+        early = counter(b"ml_early_chunks") - c0
+        ne, nd = counter(b"ml_tiles_eigen") - e0, counter(b"ml_tiles_direct") - d0
+        assert early >= 1, "the early-reject path was not taken: the test no longer covers what it is for"
+        assert ne + nd == 2 * (lmax + 1) and 20 <= ne <= 70, (ne, nd)
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+        ref = eng.solve("ml", mv, mw, [0, 1], lmax, acond=1e-4, rcond=1e-3).cpu().numpy()
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_workspace_mib", 0))
+    assert np.all(np.isfinite(out))
+    assert _rel(out, ref) < 1e-8
