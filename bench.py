@@ -420,39 +420,60 @@ def main():
     value = scale * (lmax + 1) / (elapsed / args.steps)
     achieved = job.dirty_bytes / (dirty_avg_ms * 1e-3) / 1e9
 
-    # the north star's one collective, after the timed region: all-gather of the rank-local Maps over RCCL
+    # the north star's one collective, after the timed region: all-gather of the rank-local Maps over RCCL.
+    # It must never cost the headline: (1) rank 0 leaves a copy of the headline on stderr before the first collective
+    # of the measurement, (2) every rank first checks ALONE that it can hold the gathered map (the one realistic
+    # failure: N x 6.4 GB next to everything else) and the ranks AGREE on going ahead with one all-reduce, so that no
+    # rank enters a collective the others skip, (3) what fails after that is recorded and agreed on the same way.
     gather = None
     if world > 1 and not args.no_allgather:
+        if rank == 0:
+            print("headline before the all-gather measurement: " + json.dumps({"value": value, "ms_per_step": ms_per_step, "n_gpus": world, "steps": args.steps}), file=sys.stderr, flush=True)
 
-        def measure_allgather():
+        def all_ok(ok):
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
+
+        err = None
+        try:
             _solve.release_pools()  # the gathered map of a weak-scaled job is N x 6.4 GB: make room first
-            shard_bytes = out_map.map._dev.numel() * 8
-            ts = []
-            for _ in range(2):
-                barrier()
-                t0 = time.perf_counter()
-                full = parallel.allgather_map(out_map)
-                barrier()
-                ts.append(time.perf_counter() - t0)
-                nfull = len(full.index_map["freq"])
-                del full
-            tg = allreduce_max(min(ts))
-            return {
-                "allgather_ms": tg * 1e3,
-                "shard_GB": shard_bytes / 1e9,
-                "gathered_GB": shard_bytes * world / 1e9,
-                "frequencies_gathered": nfull,
-                # every rank receives (N-1) shards; in a direct all-gather each arrives over its own xGMI link
-                "GBs_per_link": shard_bytes / tg / 1e9,
-                "GBs_per_gpu_in": shard_bytes * (world - 1) / tg / 1e9,
-                "backend": args.backend,
-                "note": "parallel.allgather_map (one all_gather_into_tensor; RCCL over xGMI under nccl) on the maps of the last timed day, outside the timed region; best of 2",
-            }
-
-        try:  # (never allowed to cost the headline line: a failure is recorded, not raised)
-            gather = measure_allgather()
+            shard = out_map.map._dev
+            shard_bytes = shard.numel() * 8
+            probe = torch.empty((world * shard.shape[0], *shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+            del probe  # (stays in the caching allocator: the gather's own allocation of this size will be served from it)
         except Exception as exc:  # noqa: BLE001
-            gather = {"error": f"{type(exc).__name__}: {exc}"[:400], "backend": args.backend}
+            err = f"{type(exc).__name__}: {exc}"[:400]
+        if not all_ok(err is None):
+            gather = {"skipped": err or "another rank could not hold the gathered map", "backend": args.backend}
+        else:
+            ts, nfull = [], None
+            try:
+                for _ in range(2):
+                    barrier()
+                    t0 = time.perf_counter()
+                    full = parallel.allgather_map(out_map)
+                    barrier()
+                    ts.append(time.perf_counter() - t0)
+                    nfull = len(full.index_map["freq"])
+                    del full
+            except Exception as exc:  # noqa: BLE001  (a failure INSIDE a collective cannot be recovered by the other ranks;
+                err = f"{type(exc).__name__}: {exc}"[:400]  # the stderr copy above is what survives then)
+            if not all_ok(err is None) or not ts:
+                gather = {"error": err or "another rank failed", "backend": args.backend}
+            else:
+                tg = allreduce_max(min(ts))
+                gather = {
+                    "allgather_ms": tg * 1e3,
+                    "shard_GB": shard_bytes / 1e9,
+                    "gathered_GB": shard_bytes * world / 1e9,
+                    "frequencies_gathered": nfull,
+                    # every rank receives (N-1) shards; in a direct all-gather each arrives over its own xGMI link
+                    "GBs_per_link": shard_bytes / tg / 1e9,
+                    "GBs_per_gpu_in": shard_bytes * (world - 1) / tg / 1e9,
+                    "backend": args.backend,
+                    "note": "parallel.allgather_map (one all_gather_into_tensor; RCCL over xGMI under nccl) on the maps of the last timed day, outside the timed region; best of 2",
+                }
 
     traffic = None
     try:  # HBM bytes per launch from the committed PMC profile of this same command, if it matches

@@ -164,6 +164,8 @@ class SolveEngine:
         self.last_b_bytes = 0
         self.fills = 0  # slabs actually filled (the others were resident)
         self.launch_events = None  # set to a list to collect (start, stop, b_bytes, ntile) per Dirty launch
+        self._ws_offer = {}
+        self._ws = None
 
     def close(self):
         for s in self._plans.values():
@@ -243,6 +245,11 @@ class SolveEngine:
             return
         ctx = self.ctx
         ranges = self._slab_ranges(ms, mmax + 1)
+        # plans are keyed by slab range; the ranges follow the HBM budget, which may drift between passes (free memory):
+        # plans of a carving that is not this pass's are dropped instead of piling up with their device tables
+        live = {(key, a, b) for a, b in ranges}
+        for stale in [k for k in self._plans if k not in live]:
+            self._plans.pop(stale).close()
         es = _ELEM[self.b_dtype]
         bufs = _buffers(ctx, self.nbuf, max(self._pool_elems, 1) * es)
         main = torch.cuda.current_stream(ctx.device)
@@ -276,8 +283,10 @@ class SolveEngine:
                 yield s
             finally:
                 s.pool = None  # plans outlive the pass; they must not keep the device's B block alive (release_pools)
-            buf.last_use = torch.cuda.Event()
-            buf.last_use.record(main)
+                # also when the consumer raised or closed the generator after launching: whatever it did enqueue on
+                # `main` reads the buffer, and a later pass must not refill it underneath (recording is free)
+                buf.last_use = torch.cuda.Event()
+                buf.last_use.record(main)
 
     # ---- the four batched operations
     def solve(self, kind, mvis_d, mweight_d, freq_ind, mmax, on_freqs_done=None, **params):
@@ -294,6 +303,8 @@ class SolveEngine:
         n_m = mmax + 1
         alm = torch.empty((nfreq, tel.num_pol_sky, n_m, tel.lmax + 1), dtype=torch.complex128, device=self.ctx.device)
         self.last_b_bytes = 0
+        self._ws_offer = {}
+        self._ws = None
         lib = _lib.lib
         issued, f_done = 0, 0
         for slab in self.slabs(freq_ind, mmax, nfreq, n_m):
@@ -308,7 +319,7 @@ class SolveEngine:
                     self.launch_events.append((e0, e1, slab.b_bytes, slab.ntile))
             elif kind == "wiener":
                 self._offer_workspace(b"wiener_workspace_mib", 24 << 10)  # 0.0649 -> 0.0620 ms per cfg-3 solve against 6 GiB
-                ws = torch.empty(max(int(lib.dmm_wiener_workspace_bytes(slab.plan)), 16), dtype=torch.uint8, device=self.ctx.device)
+                ws = self._workspace(int(lib.dmm_wiener_workspace_bytes(slab.plan)))
                 _lib.check(
                     lib.dmm_wiener_run(
                         slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(mweight_d), float(params["prior_amp"]), float(params["prior_tilt"]), ptr(ws), ptr(alm)
@@ -316,7 +327,7 @@ class SolveEngine:
                 )
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
-                ws = torch.empty(max(int(lib.dmm_ml_workspace_bytes(slab.plan)), 16), dtype=torch.uint8, device=self.ctx.device)
+                ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
                 _lib.check(
                     lib.dmm_ml_run(
                         slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(mweight_d), float(params.get("acond", 1e-4)), float(params.get("rcond", 1e-3)), ptr(ws), ptr(alm)
@@ -328,16 +339,34 @@ class SolveEngine:
             if on_freqs_done is not None and issued // n_m > f_done:
                 on_freqs_done(alm, f_done, issued // n_m)
                 f_done = issued // n_m
+        self._ws = None
         return alm
+
+    def _workspace(self, nbytes):
+        """The pass's workspace: one allocation, reused by every slab it is large enough for (the library drains its
+        own streams before a run returns, and the caller's stream orders the slabs)."""
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.ctx.device)
+        return self._ws
 
     def _offer_workspace(self, option, cap_mib):
         """Let the dense solvers size their sub-batches for the HBM that is actually free (B block, m-modes and a_lm
         are allocated by now): half of it, at most ``cap_mib``.  The ML eigen pass pays a fixed cost per Householder
-        column; with 64 GiB (1400 cfg-3 matrices per half-batch instead of 357) that cost is shared four times wider."""
+        column; with 64 GiB (1400 cfg-3 matrices per half-batch instead of 357) that cost is shared four times wider.
+
+        Decided ONCE per pass (``solve`` clears ``_ws_offer``): the driver's free-memory figure does not count blocks
+        torch holds in its cache, so asking again per slab gave a slightly different size each time -- and a new
+        allocation of tens of GiB per slab.  What torch has reserved but not handed out is ours as well."""
+        if option in self._ws_offer:
+            return
         free, _ = torch.cuda.mem_get_info(self.ctx.device)
+        st = torch.cuda.memory_stats(self.ctx.device)
+        free += max(int(st.get("reserved_bytes.all.current", 0)) - int(st.get("allocated_bytes.all.current", 0)), 0)
         mib = min(int(cap_mib), int(free * 0.5) >> 20)
-        if mib >= 1024:
-            _lib.check(_lib.lib.dmm_ctx_set_option(self.ctx.handle, option, mib))
+        self._ws_offer[option] = mib
+        # (0 = the library's own default: an offer that fell below 1 GiB must not leave an earlier, larger one standing)
+        _lib.check(_lib.lib.dmm_ctx_set_option(self.ctx.handle, option, mib if mib >= 1024 else 0))
 
     def project(self, alm_d, freq_ind, mmax):
         """``vis [mmax+1, 2, nfreq, npairs] = B_m[f] a_m[f]`` (``stream.py:109-112``)."""

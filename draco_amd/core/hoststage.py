@@ -73,6 +73,9 @@ class HostStager:
         copy has been ENQUEUED (not finished): order later work behind an event recorded on ``stream``.
         """
         jobs = list(jobs)
+        for _, nbytes, src in jobs:  # before any worker is started: a producer must never see a truncated view
+            if nbytes > self.slot_bytes and callable(src):
+                raise ValueError(f"staged chunk of {nbytes} bytes exceeds the slot size {self.slot_bytes}")
         staged = [j for j, (_, _, src) in enumerate(jobs) if callable(src)]
         slot_of = {j: k % self.nslot for k, j in enumerate(staged)}
 
@@ -89,8 +92,9 @@ class HostStager:
         ahead = iter(staged)
         inflight = 0
 
-        def feed():
+        def feed(done=0):
             nonlocal inflight
+            inflight -= done
             while inflight < self.nslot:
                 j = next(ahead, None)
                 if j is None:
@@ -99,19 +103,30 @@ class HostStager:
                 inflight += 1
 
         feed()
+        try:
+            self._copy_loop(jobs, futs, feed, pool_u8, stream)
+        except BaseException:
+            # a producer (or a copy) failed: nothing may keep writing into ring slots after the call has returned
+            for f in futs.values():
+                f.cancel()
+            for f in futs.values():
+                try:
+                    f.result()
+                except BaseException:  # noqa: BLE001  (the first failure is the one reported)
+                    pass
+            raise
+
+    def _copy_loop(self, jobs, futs, feed, pool_u8, stream):
         with torch.cuda.stream(stream):
             for j, (dst, nbytes, src) in enumerate(jobs):
-                if nbytes > self.slot_bytes and callable(src):
-                    raise ValueError(f"staged chunk of {nbytes} bytes exceeds the slot size {self.slot_bytes}")
                 if callable(src):
                     s = futs.pop(j).result()
                     pool_u8[dst : dst + nbytes].copy_(self._ring[s * self.slot_bytes : s * self.slot_bytes + nbytes], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(stream)
                     self._free_ev[s] = ev
-                    inflight -= 1
                     self.bytes_staged += nbytes
-                    feed()
+                    feed(done=1)
                 else:
                     pool_u8[dst : dst + nbytes].copy_(src, non_blocking=True)
                     self.bytes_direct += nbytes

@@ -155,3 +155,54 @@ def test_wiener_and_ml_over_streamed_slabs():
         assert eng.fills >= 3
         assert np.abs(out - ref).max() <= tol * np.abs(ref).max()
     _solve.release_pools()
+
+
+def test_stager_rejects_oversized_chunks_before_any_producer_runs_and_drains_on_failure():
+    """`HostStager.upload`: a staged chunk larger than a slot is refused before a single producer has been
+    started (a producer must never be handed a truncated view), and when a producer raises, no other producer of the
+    call is still writing into ring slots after `upload` has returned."""
+    import threading
+    import time
+
+    import torch
+
+    from draco_amd.core.hoststage import HostStager
+
+    st = HostStager(torch.device("cuda", 0), slot_bytes=1 << 16, workers=4)
+    try:
+        pool = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.Stream()
+        calls = []
+
+        def ok(out):
+            calls.append(out.size)
+            out[:] = 7
+
+        with pytest.raises(ValueError, match="exceeds the slot size"):
+            st.upload([(0, 1 << 15, ok), (1 << 15, (1 << 16) + 1, ok)], pool, stream)
+        assert calls == []
+
+        running = []
+        lock = threading.Lock()
+
+        def slow(out):
+            with lock:
+                running.append(1)
+            time.sleep(0.05)
+            out[:] = 1
+            with lock:
+                running.pop()
+
+        def bad(out):
+            raise RuntimeError("producer failed")
+
+        jobs = [(k << 12, 1 << 12, bad if k == 1 else slow) for k in range(12)]
+        with pytest.raises(RuntimeError, match="producer failed"):
+            st.upload(jobs, pool, stream)
+        assert running == []  # everything that had been started has finished; the rest was cancelled
+        # and the stager still works
+        st.upload([(0, 1 << 12, ok)], pool, stream)
+        stream.synchronize()
+        assert int(pool[: 1 << 12].sum()) == 7 * (1 << 12)
+    finally:
+        st._pool.shutdown(wait=True)
