@@ -124,6 +124,49 @@ def _blas_vendor():
         return "unknown"
 
 
+def _cpu_share():
+    """What the box actually grants this process: the cgroup CPU quota (v2 `cpu.max`, v1 `cpu.cfs_quota_us` /
+    `cpu.cfs_period_us`), next to the affinity mask -- a 256-thread host may schedule a one-GPU job on a 16-core share,
+    which is why an arm with 256 processes can be slower than one with 16."""
+    rec = {"cpu_count": os.cpu_count()}
+    try:
+        rec["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        rec["affinity"] = None
+
+    def read(path):
+        try:
+            with open(path) as fh:
+                return fh.read().strip()
+        except Exception:
+            return None
+
+    quota = None
+    v2 = None
+    try:  # cgroup v2: the process's own group, then the root of the mount
+        rel = [ln.split("::", 1)[1].strip() for ln in (read("/proc/self/cgroup") or "").splitlines() if ln.startswith("0::")]
+        for base in ([os.path.join("/sys/fs/cgroup", rel[0].lstrip("/"))] if rel else []) + ["/sys/fs/cgroup"]:
+            v2 = read(os.path.join(base, "cpu.max"))
+            if v2:
+                break
+    except Exception:
+        v2 = None
+    if v2:
+        rec["cgroup_cpu_max"] = v2
+        parts = v2.split()
+        if parts[0] != "max":
+            quota = float(parts[0]) / float(parts[1] if len(parts) > 1 else 100000)
+    else:
+        q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        if q and per:
+            rec["cgroup_cfs_quota_us"], rec["cgroup_cfs_period_us"] = q, per
+            if float(q) > 0:
+                quota = float(q) / float(per)
+    rec["cgroup_quota_cores"] = quota  # None: no quota set (or not readable)
+    rec["loadavg"] = read("/proc/loadavg")
+    return rec
+
+
 def cpu_baseline(cfg, seconds):
     """Oracle (NumPy restatement of the reference) timed on this box's host cores.
 
@@ -212,6 +255,7 @@ def cpu_baseline(cfg, seconds):
         "kind": "port",
         "sample": f"arm '{best_name}' (fastest of {list(arms)}): {best['solves']} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from RAM pools) + the FFT+pack of whole frequencies, {seconds:.0f}s of wall time over all arms, extrapolated linearly to {(lmax+1)*nfreq} solves + {nfreq} frequencies; alm2map not charged to the CPU time (the GPU step includes it)",
         "host_cores_visible": ncpu,
+        "cpu_share": _cpu_share(),
         "blas": _blas_vendor(),
         "arms": arms,
     }

@@ -54,6 +54,30 @@ class _RandomTask(ContainerTask):
         self._rng = value
 
 
+class ReceiverTemperature(ContainerTask):
+    """Add a basic receiver temperature term into the data (``noise.py:21-45``).
+
+    An uncorrelated, frequency and time independent offset: it only reaches the auto-correlations.  The random
+    fluctuations that go with it come from :class:`SampleNoise` afterwards.
+
+    Attributes
+    ----------
+    recv_temp : float
+        The receiver temperature in Kelvin.
+    """
+
+    recv_temp = 0.0
+    _config_names = ("recv_temp",)
+
+    def process(self, data):
+        pairs = _prodstack(data)
+        autos = np.flatnonzero(pairs["input_a"] == pairs["input_b"])
+        vis = data.vis[:]
+        vis[:, autos] += self.recv_temp
+        data.vis[:] = vis
+        return data
+
+
 class GaussianNoise(_RandomTask):
     """Add Gaussian distributed noise to a visibility dataset (``noise.py:178-284``).
 

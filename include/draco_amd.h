@@ -250,6 +250,26 @@ int dmm_synth_beam_fill(dmm_ctx* ctx, const dmm_tile* tiles /*[host]*/, int64_t 
                         int npairs, int npol, int lmax, int b_dtype, int b_layout,
                         uint64_t seed, void* B);
 
+/* ------------------------------------------------ physically structured synthetic beam transfers
+ * Stand-in for the beam transfers driftscan computes from a telescope model [3P; what the reference reads through
+ * bt.beam_m(m, fi=f), mapmaker.py:160-162]: a transit telescope at latitude `lat`, two feed polarisation types with one
+ * complex Jones screen each, a primary beam of widths sigma_e / sigma_n (direction cosines), baselines sep_e / sep_n
+ * (metres east / north).  dmm_beam_screen_maps writes the response maps (A_I, A_Q, A_U, A_V; npol = 1: A_I only) of
+ * `npair` baselines at one wavelength, real parts then imaginary parts:
+ *   maps [dev] double [2, npair, npol, 12 nside^2]  -- the layout dmm_map2alm takes with nfreq = 2 npair.
+ * After dmm_map2alm(niter = 0) of those maps, dmm_beam_screen_pack writes rows s0 .. s0+nc-1 (both signs of m) of every
+ * tile of the list into the pool:  B+ = conj(a_re) + i conj(a_im),  B- = conj(a_re) - i conj(a_im)  (0 for m = 0).
+ *   alm [dev] complex128 [2, nc, npol, mmax_alm+1, lmax+1]
+ * dmm_beam_screen_coeffs returns the 16 plane waves of the screens of a seed (host twin: oracle/synth.py).
+ * sep_e, sep_n, pol_a, pol_b, tiles: host arrays.                                        */
+int dmm_beam_screen_coeffs(uint64_t seed, int32_t* ka /*[16]*/, int32_t* kb, double* cr, double* ci);
+int dmm_beam_screen_maps(dmm_ctx* ctx, int nside, int npol, double wavelength, double lat, uint64_t seed,
+                         double sigma_e, double sigma_n, double eps_gain, double eps_leak, const double* sep_e,
+                         const double* sep_n, const int32_t* pol_a, const int32_t* pol_b, int npair, double* maps);
+int dmm_beam_screen_pack(dmm_ctx* ctx, const void* alm, int nc, int s0, const dmm_tile* tiles /*[host]*/,
+                         int64_t ntile, int npairs, int npol, int lmax, int mmax_alm, int b_dtype, int b_layout,
+                         void* B);
+
 /* dmm_mmode_fill0: for every m the complex median (NumPy's order: real part, then imaginary) of the entries
  * whose weight is non-zero -- the first guess svd_em puts into the missing ones (reference
  * svdfilter.py:176); 0 where nothing is present.  mvis/mweight as below, viewed as [n_m, per_m];

@@ -416,6 +416,13 @@ def gen_noise(out):
     cases["sn_vis_in"] = exp
     cases["sn_vis"] = d2.vis.arr.view(np.ndarray)
     cases["sn_weight"] = d2.weight.arr.view(np.ndarray)
+
+    # ReceiverTemperature (noise.py:21-45): a constant offset on the auto-correlations only (no random draw)
+    r_ = rnoise.ReceiverTemperature.__new__(rnoise.ReceiverTemperature)
+    r_.recv_temp = 42.5
+    d3 = FakeNoiseStream(vis.copy(), w.copy(), 0.390625, prod, ninput)
+    r_.process(d3)
+    cases["rt_vis"] = d3.vis.arr.view(np.ndarray)
     np.savez_compressed(os.path.join(out, "noise.npz"), **cases)
 
 

@@ -111,3 +111,75 @@ def sidereal_inputs(cfg_seed, nfreq, npairs, nra, zero_frac=0.01):
     w = rng.uniform(0.5, 1.5, (nfreq, npairs, nra)).astype(np.float32)
     w[rng.uniform(size=w.shape) < zero_frac] = 0.0
     return vis, w
+
+
+# ------------------------------------------------------------------ physically structured tiles ("beam screens")
+# Twin of csrc/beamscreen.hip (BeamScreenProvider): same model, NumPy arithmetic, the oracle's own SHT.  Not a
+# restatement of reference code -- driftscan's beam transfers are third-party inputs to the path; this is
+# the checker of the library's structured INPUT generator.
+def screen_coeffs(seed):
+    """The 16 plane waves of the two polarisation types' gain / leakage screens: arrays ``[2, 2, 4]``."""
+    ka = np.zeros((2, 2, 4), dtype=np.int64)
+    kb = np.zeros((2, 2, 4), dtype=np.int64)
+    cr = np.zeros((2, 2, 4))
+    ci = np.zeros((2, 2, 4))
+    for t in range(2):
+        for w in range(2):
+            for k in range(4):
+                key = _mix64_int((seed + 0x9E3779B97F4A7C15 * (1 + k + 4 * (w + 2 * t))) & 0xFFFFFFFFFFFFFFFF)
+                ka[t, w, k] = _mix64_int((key + 1) & 0xFFFFFFFFFFFFFFFF) % 7 - 3
+                kb[t, w, k] = _mix64_int((key + 2) & 0xFFFFFFFFFFFFFFFF) % 7 - 3
+                cr[t, w, k] = (2.0 * ((_mix64_int((key + 3) & 0xFFFFFFFFFFFFFFFF) >> 11) * 2.0**-53) - 1.0) / 4
+                ci[t, w, k] = (2.0 * ((_mix64_int((key + 4) & 0xFFFFFFFFFFFFFFFF) >> 11) * 2.0**-53) - 1.0) / 4
+    return ka, kb, cr, ci
+
+
+def screen_jones(model, wavelength, sigma_e):
+    """Per pixel: ``up`` mask, direction cosines (east, north) and the Jones vectors ``e [2 types, 2 comps, npix]``."""
+    from . import sht
+
+    th, ph = sht.pix_angles(model["nside"])
+    nx, ny, nz = np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)
+    lat = np.deg2rad(model["latitude"])
+    cz = nx * np.cos(lat) + nz * np.sin(lat)
+    ce = ny
+    cn = -nx * np.sin(lat) + nz * np.cos(lat)
+    up = cz > 0
+    env = np.where(up, np.sqrt(np.where(up, cz, 0.0)) * np.exp(-0.5 * ce**2 / sigma_e**2) * np.exp(-0.5 * cn**2 / model["sigma_n"] ** 2), 0.0)
+    ka, kb, cr, ci = screen_coeffs(model["seed"])
+    e = np.zeros((2, 2, th.size), dtype=np.complex128)
+    for t in range(2):
+        scr = [sum((cr[t, w, k] + 1j * ci[t, w, k]) * np.exp(1j * np.pi * (ka[t, w, k] * ce + kb[t, w, k] * cn)) for k in range(4)) for w in range(2)]
+        g = env * (1.0 + model["eps_gain"] * scr[0])
+        e[t, t] = g
+        e[t, 1 - t] = g * (model["eps_leak"] * scr[1])
+    return up, ce, cn, e
+
+
+def screen_response(model, wavelength, sigma_e, s, npol=4):
+    """Complex response maps ``[npol, npix]`` (A_I, A_Q, A_U, A_V) of unique pair ``s``."""
+    up, ce, cn, e = screen_jones(model, wavelength, sigma_e)
+    a, b = int(model["pol_a"][s]), int(model["pol_b"][s])
+    ph = np.exp(2j * np.pi * (model["sep_e"][s] * ce + model["sep_n"][s] * cn) / wavelength)
+    c = lambda i, j: np.conj(e[a, i]) * e[b, j] * ph  # noqa: E731
+    A = np.stack([0.5 * (c(0, 0) + c(1, 1)), 0.5 * (c(0, 0) - c(1, 1)), 0.5 * (c(0, 1) + c(1, 0)), 0.5j * (c(1, 0) - c(0, 1))])
+    return np.where(up, A, 0.0)[:npol]
+
+
+def screen_tile(model, freq_mhz, m, lmax, npol=4, sigma_e_600=None):
+    """Tile ``[2, npairs, npol, lmax+1]`` of the beam-screen model at one frequency (MHz) and m."""
+    from . import sht
+
+    wavelength = 299.792458 / float(freq_mhz)
+    sigma_e = (model["sigma_e"] if sigma_e_600 is None else sigma_e_600) * wavelength / (299.792458 / 600.0)
+    npairs = len(model["sep_e"])
+    out = np.zeros((2, npairs, npol, lmax + 1), dtype=np.complex128)
+    for s in range(npairs):
+        A = screen_response(model, wavelength, sigma_e, s, npol)
+        ar = sht.map2alm(A.real, lmax, niter=0)  # [npol, l, m]
+        ai = sht.map2alm(A.imag, lmax, niter=0)
+        out[0, s] = np.conj(ar[:, :, m]) + 1j * np.conj(ai[:, :, m])
+        if m > 0:
+            out[1, s] = np.conj(ar[:, :, m]) - 1j * np.conj(ai[:, :, m])
+    out[..., :m] = 0.0
+    return out

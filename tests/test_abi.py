@@ -59,3 +59,26 @@ def test_argument_errors():
     h = ctypes.c_void_p(1)  # a non-NULL ctx is not dereferenced before the argument checks
     with pytest.raises(ValueError, match="NULL argument"):
         _lib.check(_lib.lib.dmm_mfft_pack(h, None, 1, 8, None, 4, 1, None))
+
+
+def test_beam_screen_coefficients_match_the_oracle_twin():
+    """`dmm_beam_screen_coeffs` is a pure host function: the plane waves of the beam screens of a seed must be the
+    ones the oracle's twin draws (oracle/synth.py::screen_coeffs) -- the hash, the integer wave numbers, the scaling."""
+    import ctypes as C
+
+    import numpy as np
+
+    from draco_amd import _lib
+    from oracle import synth as osyn
+
+    for seed in (0, 77, 3005, 2**63 + 12345):
+        ka = np.zeros(16, np.int32)
+        kb = np.zeros(16, np.int32)
+        cr = np.zeros(16)
+        ci = np.zeros(16)
+        vp = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        _lib.check(_lib.lib.dmm_beam_screen_coeffs(seed, vp(ka), vp(kb), vp(cr), vp(ci)))
+        rka, rkb, rcr, rci = osyn.screen_coeffs(seed)
+        assert np.array_equal(ka, rka.reshape(-1)) and np.array_equal(kb, rkb.reshape(-1))
+        assert np.array_equal(cr, rcr.reshape(-1)) and np.array_equal(ci, rci.reshape(-1))
+        assert np.all(np.abs(ka) <= 3) and np.all(np.abs(cr) <= 0.25)

@@ -16,6 +16,22 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
+def _check_rows_against_oracle_svd(out, seed, mv, mw, f_bt, f_data, ms, tol):
+    """Rows (m) of a BATCHED pass against the oracle's SVD solve (``pinv_svd`` restated, mapmaker.py:184-201,287-300)
+    on the same tiles: the batch scheduler (half-batches, deferred orders, probes, chunk slots) is between the two."""
+    from oracle import mapmaker as omm
+
+    mv_h, mw_h = mv[:, :, f_data].cpu().numpy(), mw[:, :, f_data].cpu().numpy()
+    npairs, lmax = mv_h.shape[-1], out.shape[-1] - 1
+    worst = 0.0
+    for m in ms:
+        full = osyn.beam_tile(seed, int(m), f_bt, npairs, 4, lmax)
+        ref = omm.ml_solve(full, mv_h[m], mw_h[m])
+        worst = max(worst, _rel(out[f_data, :, m, :], ref))
+    assert worst < tol, worst
+    return worst
+
+
 def _tel(cfg, nfreq):
     from draco_amd.core.products import TransitTelescope
 
@@ -235,6 +251,8 @@ def test_cfg3_ml_eigen_pass_mixes_pipelined_and_synchronous_batches():
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_eigen", 0))
     assert np.all(np.isfinite(out[0]))
     assert _rel(out[0], out[1]) < 1e-9
+    # and the batched pass against the oracle's SVD on sampled rows: telescope side, near-square, sky side
+    _check_rows_against_oracle_svd(out[0], 31, mv, mw, 0, 0, (0, 77, 200, 310, 322, 324, 331, 400, 470, 512), 1e-8)
 
 
 @pytest.mark.parametrize("nfeed_cyl,np_expected", [(33, 832), (70, 1728), (90, 2176)])
@@ -359,6 +377,9 @@ def test_cfg3_ml_low_pass_rate_scheduling_matches_the_eigen_only_pass():
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
     assert np.all(np.isfinite(out))
     assert _rel(out, ref) < 1e-8
+    # sampled rows of the scheduled pass against the oracle's SVD.  The weights span eight decades: modes just above the
+    # reference's cut are amplified by up to 1 / acond^2, so agreement is looser than on well-conditioned tiles
+    _check_rows_against_oracle_svd(out, 33, mv, mw, 0, 0, (0, 50, 150, 250, 321, 323, 326, 380, 450, 505), 1e-6)
 
 
 def test_cfg3_ml_early_reject_chunk_runs_beside_full_direct_batches():
@@ -415,3 +436,6 @@ def test_cfg3_ml_early_reject_chunk_runs_beside_full_direct_batches():
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_workspace_mib", 0))
     assert np.all(np.isfinite(out))
     assert _rel(out, ref) < 1e-8
+    # rows of both frequencies against the oracle's SVD: certified tiles, the ill-conditioned ones of the early chunk, sky side
+    _check_rows_against_oracle_svd(out, 34, mv, mw, 0, 0, (0, 120, 291, 296, 322, 330, 500), 1e-6)
+    _check_rows_against_oracle_svd(out, 34, mv, mw, 1, 1, (3, 240, 293, 299, 323, 410), 1e-6)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from draco_amd.core import containers
-from draco_amd.synthesis.noise import GaussianNoise, SampleNoise
+from draco_amd.synthesis.noise import GaussianNoise, ReceiverTemperature, SampleNoise
 from draco_amd.util import random
 
 
@@ -80,3 +80,14 @@ def test_sample_noise_task(golden_dir):
     t.process(ss)
     np.testing.assert_allclose(ss.vis[:], g["sn_vis"], rtol=1e-12)
     np.testing.assert_allclose(ss.weight[:], g["sn_weight"], rtol=1e-12)
+
+
+def test_receiver_temperature_task(golden_dir):
+    """ReceiverTemperature.process (noise.py:21-45) against the reference class run from source: the offset reaches the
+    auto-correlations only."""
+    g = np.load(os.path.join(golden_dir, "noise.npz"))
+    ss = _stream(g["gn_vis_in"].copy(), np.ones(g["gn_vis_in"].shape, np.float32), 3)
+    t = ReceiverTemperature(recv_temp=42.5)
+    out = t.process(ss)
+    assert out is ss
+    assert np.array_equal(ss.vis[:], g["rt_vis"])
