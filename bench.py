@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3, help="sidereal days timed")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, help="SURVEY 8d config number (metric is quoted on 3)")
+    ap.add_argument("--maker", default="dirty", choices=["dirty", "ml", "wiener"], help="map-maker of the timed day (the headline metric is quoted on dirty; cfg 3 of BASELINE.json names ml)")
+    ap.add_argument("--tiles", default=None, choices=["random", "screen"], help="B tile source: counter-hash tiles (SyntheticProvider) or physically structured ones (BeamScreenProvider); default: random for dirty, screen for ml / wiener")
+    ap.add_argument("--freqs", type=int, default=0, help="ml / wiener: frequencies of the timed day (0 = all of the config's; fewer = a stated sample, scaled)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--b-dtype", default="complex128", choices=["complex128", "complex64"])
     ap.add_argument("--pool-freqs", type=int, default=0, help="frequencies' worth of distinct B tiles resident (0 = auto)")
@@ -261,6 +264,252 @@ def cpu_baseline(cfg, seconds):
     }
 
 
+def _cpu_dense_worker(args):
+    """One single-threaded process of a multi-process CPU arm of the dense map-makers: ML (SVD pseudo-inverse) or
+    Wiener (Hermitian-PD solve) on its own tiles until the budget is spent."""
+    kind, seed, npairs, lmax, ms, budget = args
+    from oracle import mapmaker as omm
+    from oracle import synth as osyn
+
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((2, npairs)) + 1j * rng.standard_normal((2, npairs))
+    Ni = rng.uniform(0.5, 1.5, (2, npairs)) * 20
+    n, spent = 0, 0.0
+    while n < 1 or spent < budget:
+        m = int(ms[n % len(ms)])
+        bm = osyn.beam_tile(3000, m, seed % 7, npairs, 4, lmax)  # (tile generation is not charged)
+        t1 = time.perf_counter()
+        omm.ml_solve(bm, v, Ni) if kind == "ml" else omm.wiener_solve(bm, m, v, Ni, 1.0, 0.5)
+        spent += time.perf_counter() - t1
+        n += 1
+    return n, spent
+
+
+def cpu_baseline_dense(cfg, kind, seconds):
+    """The oracle's ML (``pinv_svd`` restated: scipy.linalg.svd of the 758 x 2052 tile, mapmaker.py:184-201,287-300) or
+    Wiener solve (Hermitian-PD solve of the smaller normal system, mapmaker.py:235-284) timed on this box's host cores,
+    on an m-stratified sample of cfg-3 tiles, extrapolated linearly to the day's solves.  Arms as for the Dirty
+    baseline: 1 thread; one process with every BLAS thread; 16 single-threaded processes.  Tile contents are the
+    counter-hash tiles (LAPACK's cost does not depend on them; generating structured tiles on the host would cost more
+    than the solves); generation time is excluded.  The m-mode transform is negligible next to these solves and is not
+    charged."""
+    from oracle import mapmaker as omm
+    from oracle import synth as osyn
+
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        ncpu = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    import contextlib
+
+    npairs = osyn.npairs_of(cfg["ncyl"], cfg["nfeed_cyl"])
+    nfreq, lmax = cfg["nfreq"], cfg["lmax"]
+    ms = np.unique(np.linspace(0, lmax, 9).astype(int))  # stratified in m: the cost of both solvers depends on it
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal((2, npairs)) + 1j * rng.standard_normal((2, npairs))
+    Ni = rng.uniform(0.5, 1.5, (2, npairs)) * 20
+    budget = seconds / 3
+
+    def arm(nthreads):
+        cm = threadpool_limits(limits=nthreads) if threadpool_limits is not None else contextlib.nullcontext()
+        spent, n = 0.0, 0
+        with cm:
+            while n < len(ms) and (n < 2 or spent < budget):  # one pass over the strata at most, at least two solves
+                bm = osyn.beam_tile(3000, int(ms[n]), 0, npairs, 4, lmax)
+                t0 = time.perf_counter()
+                omm.ml_solve(bm, v, Ni) if kind == "ml" else omm.wiener_solve(bm, int(ms[n]), v, Ni, 1.0, 0.5)
+                spent += time.perf_counter() - t0
+                n += 1
+        return spent / n, n
+
+    arms = {}
+    t1, n1 = arm(1)
+    arms["1_thread"] = {"cores": 1, "ms_per_solve": t1 * 1e3, "solves": n1}
+    if threadpool_limits is not None and ncpu > 1:
+        tn, nn = arm(ncpu)
+        arms[f"{ncpu}_blas_threads"] = {"cores": ncpu, "ms_per_solve": tn * 1e3, "solves": nn}
+    nproc = min(ncpu, 16)
+    if nproc > 1:
+        try:
+            import multiprocessing as mp
+
+            keys = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+            saved = {k: os.environ.get(k) for k in keys}
+            os.environ.update({k: "1" for k in keys})
+            try:
+                with mp.get_context("spawn").Pool(nproc) as pool:
+                    res = pool.map(_cpu_dense_worker, [(kind, 100 + i, npairs, lmax, np.roll(ms, i), budget) for i in range(nproc)], chunksize=1)
+            finally:
+                for k, v_ in saved.items():
+                    os.environ.pop(k, None) if v_ is None else os.environ.__setitem__(k, v_)
+            rate = sum(n / t for n, t in res)
+            arms[f"{nproc}_processes"] = {"cores": nproc, "ms_per_solve": 1e3 / rate, "solves": sum(n for n, _ in res)}
+        except Exception as e:  # the baseline must never break the bench line
+            print(f"cpu_baseline_dense: {nproc}-process arm failed: {e!r}", file=sys.stderr)
+    for a in arms.values():
+        a["job_seconds"] = a["ms_per_solve"] * 1e-3 * (lmax + 1) * nfreq
+        a["m_modes_per_s"] = (lmax + 1) / a["job_seconds"]
+    best_name = min(arms, key=lambda k: arms[k]["job_seconds"])
+    best = arms[best_name]
+    what = "scipy.linalg.svd pseudo-inverse (pinv_svd restated)" if kind == "ml" else "Hermitian-PD solve of the smaller normal system"
+    return {
+        "value": best["m_modes_per_s"], "unit": "m-modes/s", "cores": int(best["cores"]), "kind": "port",
+        "sample": f"arm '{best_name}' (fastest of {list(arms)}): {best['solves']} {kind} solves ({what}) on {2*npairs} x {4*(lmax+1)} counter-hash tiles stratified over m = {ms.tolist()}, extrapolated linearly to {(lmax+1)*nfreq} solves; tile generation, the m-mode transform and alm2map not charged",
+        "host_cores_visible": ncpu, "cpu_share": _cpu_share(), "blas": _blas_vendor(), "arms": arms,
+    }
+
+
+def dense_flops(cfg, npairs):
+    """Useful FP64 flops of ONE frequency of a dense map-maker at the config's sizes: the Hermitian half of the smaller
+    Gram matrix of every (m, f) tile, 8 k^2 K / 2, and the factorisation (8/3) k^3."""
+    lmax, ntel = cfg["lmax"], 2 * npairs
+    gram = chol = 0.0
+    for m in range(lmax + 1):
+        nsky = 4 * (lmax + 1 - m)
+        k, K = min(ntel, nsky), max(ntel, nsky)
+        gram += 4.0 * k * k * K
+        chol += (8.0 / 3.0) * k**3
+    return gram, chol
+
+
+def main_dense(args, cpu):
+    """`--maker ml|wiener`: one cfg-3 day through MModeTransform.process + {MaximumLikelihood,Wiener}MapMaker.process
+    (single GPU), B tiles resident under the hbm-pool policy, physically structured by default."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd import workloads as wl
+    from draco_amd.analysis import _solve
+    from draco_amd.analysis.mapmaker import DirtyMapMaker, MaximumLikelihoodMapMaker, WienerMapMaker
+    from draco_amd.analysis.transform import MModeTransform
+    from draco_amd.core import containers
+    from draco_amd.core.products import BeamScreenProvider, PoolCycledProvider, SyntheticProvider, TransitTelescope
+    from draco_amd.device import Context
+
+    torch.cuda.set_device(0)
+    ctx = Context.get()
+    cfg = wl.CONFIGS[args.config]
+    kind = args.maker
+    tiles = args.tiles or "screen"
+    nfreq_cfg, nra, lmax, nside = cfg["nfreq"], cfg["nra"], cfg["lmax"], cfg["nside"]
+    nfreq = args.freqs if args.freqs > 0 else nfreq_cfg
+    pool_freqs = args.pool_freqs if args.pool_freqs > 0 else 16  # 102 GB of distinct tiles; leaves the solvers their workspace
+    pool_freqs = min(pool_freqs, nfreq)
+    while nfreq % pool_freqs:
+        pool_freqs -= 1
+    tel = TransitTelescope(wl.frequencies(nfreq_cfg)[:nfreq], lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+    npairs = tel.npairs
+    es = 16 if args.b_dtype == "complex128" else 8
+    per_freq = sum(2 * npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * es
+    base = BeamScreenProvider(tel, seed=3003) if tiles == "screen" else SyntheticProvider(tel, seed=3003)
+    bt = PoolCycledProvider(base, pool_freqs)
+    gen = torch.Generator(device=ctx.device).manual_seed(1000)
+    vis = torch.randn((nfreq, npairs, nra), dtype=torch.complex64, device=ctx.device, generator=gen)
+    weight = (torch.rand((nfreq, npairs, nra), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5) * 20.0
+    weight[torch.rand(weight.shape, dtype=torch.float32, device=ctx.device, generator=gen) < 0.01] = 0.0
+    ss = containers.SiderealStream(freq=tel.frequencies, ra=nra, stack=npairs, allocate=False)
+    ss.attach("vis", vis)
+    ss.attach("vis_weight", weight)
+    mt = MModeTransform()
+    mt.setup(bt)
+    cls = MaximumLikelihoodMapMaker if kind == "ml" else WienerMapMaker
+    task = cls(nside=nside, b_dtype=args.b_dtype, pool_bytes=pool_freqs * per_freq + (1 << 20))
+    task.setup(bt)
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    # B resident before the clock starts: a Dirty pass over the first slab fills the pool (the engines of equal providers share it)
+    t_fill0 = time.perf_counter()
+    warm = DirtyMapMaker(nside=nside, b_dtype=args.b_dtype, pool_bytes=pool_freqs * per_freq + (1 << 20))
+    warm.setup(bt)
+    mm0 = mt.process(ss)
+    warm.make_alm(mm0)
+    torch.cuda.synchronize()
+    t_fill = time.perf_counter() - t_fill0
+    del warm, mm0
+    for _ in range(args.warmup):
+        task.process(mt.process(ss))
+    torch.cuda.synchronize()
+    eng = task._get_engine()
+    fills_before = eng.fills
+    _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
+    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed")}
+    mem0 = torch.cuda.memory_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_map = task.process(mt.process(ss))
+    out_map.map._dev  # (orders this stream behind the side-stream SHT)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mem1 = torch.cuda.memory_stats()
+    prof = {k: {"ms": counter(f"prof_{k}_us".encode()) / 1e3 / args.steps, "spans": counter(f"prof_{k}_n".encode()) // max(args.steps, 1)}
+            for k in ("gram", "chol", "tridiag", "band", "ql", "backproj")}
+    _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
+    c1 = {k: counter(k) for k in c0}
+    assert eng.fills == fills_before or args.warmup == 0, "B was generated inside the timed region"
+
+    day_s = elapsed / args.steps
+    scale = nfreq_cfg / nfreq  # a frequency sample is scaled to the config's day (frequencies are independent)
+    value = (lmax + 1) / (day_s * scale)
+    gram_fl, chol_fl = dense_flops(cfg, npairs)
+    gram_tf = gram_fl * nfreq / (prof["gram"]["ms"] * 1e-3) / 1e12 if prof["gram"]["ms"] > 0 else None
+    n_direct = (c1[b"ml_tiles_direct"] - c0[b"ml_tiles_direct"]) // max(args.steps, 1)
+    n_eigen = (c1[b"ml_tiles_eigen"] - c0[b"ml_tiles_eigen"]) // max(args.steps, 1)
+    secondary = []
+    if kind == "ml" and (prof["tridiag"]["ms"] > 0 or prof["band"]["ms"] > 0):
+        ntel = 2 * npairs
+        # one-stage Householder reduction: every column sweeps the upper triangle of its trailing matrix once, 16 B read
+        # per element and 16 B more on the sweeps that apply the pending rank-2 updates (every fourth): n^3/6 * 20 B
+        red_ms = prof["tridiag"]["ms"] + prof["band"]["ms"]
+        by = 0.0
+        for m in range(lmax + 1):
+            k = min(ntel, 4 * (lmax + 1 - m))
+            by += k**3 / 6.0 * 20.0
+        by *= nfreq * (n_eigen / max(n_direct + n_eigen, 1))
+        secondary.append({"kernel": "Hermitian tridiagonal reduction of the decomposed tiles (k_td_col + k_td_trail_tri; two-stage: dense -> band -> tridiagonal)",
+                          "bound": "hbm", "achieved": by / (red_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": by / (red_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_day": red_ms,
+                          "note": "bytes = the ONE-STAGE algorithm's n^3/6 * 20 B per decomposed tile (the yardstick VERDICT r2 used); a two-stage reduction moves fewer bytes, its fraction on this yardstick may exceed what its own traffic would give"})
+    out = {
+        "metric": f"m-modes/sec through MModeTransform+{cls.__name__} (128-feed, 256-freq)",
+        "value": value, "unit": "m-modes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": day_s * scale * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 (Gram / factorisations / eigen-solve); B stored " + args.b_dtype + "; FFT complex64 (as the reference)",
+        "data": "synthetic",
+        "config": {
+            "workload": f"cfg{args.config}: {tel.nfeed}-feed ({npairs} stacked baselines), {nfreq} of {nfreq_cfg} freq timed" + (f" (scaled x{scale:g} to the day)" if scale != 1 else "") + f", {nra} RA, lmax=mmax={lmax}: MModeTransform.process + {cls.__name__}.process through the task classes ({(lmax+1)*nfreq} (m,f) solves + alm2map to nside={nside})",
+            "tiles": ("physically structured (BeamScreenProvider: per-polarisation Jones screens, narrow east-west primary beam; ill-conditioned Gram matrices like real products)" if tiles == "screen" else "counter-hash (SyntheticProvider: best-conditioned tiles possible)"),
+            "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}; generated on the GPU in {t_fill:.1f} s before the clock starts",
+            "solves_per_s": (lmax + 1) * nfreq / day_s,
+            "ms_per_solve": day_s * 1e3 / ((lmax + 1) * nfreq),
+            "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "ql_failed": c1[b"ml_tiles_ql_failed"] - c0[b"ml_tiles_ql_failed"]} if kind == "ml" else None,
+        },
+        "roofline": {
+            "kernel": "k_nt<GRAM/GRAMX> (Hermitian products D B B^H D / B^H N B on v_mfma_f64_16x16x4_f64)",
+            "bound": "mfma", "achieved": gram_tf, "peak": 78.6, "unit": "TFLOP/s",
+            "frac": gram_tf / 78.6 if gram_tf else None, "traffic": None,
+            "flops_per_day": gram_fl * nfreq_cfg, "ms_per_day_timed": prof["gram"]["ms"],
+            "note": "useful flops (one Hermitian half-product of the smaller side per tile: 8 k^2 K / 2) / HIP-event time of every Gram launch of the timed day on its launch stream ('profile' option of the library); tiles whose certificate is rejected form their Gram matrix twice, so the fraction is a lower bound then",
+        },
+        "roofline_secondary": secondary,
+        "kernel_classes_ms_per_day_timed": prof,
+        "allocator": {"num_alloc_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
+                      "reserved_peak_GB": mem1.get("reserved_bytes.all.peak", 0) / 1e9},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
 class Job:
     """One rank's share of the job, held as the product's own containers and task objects."""
 
@@ -380,7 +629,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from draco_amd import workloads as _wl  # (the oracle is imported inside cpu_baseline only)
 
-        cpu = cpu_baseline(_wl.CONFIGS[args.config], args.cpu_seconds)  # before any GPU work: it spawns processes
+        if args.maker == "dirty":
+            cpu = cpu_baseline(_wl.CONFIGS[args.config], args.cpu_seconds)  # before any GPU work: it spawns processes
+        else:
+            cpu = cpu_baseline_dense(_wl.CONFIGS[args.config], args.maker, max(args.cpu_seconds, 24.0))
+    if args.maker != "dirty":
+        if world != 1:
+            raise SystemExit("--maker ml / wiener is a single-GPU measurement (frequencies are independent: shard them as the Dirty job does)")
+        return main_dense(args, cpu)
 
     import torch
     import torch.distributed as dist

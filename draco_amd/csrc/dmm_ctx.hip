@@ -14,6 +14,22 @@ int dmm_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
+static const char* const kProfNames[DMM_PROF_NSLOT] = {"gram", "chol", "tridiag", "ql", "backproj", "band"};
+
+// read every finished span into the per-class sums (waits for spans still running)
+static void prof_collect(dmm_ctx* c) {
+  for (dmm_prof_span& sp : c->prof_open) {
+    float ms = 0.f;
+    if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      c->prof_us[sp.slot] += 1e3 * (double)ms;
+      ++c->prof_n[sp.slot];
+    }
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  c->prof_open.clear();
+}
+
 int dmm_get_scratch(dmm_ctx* ctx, size_t bytes, void** out) {
   if (ctx->scratch_bytes < bytes) {
     if (ctx->scratch) {
@@ -81,6 +97,7 @@ int dmm_ctx_destroy(dmm_ctx* c) {
   free_tables(c->ifft);
   for (auto& kv : c->sht)
     if (kv.second) (void)hipFree(kv.second);
+  prof_collect(c);
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->ticket) (void)hipFree(c->ticket);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -114,6 +131,11 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_eigen")) c->opt_ml_eigen = (int)value;
   else if (!strcmp(name, "ml_workspace_mib")) c->opt_ml_ws_mib = value > 0 ? value : 0;
   else if (!strcmp(name, "wiener_workspace_mib")) c->opt_wiener_ws_mib = value > 0 ? value : 0;
+  else if (!strcmp(name, "profile")) {  // (re)start the per-class kernel timing: sums cleared
+    prof_collect(c);
+    for (int k = 0; k < DMM_PROF_NSLOT; ++k) c->prof_us[k] = 0.0, c->prof_n[k] = 0;
+    c->opt_profile = value != 0;
+  }
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_set_option: unknown option '%s'", name);
   return DMM_OK;
 }
@@ -124,6 +146,19 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   else if (!strcmp(name, "ml_tiles_eigen")) *value = c->ml_tiles_eigen;
   else if (!strcmp(name, "ml_tiles_ql_failed")) *value = c->ml_tiles_ql_failed;
   else if (!strcmp(name, "ml_early_chunks")) *value = c->ml_early_chunks;
+  else if (!strncmp(name, "prof_", 5)) {
+    const size_t len = strlen(name);
+    const bool want_n = len > 7 && !strcmp(name + len - 2, "_n");
+    const bool want_us = len > 8 && !strcmp(name + len - 3, "_us");
+    int slot = -1;
+    for (int k = 0; k < DMM_PROF_NSLOT; ++k) {
+      const size_t nl = strlen(kProfNames[k]);
+      if (!strncmp(name + 5, kProfNames[k], nl) && name[5 + nl] == '_' && 5 + nl + (want_n ? 2 : 3) == len) slot = k;
+    }
+    if (slot < 0 || !(want_n || want_us)) return dmm_set_error(DMM_E_ARG, "dmm_ctx_get_counter: unknown counter '%s'", name);
+    prof_collect(c);
+    *value = want_n ? c->prof_n[slot] : (int64_t)(c->prof_us[slot] + 0.5);
+  }
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_get_counter: unknown counter '%s'", name);
   return DMM_OK;
 }

@@ -16,6 +16,14 @@ struct dmm_fft_tables {          // per transform length, built on first use
   float2* bfilt = nullptr;       // [M]   FFT_M(conj chirp, wrapped)/M, bit-reversed order (Bluestein only)
 };
 
+// Kernel classes of the dense solvers that bench.py times live (HIP events on the stream a class is launched on;
+// "profile" option of dmm_ctx_set_option, read back through dmm_ctx_get_counter("prof_<class>_us" / "prof_<class>_n")).
+enum dmm_prof_slot { DMM_PROF_GRAM = 0, DMM_PROF_CHOL, DMM_PROF_TRIDIAG, DMM_PROF_QL, DMM_PROF_BACKPROJ, DMM_PROF_BAND, DMM_PROF_NSLOT };
+struct dmm_prof_span {
+  hipEvent_t a, b;
+  int slot;
+};
+
 struct dmm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -41,6 +49,10 @@ struct dmm_ctx {
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
   int64_t ml_tiles_ql_failed = 0;          // ... of the latter: QL gave up, the tile was redone by the Jacobi solver
+  int opt_profile = 0;                     // 1: dmm_prof_scope records event pairs (bench.py's live kernel timing)
+  std::vector<dmm_prof_span> prof_open;    // spans whose events have not been read yet
+  double prof_us[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0};
+  int64_t prof_n[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0};
   int64_t ml_early_chunks = 0;             // reject chunks decomposed on the end-of-workspace slots under the direct batches
   unsigned long long* ticket = nullptr;    // ring of task counters for the dirty kernel's dynamic hand-out
   unsigned ticket_seq = 0;
@@ -82,6 +94,33 @@ struct dmm_aux_scope {
   ~dmm_aux_scope() {
     if (c && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c && c->aux_stream_b) (void)hipStreamSynchronize(c->aux_stream_b);
+  }
+};
+
+// Times everything enqueued on `st` between construction and destruction as one span of class `slot` (no-op unless the
+// context's "profile" option is set).  Spans on different streams overlap in time: the sums are busy time per class.
+struct dmm_prof_scope {
+  dmm_ctx* c;
+  hipStream_t st;
+  dmm_prof_span sp;
+  bool on;
+  dmm_prof_scope(dmm_ctx* ctx, int slot, hipStream_t stream) : c(ctx), st(stream), on(false) {
+    if (!c->opt_profile) return;
+    sp.slot = slot;
+    if (hipEventCreate(&sp.a) != hipSuccess) return;
+    if (hipEventCreate(&sp.b) != hipSuccess) {
+      (void)hipEventDestroy(sp.a);
+      return;
+    }
+    (void)hipEventRecord(sp.a, st);
+    on = true;
+  }
+  dmm_prof_scope(const dmm_prof_scope&) = delete;
+  dmm_prof_scope& operator=(const dmm_prof_scope&) = delete;
+  ~dmm_prof_scope() {
+    if (!on) return;
+    (void)hipEventRecord(sp.b, st);
+    c->prof_open.push_back(sp);
   }
 };
 

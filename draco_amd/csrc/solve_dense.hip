@@ -519,27 +519,33 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
     DMM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors are reused by the next batch
     const int T = p.T;
     if (sky) {
+      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, ctx->stream);
       p.ldx = ntel;
       p.X = Xbuf;
       hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Xbuf);
       hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
       hipLaunchKernelGGL(k_add_prior_diag, dim3((p.Np + 255) / 256, nmat), dim3(256), 0, ctx->stream, p, (const double*)Sl);
     } else {
+      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, ctx->stream);
       p.Sl = Sl;
       p.Sk = Sk;
       p.sk_pitch = L.sk_pitch;
       p.add_identity = 1;
       hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
     }
-    for (int J = 0; J < T; ++J) {
-      p.J = J;
-      if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(T - J, nmat), dim3(kThreads), 0, ctx->stream, p);
-      hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, ctx->stream, p);
-      if (J < T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(T - J - 1, nmat), dim3(kThreads), 0, ctx->stream, p);
+    {
+      dmm_prof_scope prof(ctx, DMM_PROF_CHOL, ctx->stream);
+      for (int J = 0; J < T; ++J) {
+        p.J = J;
+        if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(T - J, nmat), dim3(kThreads), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, ctx->stream, p);
+        if (J < T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(T - J - 1, nmat), dim3(kThreads), 0, ctx->stream, p);
+      }
+      hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, p);  // sky: a_lm in place
     }
-    hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, p);  // sky: a_lm in place
     DMM_HIP(hipGetLastError());
     if (!sky) {
+      dmm_prof_scope prof(ctx, DMM_PROF_BACKPROJ, ctx->stream);
       int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, Sl, tiles_d, work_d, nmat, work_c[nmat], alm);
       if (rc) return rc;
     }
@@ -695,6 +701,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const size_t rs_lds = (size_t)5 * p.Np * sizeof(double);
     const bool lower_only = cert_only && rs_lds <= 40 * 1024;
     auto form_gram = [&](bool mirror = true) {
+      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, ctx->stream);
       if (sky) {
         hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
@@ -715,6 +722,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       pc.Linv = Wb;
       pc.fail = fail_b;
       auto cholesky = [&]() {
+        dmm_prof_scope prof(ctx, DMM_PROF_CHOL, ctx->stream);
         for (int J = 0; J < T; ++J) {
           pc.J = J;
           if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(T - J, nmat), dim3(kThreads), 0, ctx->stream, pc);
@@ -729,7 +737,10 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       hipLaunchKernelGGL(k_pin_diag, dim3((p.Np + 255) / 256, nmat), dim3(256), 0, ctx->stream, p);
       pc.A = p.A;
       cholesky();
-      hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, pc);
+      {
+        dmm_prof_scope prof(ctx, DMM_PROF_CHOL, ctx->stream);
+        hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, pc);
+      }
       DMM_HIP(hipGetLastError());
       DMM_HIP(hipMemcpyAsync(fail_h.data(), fail_b, nmat * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       DMM_HIP(hipStreamSynchronize(ctx->stream));
@@ -767,8 +778,14 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.fail = fail_b;
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
-        td_reduce(tp, nsel, ctx->stream);
-        td_solve(tp, nsel, ctx->stream);
+        {
+          dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, ctx->stream);
+          td_reduce(tp, nsel, ctx->stream);
+        }
+        {
+          dmm_prof_scope prof(ctx, DMM_PROF_QL, ctx->stream);
+          td_solve(tp, nsel, ctx->stream);
+        }
         DMM_HIP(hipGetLastError());
         td_fail_h.assign(nsel, 0);
         DMM_HIP(hipMemcpyAsync(td_fail_h.data(), fail_b, nsel * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -836,6 +853,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       }
     }
     if (!sky) {
+      dmm_prof_scope prof(ctx, DMM_PROF_BACKPROJ, ctx->stream);
       int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_b, work_b, nmat, work_c[nmat], alm);
       if (rc) return rc;
       DMM_HIP(hipStreamSynchronize(ctx->stream));  // tiles_b / work_b are rewritten by the next batch
@@ -925,15 +943,18 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipMemcpyAsync(tiles_h, H.tiles.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, S1));
     DMM_HIP(hipMemcpyAsync(work_h, H.work.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, S1));
     const int T = p.T, n = p.Np;
-    if (sky) {
-      p.ldx = ntel;
-      p.X = Vb;
-      hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, S1, p, Vb);
-      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
-    } else {
-      hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+    {
+      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, S1);
+      if (sky) {
+        p.ldx = ntel;
+        p.X = Vb;
+        hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, S1, p, Vb);
+        hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+      } else {
+        hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+      }
+      hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, S1, p);
     }
-    hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, S1, p);
     TdParams tp;
     tp.d = p;
     tp.d.msel = nullptr;
@@ -948,13 +969,20 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.fail = fail_hd;
     tp.tri = n <= 2048 ? 1 : 0;
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
-    td_reduce(tp, nmat, S1);
+    {
+      dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, S1);
+      td_reduce(tp, nmat, S1);
+    }
     DMM_HIP(hipGetLastError());
     DMM_HIP(hipEventRecord(ctx->aux_ev[h], S1));
     DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
-    td_solve(tp, nmat, S2);
+    {
+      dmm_prof_scope prof(ctx, DMM_PROF_QL, S2);
+      td_solve(tp, nmat, S2);
+    }
     DMM_HIP(hipGetLastError());
     if (!sky) {  // back-projection a = B^H w of the half's tiles, behind its solve on the second stream
+      dmm_prof_scope prof(ctx, DMM_PROF_BACKPROJ, S2);
       ctx->stream = S2;
       rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_h, work_h, nmat, H.work[nmat], alm);
       ctx->stream = S1;

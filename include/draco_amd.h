@@ -76,12 +76,17 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give
  * up on every other matrix, which exercises the Jacobi fallback),
  * "ml_workspace_mib" / "wiener_workspace_mib" (size dmm_ml_workspace_bytes / dmm_wiener_workspace_bytes report,
- * i.e. the matrices solved per sub-batch; 0 = 20 GiB / 6 GiB) */
+ * i.e. the matrices solved per sub-batch; 0 = 20 GiB / 6 GiB), "profile" (1: time the kernel classes of the dense
+ * solvers with HIP events on their launch streams, sums cleared; 0: off) */
 int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
 /* diagnostics counters, cumulative per context: "ml_tiles_direct" (tiles whose pseudo-inverse was
  * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed), "ml_tiles_ql_failed"
  * (of those: tridiagonal QL did not converge, the tile was redone by the blocked Jacobi solver), "ml_early_chunks"
- * (chunks of early-known rejects decomposed beside the remaining certificate batches) */
+ * (chunks of early-known rejects decomposed beside the remaining certificate batches); with the "profile" option on,
+ * "prof_<class>_us" / "prof_<class>_n" = summed HIP-event time (microseconds) and number of spans of a kernel class,
+ * class = gram (Hermitian products B B^H / B^H N B), chol (factorisations + triangular solves), tridiag (Householder
+ * reduction), band (two-stage reduction: dense -> band -> tridiagonal), ql (tridiagonal eigen-solve + replay),
+ * backproj (a = B^H w).  Reading a counter waits for the spans still running. */
 int dmm_ctx_get_counter(dmm_ctx* ctx, const char* name, int64_t* value);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
 int dmm_timer_start(dmm_ctx* ctx);
