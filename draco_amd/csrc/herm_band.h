@@ -1,0 +1,709 @@
+// Two-stage Hermitian tridiagonalisation for the maximum-likelihood map-maker's eigen path (pinv_svd of the tile's Gram
+// matrix, reference draco/analysis/mapmaker.py:287-300; herm_tridiag.h is the one-stage form and keeps the QL solve).
+//
+// A one-stage Householder reduction multiplies the trailing matrix by a vector once per column: n^3/6 * 20 bytes of HBM
+// traffic per matrix whatever the blocking.  Here:
+//
+//   stage 1  dense -> band of half-width kSbB = 8, panel by panel (k_sb_panel, k_sb_sweep).  Per panel of 8 columns:
+//            QR of the sub-panel below the band (reflectors V, triangular factor T; one block per matrix, the panel in
+//            registers), then ONE sweep over the trailing matrix that applies the previous panel's two-sided update
+//            A -= V X^H + X V^H and forms Z = A V of the new panel from the freshly updated tiles -- both on
+//            v_mfma_f64_16x16x4_f64, the updated tile never leaving the accumulators in between: its D layout
+//            (row = (lane >> 4) + 4 reg, column = lane & 15) IS a valid A-operand layout for the product over the
+//            tile's rows, which by Hermitian symmetry is the product the next panel needs.  32 bytes per trailing
+//            element and 8 columns instead of 20 per column.
+//   stage 2  band -> real tridiagonal by bulge chasing with length-8 reflectors, the whole band in LDS (k_sb_chase):
+//            9 diagonals + the 21-entry bulge triangle each block position keeps between sweeps = 143 KB at n = 768.
+//            Every reflector is logged (8 complex values) for the back-transformation.
+//   apply    z = Q2^H Q1^H b before the QL solve, x = Q1 Q2 y after it (sb_apply_q1 / sb_apply_q2, called from
+//            k_td_solve): Q1 panel by panel (block reflectors), Q2 sweep by sweep -- the reflectors of one sweep act
+//            on disjoint index ranges, so a whole sweep is applied at once.
+//
+// Storage.  A [n][n] full Hermitian on entry (both triangles).  On exit of stage 1 the LOWER band holds the band
+// matrix, row 8k + c of the upper triangle (columns >= 8 (k + 1)) column c of panel k's V.  The work arrays live in the
+// matrix's rotation-log region, which is free until the QL solve: the operand arrays V[2], X, Z ([n][8] each, indexed
+// by GLOBAL row, zero outside their support -- no tile of the sweep needs a mask) at its head, the T factors and the
+// stage-2 reflector log at its tail (the QL log's capacity shrinks by a quarter).
+//
+// NumPy prototype of the same arithmetic: tools/proto/twostage.py.
+#ifndef DMM_HERM_BAND_H
+#define DMM_HERM_BAND_H
+
+namespace {
+
+constexpr int kSbB = 8;  // half-width of the band = columns per panel
+
+__host__ __device__ constexpr int sb_npanel(int n) { return n / kSbB - 1; }  // panels j0 = 0, 8, ..., n - 16
+// reflectors of stage 2: sweep j (0 <= j <= n-2) has ceil((n-1-j)/8) of them
+__host__ __device__ constexpr int64_t sb_total(int64_t M) { return kSbB * (M / kSbB) * (M / kSbB + 1) / 2 + (M % kSbB) * (M / kSbB + 1); }
+__host__ __device__ constexpr int64_t sb_log_prefix(int n, int j) { return sb_total(n - 1) - sb_total(n - 1 - j); }
+__host__ __device__ constexpr int64_t sb_nlog(int n) { return sb_total(n - 1); }
+// double2 units at the tail of a matrix's log region: T factors [npanel][64], then the reflector log [nlog][8]
+__host__ __device__ constexpr int64_t sb_tail(int n) { return (int64_t)sb_npanel(n) * 64 + sb_nlog(n) * kSbB; }
+// LDS of the chase kernel: band [9][n+1] + bulge triangles [n/8 + 2][21], double2
+__host__ __device__ constexpr size_t sb_chase_lds(int n) { return ((size_t)(kSbB + 1) * (n + 1) + (size_t)(n / kSbB + 2) * 21) * sizeof(double2); }
+
+// where a matrix's work arrays live in its log region (single pointers: a struct of them ends up in scratch / LDS)
+__device__ __forceinline__ double2* sb_base(const TdParams& tp, int mat) { return tp.log_cs + (int64_t)mat * tp.log_stride; }
+__device__ __forceinline__ double2* sb_V(const TdParams& tp, int mat, int k) { return sb_base(tp, mat) + (int64_t)(k & 1) * tp.d.Np * kSbB; }  // V_k
+__device__ __forceinline__ double2* sb_X(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)2 * tp.d.Np * kSbB; }
+__device__ __forceinline__ double2* sb_Z(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)3 * tp.d.Np * kSbB; }
+// [waves of the last sweep][256]: their pieces of V^H Z (16 x 16 real blocks [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]])
+__device__ __forceinline__ double* sb_Mp(const TdParams& tp, int mat) { return reinterpret_cast<double*>(sb_base(tp, mat) + (int64_t)4 * tp.d.Np * kSbB); }
+__device__ __forceinline__ double2* sb_T(const TdParams& tp, int mat) { return sb_base(tp, mat) + tp.log_stride - sb_tail(tp.d.Np); }
+__device__ __forceinline__ double2* sb_rlog(const TdParams& tp, int mat) { return sb_T(tp, mat) + (int64_t)sb_npanel(tp.d.Np) * 64; }
+
+__device__ __forceinline__ void sb_solve_ptrs(const TdParams& tp, int mat, const double2** T, const double2** rlog) {
+  *T = sb_T(tp, mat);
+  *rlog = sb_rlog(tp, mat);
+}
+
+// component-wise select (a ternary on double2 values is compiled to a two-entry array in scratch and an indexed load)
+__device__ __forceinline__ double2 sel2(bool c, double2 a, double2 b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cconj2(double2 a) { return make_double2(a.x, -a.y); }
+// a += b * c
+__device__ __forceinline__ void cfma(double2& a, double2 b, double2 c) {
+  a.x = __builtin_fma(b.x, c.x, __builtin_fma(-b.y, c.y, a.x));
+  a.y = __builtin_fma(b.x, c.y, __builtin_fma(b.y, c.x, a.y));
+}
+// a += conj(b) * c
+__device__ __forceinline__ void cfmac(double2& a, double2 b, double2 c) {
+  a.x = __builtin_fma(b.x, c.x, __builtin_fma(b.y, c.y, a.x));
+  a.y = __builtin_fma(b.x, c.y, __builtin_fma(-b.y, c.x, a.y));
+}
+
+// The zlarfg rule: H^H (alpha; x) = (beta; 0), H = I - tau (1; v)(1; v)^H, v = x * scale, beta real.
+struct SbRefl {
+  double2 tau, scale;
+  double beta;
+};
+__device__ __forceinline__ SbRefl sb_larfg(double2 alpha, double xnorm2) {
+  SbRefl r;
+  const bool id = xnorm2 == 0.0 && alpha.y == 0.0;
+  const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2);
+  const double b = alpha.x >= 0.0 ? -nrm : nrm;
+  const double ib = 1.0 / b;
+  const double2 dn = make_double2(alpha.x - b, alpha.y);
+  const double q = 1.0 / (dn.x * dn.x + dn.y * dn.y);
+  r.tau = make_double2(id ? 0.0 : (b - alpha.x) * ib, id ? 0.0 : -alpha.y * ib);
+  r.scale = make_double2(id ? 0.0 : dn.x * q, id ? 0.0 : -dn.y * q);
+  r.beta = id ? alpha.x : b;
+  return r;
+}
+
+// sums of NV doubles per thread over the 256 threads of a block; result in out[0 .. NV) (LDS, >= 4 NV doubles) for all
+template <int NV>
+__device__ __forceinline__ void sb_block_sums(double (&x)[NV], double* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_sums<NV>(x, lane);
+  __syncthreads();  // (out may still be read from the previous round)
+  if (lane < NV) {
+    int rev = 0;  // lane l holds value number bitrev(l)
+#pragma unroll
+    for (int b = 1, bit = NV >> 1; b < NV; b <<= 1, bit >>= 1)
+      if (lane & b) rev |= bit;
+    out[wave * NV + rev] = x[0];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const double s = out[threadIdx.x] + out[NV + threadIdx.x] + out[2 * NV + threadIdx.x] + out[3 * NV + threadIdx.x];
+    out[4 * NV + threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// the operand arrays V[2], X of every matrix start from zero (their rows outside the support must read as zero)
+__global__ __launch_bounds__(kThreads) void k_sb_zero(TdParams tp) {
+  const int n = tp.d.Np;
+  const int mat = tp.d.msel ? tp.d.msel[blockIdx.y] : blockIdx.y;
+  double2* base = tp.log_cs + (int64_t)mat * tp.log_stride;
+  const int64_t cnt = (int64_t)3 * n * kSbB;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * kThreads) base[e] = make_double2(0.0, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------------- stage 1: panel
+// Panel k (tp.j), one block per matrix.  k > 0: finishes update k-1 (X = Z T - V (T^H M T) / 2, M = V^H Z) and applies it
+// to the panel's own columns on the fly; then the diagonal block goes back to A, the sub-panel below it is QR-factored
+// (reflectors into the upper triangle of A and the operand array of the next sweep, R into the lower band, T aside).
+// k == npanel: only the trailing 8 x 8 block is finished.  Rows of a thread: j0 + threadIdx.x + 256 u.
+constexpr int kSbRows = 4;  // most rows per thread: orders up to 1024
+template <int ROWS>  // rows per thread: 3 up to order 768, 4 up to 1024
+__global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
+  __shared__ __align__(16) double2 s_a[1][kSbB];  // the pivot row of the current column
+  __shared__ __align__(16) double2 s_M[64];
+  __shared__ __align__(16) double2 s_T[64], s_S[64], s_tmp[64];
+  __shared__ __align__(16) double2 s_vrow[kSbB][kSbB], s_xrow[kSbB][kSbB];
+  __shared__ double s_red[256];
+  const DenseParams& p = tp.d;
+  const int n = p.Np, k = tp.j, K = sb_npanel(n);
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  double2* A = p.A + (int64_t)mat * n * n;
+  double2* Vold = sb_V(tp, mat, k + 1);  // V_{k-1}
+  double2* Vnew = sb_V(tp, mat, k);      // V_k (holds V_{k-2} on entry)
+  double2* const Xa = sb_X(tp, mat);
+  const double2* const Za = sb_Z(tp, mat);
+  double2* const Ta = sb_T(tp, mat);
+  const double* const Mpa = sb_Mp(tp, mat);
+  const int j0 = kSbB * k, o = j0 + kSbB;
+  const int t = threadIdx.x;
+  const bool last = k == K;
+
+  // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
+  if (k > 0) {
+    const int org_prev = (kSbB * k) & ~15;
+    const int nw = (n - org_prev) / 16;
+    double acc = 0.0;
+    for (int w = 0; w < nw; ++w) acc += Mpa[(int64_t)w * 256 + t];
+    s_red[t] = acc;
+    if (t < 64) s_T[t] = Ta[(int64_t)(k - 1) * 64 + t];
+    __syncthreads();
+    const int q = (t >> 3) & 7, qq = t & 7;
+    if (t < 64)  // M[q][q'] = (Vr'Zr + Vi'Zi) + i (Vr'Zi - Vi'Zr)
+      s_M[t] = make_double2(s_red[q * 16 + qq] + s_red[(8 + q) * 16 + 8 + qq], s_red[q * 16 + 8 + qq] - s_red[(8 + q) * 16 + qq]);
+    __syncthreads();
+    if (t < 64) {  // tmp = M T
+      double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cfma(a, s_M[q * 8 + u], s_T[u * 8 + qq]);
+      s_tmp[t] = a;
+    }
+    __syncthreads();
+    if (t < 64) {  // S = T^H (M T) / 2
+      double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cfmac(a, s_T[u * 8 + q], s_tmp[u * 8 + qq]);
+      s_S[t] = make_double2(0.5 * a.x, 0.5 * a.y);
+    }
+    __syncthreads();
+    // X = Z T - V S for the rows >= j0, one row per thread and pass.  (The memory clobber keeps the 128 table entries in
+    // LDS: hoisted out of the row loop as loop invariants they are every register a thread can have.)
+#pragma unroll 1
+    for (int r = j0 + t; r < n; r += kThreads) {
+      asm volatile("" ::: "memory");
+      double2 z[8], v[8], x[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        z[c] = Za[(int64_t)r * kSbB + c];
+        v[c] = Vold[(int64_t)r * kSbB + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          cfma(a, z[u], s_T[u * 8 + c]);
+          const double2 sv = s_S[u * 8 + c];
+          cfma(a, v[u], make_double2(-sv.x, -sv.y));
+        }
+        x[c] = a;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) Xa[(int64_t)r * kSbB + c] = x[c];
+      if (r < o) {  // the panel's own rows: their V and X rows are what the look-ahead below needs
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          s_vrow[r - j0][c] = v[c];
+          s_xrow[r - j0][c] = x[c];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- the panel's columns with update k-1 applied:  P[r][c] = A[r][j0+c] - sum_q X[r][q] conj(V[j0+c][q]) + V[r][q] conj(X[j0+c][q])
+  double2 P[ROWS][kSbB];
+#pragma unroll
+  for (int u = 0; u < ROWS; ++u) {
+    const int r = j0 + t + kThreads * u;
+    if (r < n) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) P[u][c] = A[(int64_t)r * n + j0 + c];
+      if (k > 0) {
+        double2 xr[8], vr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          xr[q] = Xa[(int64_t)r * kSbB + q];
+          vr[q] = Vold[(int64_t)r * kSbB + q];
+        }
+        asm volatile("" ::: "memory");  // (the 128 entries of s_vrow / s_xrow stay in LDS between the rows)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            cfma(a, xr[q], cconj2(s_vrow[c][q]));
+            cfma(a, vr[q], cconj2(s_xrow[c][q]));
+          }
+          P[u][c] = csub(P[u][c], a);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) P[u][c] = make_double2(0.0, 0.0);
+    }
+  }
+  __syncthreads();  // everybody has read rows [j0, o) of V_{k-1} / X_{k-1} (from LDS) and its own rows of them
+  // rows [j0, o): the finished diagonal block goes back; their operand rows are zeroed -- the sweep then leaves every
+  // tile row / column above o alone, whatever its 16-aligned origin
+  if (t < kSbB) {
+    const int r = j0 + t;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      A[(int64_t)r * n + j0 + c] = P[0][c];
+      if (k > 0) {
+        Vold[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
+        Xa[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
+      }
+      Vnew[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
+    }
+  }
+  if (last) return;
+
+  // ---- QR of the sub-panel rows >= o, column by column.  One reduction round per column carries everything: for
+  // cc >= c the raw products g_cc = sum_{r > pivot} conj(P[r][c]) P[r][cc] (norm and v^H P of the reflector), for a < c
+  // h_a = sum_{r > pivot} conj(V[r][a]) P[r][c], from which column c of T follows (zlarft):
+  //   T[c][c] = tau_c,  T[0:c, c] = -tau_c T[0:c, 0:c] G[0:c, c],  G[a][c] = V[:, a]^H v_c = conj(V[pivot][a]) + scale_c h_a
+#pragma unroll
+  for (int c = 0; c < kSbB; ++c) {  // (unrolled: every index into P[][] is a compile-time constant -- registers, not scratch)
+    const int rp = o + c;  // pivot row
+    if (t == rp - j0) {    // (rp - j0 = 8 + c < 256: always in the first row set)
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) s_a[0][cc] = P[0][cc];
+    }
+    double g[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) g[cc] = 0.0;
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
+      const int r = j0 + t + kThreads * u;
+      if (r > rp && r < n) {
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          // cc >= c: conj(P[r][c]) P[r][cc];  cc < c: conj(V[r][cc]) P[r][c]
+          const double2 l = cc >= c ? P[u][c] : P[u][cc], rr = cc >= c ? P[u][cc] : P[u][c];  // (compile-time: c and cc are unrolled)
+          g[2 * cc] += l.x * rr.x + l.y * rr.y;
+          g[2 * cc + 1] += l.x * rr.y - l.y * rr.x;
+        }
+      }
+    }
+    sb_block_sums<16>(g, s_red);
+    const double* tot = s_red + 4 * 16;
+    const SbRefl rf = sb_larfg(s_a[0][c], tot[2 * c]);
+    const double2 tau = rf.tau, scale = rf.scale;
+    const double beta = rf.beta;
+    if (t < 8) {  // thread a: T[a][c]
+      const int a = t;
+      double2 tv = make_double2(0.0, 0.0);
+      if (a == c) tv = tau;
+      if (a < c) {
+        double2 sacc = make_double2(0.0, 0.0);
+        for (int u = a; u < c; ++u) {  // G[u] = conj(V[pivot][u]) + scale h_u
+          double2 G = cconj2(s_a[0][u]);
+          cfma(G, scale, make_double2(tot[2 * u], tot[2 * u + 1]));
+          cfma(sacc, s_T[a * 8 + u], G);
+        }
+        tv = cmul(make_double2(-tau.x, -tau.y), sacc);
+      }
+      s_T[a * 8 + c] = tv;
+    }
+    // H^H = I - conj(tau) v v^H on the columns cc > c:  fac = conj(tau) (P[rp][cc] + conj(scale) g_cc)
+    double2 fac[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      double2 vhp = s_a[0][cc];
+      cfmac(vhp, scale, make_double2(tot[2 * cc], tot[2 * cc + 1]));
+      fac[cc] = cmul(cconj2(tau), vhp);
+    }
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
+      const int r = j0 + t + kThreads * u;
+      if (r == rp) {
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (cc > c) P[u][cc] = csub(P[u][cc], fac[cc]);
+        P[u][c] = make_double2(beta, 0.0);
+      } else if (r > rp && r < n) {
+        const double2 v = cmul(P[u][c], scale);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+          if (cc > c) cfma(P[u][cc], v, make_double2(-fac[cc].x, -fac[cc].y));
+        P[u][c] = v;
+      }
+    }
+    __syncthreads();  // s_a[0] is rewritten by the next column
+  }
+  if (t < 64) Ta[(int64_t)k * 64 + t] = s_T[t];
+  // ---- outputs: R into the lower band, V into the upper triangle (row j0 + c, columns >= o) and the operand array
+#pragma unroll
+  for (int u = 0; u < ROWS; ++u) {
+    const int r = j0 + t + kThreads * u;
+    if (r >= o && r < n) {
+      const int i = r - o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double2 v = make_double2(i > c ? P[u][c].x : (i == c ? 1.0 : 0.0), i > c ? P[u][c].y : 0.0);
+        if (i <= c) A[(int64_t)r * n + j0 + c] = P[u][c];
+        A[(int64_t)(j0 + c) * n + r] = v;
+        Vnew[(int64_t)r * kSbB + c] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- stage 1: sweep
+// Sweep k (tp.j): every 16 x 16 tile of the trailing matrix from the 16-aligned origin below o_k = 8 (k + 1):
+//   C -= V_I X_J^H + X_I V_J^H   (update k-1; operands zero above their support),   Z_J += C^H V'_I   (V' = V_k).
+// A block owns 64 columns, each of its 4 waves 16 of them for all rows: the wave's piece of Z stays in its accumulators.
+__global__ __launch_bounds__(kThreads) void k_sb_sweep(TdParams tp) {
+  const DenseParams& p = tp.d;
+  const int n = p.Np, k = tp.j;
+  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
+  double2* A = p.A + (int64_t)mat * n * n;
+  const double2* Vold = sb_V(tp, mat, k + 1);
+  const double2* Vnew = sb_V(tp, mat, k);
+  const double2* X = sb_X(tp, mat);
+  const int org = (kSbB * (k + 1)) & ~15;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int c0 = org + 64 * blockIdx.x + 16 * wave;
+  if (c0 >= n) return;
+  // J side (this wave's columns), constant over the row loop: negated, so that the MFMAs subtract
+  double nxr[2], nxi[2], pxi[2], nvr[2], nvi[2], pvi[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const double2 x = X[(int64_t)(c0 + lr) * kSbB + lk + 4 * h], v = Vold[(int64_t)(c0 + lr) * kSbB + lk + 4 * h];
+    nxr[h] = -x.x, nxi[h] = -x.y, pxi[h] = x.y;
+    nvr[h] = -v.x, nvi[h] = -v.y, pvi[h] = v.y;
+  }
+  v4d z = (v4d){0.0, 0.0, 0.0, 0.0};
+  double2* cp = A + (int64_t)(org + lk) * n + c0 + lr;  // C[lk + 4 reg][lr] of the current tile
+  const bool lo = lr < 8;
+  const int vq = lr & 7;
+  // operands of a tile: I-side rows r0 + lr (update), r0 + lk + 4 reg (product)
+  double2 cc[4], vi[2], xi[2], vn[4];
+#define SB_LOAD_TILE(R0, CPTR)                                                             \
+  {                                                                                        \
+    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) cc[reg] = (CPTR)[(int64_t)4 * reg * n]; \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                        \
+      vi[h] = Vold[(int64_t)((R0) + lr) * kSbB + lk + 4 * h];                              \
+      xi[h] = X[(int64_t)((R0) + lr) * kSbB + lk + 4 * h];                                 \
+    }                                                                                      \
+    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) vn[reg] = Vnew[(int64_t)((R0) + lk + 4 * reg) * kSbB + vq]; \
+  }
+  SB_LOAD_TILE(org, cp)
+  for (int r0 = org; r0 < n; r0 += 16) {
+    v4d cre, cim;
+    double a_vr[2], a_vi[2], a_xr[2], a_xi[2], b1[4], b2[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      cre[reg] = cc[reg].x;
+      cim[reg] = cc[reg].y;
+      b1[reg] = lo ? vn[reg].x : vn[reg].y;
+      b2[reg] = lo ? vn[reg].y : -vn[reg].x;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_vr[h] = vi[h].x, a_vi[h] = vi[h].y, a_xr[h] = xi[h].x, a_xi[h] = xi[h].y;
+    double2* cur = cp;
+    cp += (int64_t)16 * n;
+    if (r0 + 16 < n) SB_LOAD_TILE(r0 + 16, cp)  // the next tile's loads fly under this tile's MFMAs
+    // Re(V X^H + X V^H) = Vr Xr + Vi Xi + Xr Vr + Xi Vi;  Im = Vi Xr - Vr Xi + Xi Vr - Xr Vi
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vr[h], nxr[h], cre, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vi[h], nxr[h], cim, 0, 0, 0);
+      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vi[h], nxi[h], cre, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vr[h], pxi[h], cim, 0, 0, 0);
+      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xr[h], nvr[h], cre, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xi[h], nvr[h], cim, 0, 0, 0);
+      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xi[h], nvi[h], cre, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xr[h], pvi[h], cim, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) cur[(int64_t)4 * reg * n] = make_double2(cre[reg], cim[reg]);
+    // Z[c] += sum_r conj(C[r][c]) V'[r]:  [Zr | Zi] += Cr^T [V'r | V'i] + Ci^T [V'i | -V'r], register `reg` of the
+    // accumulators being the A operand of rows r0 + lk + 4 reg
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      z = __builtin_amdgcn_mfma_f64_16x16x4f64(cre[reg], b1[reg], z, 0, 0, 0);
+      z = __builtin_amdgcn_mfma_f64_16x16x4f64(cim[reg], b2[reg], z, 0, 0, 0);
+    }
+  }
+#undef SB_LOAD_TILE
+  // z: row (column of A) c0 + lk + 4 reg, entry lr: Re Z[.][lr] (lr < 8), Im Z[.][lr - 8]
+  double* Zd = reinterpret_cast<double*>(sb_Z(tp, mat));
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) Zd[((int64_t)(c0 + lk + 4 * reg) * kSbB + vq) * 2 + (lo ? 0 : 1)] = z[reg];
+  // this wave's piece of M = V'^H Z (its 16 rows): [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]] = [V'r | V'i]^T [Zr | Zi]; the
+  // accumulator registers of z are B operands as they stand (k = lk <-> row lk + 4 reg, n = lr)
+  v4d mp = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const double2 vj = Vnew[(int64_t)(c0 + lk + 4 * reg) * kSbB + vq];
+    mp = __builtin_amdgcn_mfma_f64_16x16x4f64(lo ? vj.x : vj.y, z[reg], mp, 0, 0, 0);
+  }
+  double* Mw = sb_Mp(tp, mat) + (int64_t)((c0 - org) / 16) * 256;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) Mw[(lk + 4 * reg) * 16 + lr] = mp[reg];
+}
+
+// ---------------------------------------------------------------------------------------------------- stage 2: chase
+// One wave per matrix (64 lanes = one 8 x 8 block: row i = lane & 7, column c = lane >> 3).  Band ab[d][col] = A[col+d][col]
+// (pitch n + 1: the 8 lanes of a column spread over the banks), bulge triangles bg[s][i (i - 1) / 2 + c], c < i <= 6, in
+// the coordinates of the sweep that reads them.  Blocks of sweep j: D_s = rows / columns R_s = [j + 1 + 8 s, + 8),
+// O_s = rows R_{s+1} x columns R_s.
+__device__ __forceinline__ double2 sb_sum_over_c(double2 v) {  // sum over the lanes of equal i (c = lane >> 3)
+  v.x += __shfl_xor(v.x, 8), v.y += __shfl_xor(v.y, 8);
+  v.x += __shfl_xor(v.x, 16), v.y += __shfl_xor(v.y, 16);
+  v.x += __shfl_xor(v.x, 32), v.y += __shfl_xor(v.y, 32);
+  return v;
+}
+__device__ __forceinline__ double2 sb_sum_over_i(double2 v) {  // sum over the lanes of equal c (i = lane & 7)
+  v.x += __shfl_xor(v.x, 1), v.y += __shfl_xor(v.y, 1);
+  v.x += __shfl_xor(v.x, 2), v.y += __shfl_xor(v.y, 2);
+  v.x += __shfl_xor(v.x, 4), v.y += __shfl_xor(v.y, 4);
+  return v;
+}
+__device__ __forceinline__ double2 sb_shfl2(double2 v, int src) { return make_double2(__shfl(v.x, src), __shfl(v.y, src)); }
+
+// kSbWaves waves per matrix, wave w taking the sweeps j = w, w + W, ...: sweep j may run iteration s once sweep j - 1 has
+// finished its iteration s + 2 (iteration s of sweep j touches the indices j + 1 + 8 s .. j + 8 s + 16, the iterations
+// >= s + 3 of sweep j - 1 only j + 8 s + 24 and beyond), so the waves follow each other down the band three iterations
+// apart.  A wave publishes (sweep, iterations done) in LDS after its writes have landed; its successor spins on it.
+constexpr int kSbWaves = 16;
+// Ordering between the waves of the chase goes through LDS only, and the LDS serves a CU's requests in the order they
+// were issued: what a wave has to do before it publishes its progress is to have ISSUED its band writes (in order, one
+// queue) -- `s_waitcnt lgkmcnt(0)` plus a compiler barrier.  (__threadfence_block() also waits for the global stores of
+// the reflector log, ~2 us each: measured 4x on the whole kernel.)
+#define SB_LDS_FENCE()                          \
+  do {                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  } while (0)
+__global__ __launch_bounds__(64 * kSbWaves) void k_sb_chase(TdParams tp) {
+  extern __shared__ __align__(16) unsigned char smem_sb[];
+  __shared__ int s_prog[kSbWaves];
+  const DenseParams& p = tp.d;
+  const int n = p.Np, pitch = n + 1;
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  const double2* A = p.A + (int64_t)mat * n * n;
+  double2* ab = reinterpret_cast<double2*>(smem_sb);
+  double2* bg = ab + (int64_t)(kSbB + 1) * pitch;
+  double2* const rlog = sb_rlog(tp, mat);
+  double2* vbm = tp.vec + (int64_t)mat * td_slots(n) * n;
+  double* dd = reinterpret_cast<double*>(vbm + 5 * n);
+  double* ee = dd + n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 7, c = lane >> 3;
+#define SB_ZERO make_double2(0.0, 0.0)
+  for (int e = threadIdx.x; e < (kSbB + 1) * n; e += 64 * kSbWaves) {
+    const int d = e / n, col = e - d * n;
+    ab[d * pitch + col] = col + d < n ? A[(int64_t)(col + d) * n + col] : SB_ZERO;
+  }
+  for (int e = threadIdx.x; e < (n / kSbB + 2) * 21; e += 64 * kSbWaves) bg[e] = SB_ZERO;
+  if (threadIdx.x < kSbWaves) s_prog[threadIdx.x] = 0;
+  __syncthreads();
+  volatile int* prog = s_prog;
+  const int pred = (wave + kSbWaves - 1) % kSbWaves;
+  for (int j = wave; j < n - 1; j += kSbWaves) {
+    int64_t lpos = sb_log_prefix(n, j);
+    // the predecessor (sweep j - 1) must have finished iterations <= it + 2 before iteration `it` here; the first
+    // reflector counts as part of iteration 0
+#define SB_WAIT_FOR(IT)                                                               \
+  if (j > 0) {                                                                       \
+    const int need = ((j - 1) << 12) + (IT) + 3; /* iterations done >= it + 3 */      \
+    while (prog[pred] < need) __builtin_amdgcn_s_sleep(1);                           \
+    SB_LDS_FENCE();                                                           \
+  }
+    SB_WAIT_FOR(0)
+    // ---- first reflector of the sweep: from column j below the diagonal, rows r0 = j + 1 .. j + 8
+    int r0 = j + 1;
+    double2 x = SB_ZERO;
+    if (c == 0 && r0 + i < n) x = ab[(1 + i) * pitch + j];  // lanes c = 0 hold x_i
+    double2 tau, vi;
+    {
+      const double2 xx = make_double2((c == 0 && i > 0) ? x.x * x.x + x.y * x.y : 0.0, 0.0);
+      const double xn2 = __shfl(sb_sum_over_i(xx).x, 0);
+      const double2 alpha = sb_shfl2(x, 0);
+      const SbRefl rf = sb_larfg(alpha, xn2);
+      tau = rf.tau;
+      const double2 scale = rf.scale;
+      const double beta = rf.beta;
+      const double2 vv = sel2(i == 0, make_double2(1.0, 0.0), cmul(x, scale));  // valid in lanes c = 0
+      vi = sb_shfl2(vv, i);                                                   // v_i for every lane
+      if (r0 + i >= n) vi = SB_ZERO;
+      if (lane == 0) {
+        ab[1 * pitch + j] = make_double2(beta, 0.0);
+        ee[j] = beta;
+        dd[j] = ab[j].x;
+      }
+      if (c == 0 && i > 0 && r0 + i < n) ab[(1 + i) * pitch + j] = SB_ZERO;
+      if (c == 0) rlog[lpos * kSbB + i] = sel2(i == 0, tau, vi);
+      ++lpos;
+    }
+    for (int s = 0;; ++s) {
+      if (s > 0) SB_WAIT_FOR(s)
+      const double2 vc = sb_shfl2(vi, c);  // v_c (lane c holds i = c, column 0)
+      // ---- D <- H^H D H on rows / columns r0 .. r0 + 7:  u = D v,  w = tau u - (|tau|^2 (v^H u) / 2) v,  D -= w v^H + v w^H
+      {
+        const bool in = r0 + i < n && r0 + c < n;
+        double2 dv = SB_ZERO;
+        if (in) {
+          const double2 raw = ab[(i >= c ? i - c : c - i) * pitch + r0 + (i >= c ? c : i)];
+          dv = make_double2(raw.x, i >= c ? raw.y : -raw.y);
+        }
+        if (i == c) dv.y = 0.0;
+        double2 u = SB_ZERO;
+        cfma(u, dv, vc);
+        u = sb_sum_over_c(u);  // u_i
+        double2 vhu = SB_ZERO;
+        if (c == 0) cfmac(vhu, vi, u);
+        const double h = __shfl(sb_sum_over_i(vhu).x, 0);  // v^H u (real)
+        const double t2 = 0.5 * (tau.x * tau.x + tau.y * tau.y) * h;
+        double2 wi = cmul(tau, u);
+        wi.x -= t2 * vi.x, wi.y -= t2 * vi.y;
+        const double2 wc = sb_shfl2(wi, c);
+        cfma(dv, wi, make_double2(-vc.x, vc.y));  // - w_i conj(v_c)
+        cfma(dv, vi, make_double2(-wc.x, wc.y));  // - v_i conj(w_c)
+        if (in && i >= c) ab[(i - c) * pitch + r0 + c] = make_double2(dv.x, i == c ? 0.0 : dv.y);
+      }
+      const int q0 = r0 + kSbB;
+      if (q0 >= n) break;
+      // ---- O = rows q0 .. q0 + 7 x columns r0 .. r0 + 7: band part (i <= c), the bulge the previous sweep left (c < i <= 6)
+      const bool oin = q0 + i < n && r0 + c < n;
+      double2 ov = SB_ZERO;
+      if (oin) {
+        if (i <= c) ov = ab[(kSbB + i - c) * pitch + r0 + c];
+        else if (i <= kSbB - 2) ov = bg[s * 21 + i * (i - 1) / 2 + c];
+      }
+      // O <- O H = O - tau (O v) v^H
+      double2 tv = SB_ZERO;
+      cfma(tv, ov, vc);
+      tv = sb_sum_over_c(tv);
+      cfma(ov, cmul(tau, tv), make_double2(-vc.x, vc.y));
+      // reflector of the block's first column
+      const double2 xx = make_double2((c == 0 && i > 0) ? ov.x * ov.x + ov.y * ov.y : 0.0, 0.0);
+      const double xn2 = __shfl(sb_sum_over_i(xx).x, 0);
+      const double2 alpha = sb_shfl2(ov, 0);
+      const SbRefl rf = sb_larfg(alpha, xn2);
+      const double2 tau2 = rf.tau, scale = rf.scale;
+      const double beta = rf.beta;
+      const double2 vv = sel2(i == 0, make_double2(1.0, 0.0), cmul(ov, scale));  // valid in lanes c = 0
+      double2 v2 = sb_shfl2(vv, i);
+      if (q0 + i >= n) v2 = SB_ZERO;
+      // O <- H2^H O = O - conj(tau2) v2 (v2^H O)
+      double2 sc = SB_ZERO;
+      cfmac(sc, v2, ov);
+      sc = sb_sum_over_i(sc);
+      cfma(ov, cmul(cconj2(tau2), sc), make_double2(-v2.x, -v2.y));
+      if (c == 0) ov = make_double2(i == 0 ? beta : 0.0, 0.0);
+      if (oin) {
+        if (i <= c) ab[(kSbB + i - c) * pitch + r0 + c] = ov;
+        else if (c >= 1) bg[s * 21 + (i - 1) * (i - 2) / 2 + c - 1] = ov;  // next sweep's coordinates (i - 1, c - 1)
+      }
+      if (c == 0) rlog[lpos * kSbB + i] = sel2(i == 0, tau2, v2);
+      ++lpos;
+      r0 = q0;
+      tau = tau2;
+      vi = v2;
+      // iteration s is done: its LDS writes first, then the counter
+      SB_LDS_FENCE();
+      if (lane == 0) prog[wave] = (j << 12) + s + 1;
+    }
+    SB_LDS_FENCE();
+    if (lane == 0) prog[wave] = (j << 12) + 4095;  // the whole sweep
+#undef SB_WAIT_FOR
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dd[n - 1] = ab[n - 1].x;
+    ee[n - 1] = 0.0;
+  }
+}
+#undef SB_ZERO
+#undef SB_LDS_FENCE
+
+// ---------------------------------------------------------------------------------------------------- applications
+// b (LDS, n entries) <- Q1^H b (ADJ) or Q1 b,  Q1 = prod_k (I - V_k T_k V_k^H);  256 threads, `red`: >= 5 * 16 doubles
+template <bool ADJ>
+__device__ __forceinline__ void sb_apply_q1(double2* b, const double2* A, const double2* T, int n, double* red) {
+  const int K = sb_npanel(n), t = threadIdx.x;
+  __shared__ double2 s_s[kSbB];
+  for (int kk = 0; kk < K; ++kk) {
+    const int k = ADJ ? kk : K - 1 - kk;
+    const int j0 = kSbB * k, o = j0 + kSbB;
+    double2 v[kSbRows][kSbB];
+    double g[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g[e] = 0.0;
+#pragma unroll
+    for (int u = 0; u < kSbRows; ++u) {
+      const int r = o + t + kThreads * u;
+      if (r < n) {
+        const double2 br = b[r];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          v[u][c] = A[(int64_t)(j0 + c) * n + r];
+          g[2 * c] += v[u][c].x * br.x + v[u][c].y * br.y;  // conj(v) b
+          g[2 * c + 1] += v[u][c].x * br.y - v[u][c].y * br.x;
+        }
+      }
+    }
+    sb_block_sums<16>(g, red);
+    const double* tot = red + 4 * 16;
+    if (t < kSbB) {  // s' = T^H s (ADJ) or T s
+      double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const double2 su = make_double2(tot[2 * u], tot[2 * u + 1]);
+        if (ADJ) cfmac(a, T[(int64_t)k * 64 + u * 8 + t], su);
+        else cfma(a, T[(int64_t)k * 64 + t * 8 + u], su);
+      }
+      s_s[t] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSbRows; ++u) {
+      const int r = o + t + kThreads * u;
+      if (r < n) {
+        double2 br = b[r];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cfma(br, v[u][c], make_double2(-s_s[c].x, -s_s[c].y));
+        b[r] = br;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// b <- Q2^H b (ADJ: sweeps in generation order) or Q2 b (reverse).  Reflector (j, s) acts on rows j + 1 + 8 s .. + 7; the
+// reflectors of one sweep are disjoint: thread (s, i) = (threadIdx >> 3, threadIdx & 7), 32 reflectors per pass.
+template <bool ADJ>
+__device__ __forceinline__ void sb_apply_q2(double2* b, const double2* rlog, int n) {
+  const int t = threadIdx.x, i = t & 7;
+  for (int jj = 0; jj < n - 1; ++jj) {
+    const int j = ADJ ? jj : n - 2 - jj;
+    const int nst = (n - 1 - j + kSbB - 1) / kSbB;
+    const double2* lg = rlog + sb_log_prefix(n, j) * kSbB;
+    for (int s = t >> 3; s < nst; s += kThreads / 8) {
+      const int r = j + 1 + kSbB * s + i;
+      const double2 e = lg[(int64_t)s * kSbB + i];  // i = 0: tau, else v_i
+      const double2 tau = sb_shfl2(e, (threadIdx.x & 63) & ~7);
+      const double2 v = sel2(i == 0, make_double2(1.0, 0.0), e);
+      double2 br = make_double2(0.0, 0.0);
+      if (r < n) br = b[r];
+      double2 d = make_double2(0.0, 0.0);
+      cfmac(d, v, br);
+      d = sb_sum_over_i(d);  // v^H b over the 8 lanes of the reflector
+      const double2 f = cmul(make_double2(tau.x, ADJ ? -tau.y : tau.y), d);
+      if (r < n) {
+        double2 o = br;
+        cfma(o, v, make_double2(-f.x, -f.y));
+        b[r] = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+#endif

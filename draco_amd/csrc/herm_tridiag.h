@@ -46,6 +46,8 @@ struct TdParams {
   int np;              // pending rank-2 updates (pairs v_q, w_q not yet applied to the stored matrix) at this launch
   double acond, rcond;
   int* fail;           // [nsel] set when QL does not converge or the log overflows
+  int two_stage;       // 1: the matrices were reduced by herm_band.h (dense -> band -> tridiagonal): k_td_solve applies
+                       // Q = Q1 Q2 from the block reflectors in A's upper triangle and the reflector log instead
 };
 
 // pending pair q of a matrix: v at pend + q n, w at pend + (kTdPend + q) n; the arrays live at the head of the
@@ -100,6 +102,12 @@ __device__ __forceinline__ double2 block_sum2(double2 v, double* red) {
   __syncthreads();
   return make_double2(red[0] + red[2] + red[4] + red[6], red[1] + red[3] + red[5] + red[7]);
 }
+
+template <bool ADJ>
+__device__ __forceinline__ void sb_apply_q1(double2* b, const double2* A, const double2* T, int n, double* red);
+template <bool ADJ>
+__device__ __forceinline__ void sb_apply_q2(double2* b, const double2* rlog, int n);
+__device__ __forceinline__ void sb_solve_ptrs(const TdParams& tp, int mat, const double2** T, const double2** rlog);
 
 // The column step of matrix `mat`: finishes step j-1 and forms the reflector of column j.  One whole block; `smem`: 2 n
 // double2 of LDS.  Called by k_td_col, and by the LAST block of a sweep that finishes for its matrix (k_td_trail_tri
@@ -568,13 +576,23 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
       }
     }
     b[i] = v;
-    dl[i] = dd[i];
-    el[i] = i < n - 1 ? ee[i] : 0.0;
+    if (PH == 0) {  // (PH 1 has the vector alone in LDS)
+      dl[i] = dd[i];
+      el[i] = i < n - 1 ? ee[i] : 0.0;
+    }
   }
   TD_T(0);
   if (PH != 3 && threadIdx.x == 0) s_nrot = s_fail = 0;
   __syncthreads();
   // ---- z = Q^H b = H_{n-2}^H ... H_0^H b,  H_j = I - tau_j v_j v_j^H,  v_j = (0.., 1 at j+1, row j of A beyond)
+  // (two-stage reduction: Q = Q1 Q2, block reflectors of the band reduction, then the logged reflectors of the chase)
+  if ((PH == 0 || PH == 1) && tp.two_stage) {
+    __shared__ double red_sb[5 * 16];
+    const double2 *Tq, *rl;
+    sb_solve_ptrs(tp, mat, &Tq, &rl);
+    sb_apply_q1<true>(b, A, Tq, n, red_sb);
+    sb_apply_q2<true>(b, rl, n);
+  } else
   if (PH == 0 || PH == 1)
   for (int j = 0; j < n - 1; ++j) {
     const double2 t = tau[j];
@@ -741,7 +759,14 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   td_replay<true>(b, lcs, lrun, s_nrot);
   __syncthreads();
   TD_T(4);
-  // ---- x = Q y = H_0 (H_1 (... H_{n-2} y))
+  // ---- x = Q y = H_0 (H_1 (... H_{n-2} y))   (two-stage: Q1 (Q2 y))
+  if (tp.two_stage) {
+    __shared__ double red_sb2[5 * 16];
+    const double2 *Tq, *rl;
+    sb_solve_ptrs(tp, mat, &Tq, &rl);
+    sb_apply_q2<false>(b, rl, n);
+    sb_apply_q1<false>(b, A, Tq, n, red_sb2);
+  } else
   for (int j = n - 2; j >= 0; --j) {
     const double2 t = tau[j];
     if (t.x == 0.0 && t.y == 0.0) continue;

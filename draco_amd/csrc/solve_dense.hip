@@ -36,6 +36,7 @@
 //   Re = [Xr Xi].[Yr Yi]^T,  Im = [Xr Xi].[-Yi Yr]^T   (4 real k per 2 complex k).
 #include "dense_kernels.h"
 #include "herm_tridiag.h"
+#include "herm_band.h"
 
 namespace {
 
@@ -82,6 +83,36 @@ void td_reduce(TdParams& tp, int nmat, hipStream_t st) {
     if (j >= 1) ++np_pend;  // k_td_col has completed the pair of column j-1
     if (j < n - 1) td_launch_trail(tp, np_pend, nmat, st);
   }
+}
+
+// ---- two-stage reduction (herm_band.h): dense -> band of half-width 8 on the MFMA units, band -> tridiagonal in LDS
+constexpr size_t kSbLdsMax = 160 * 1024;
+bool sb_usable(const dmm_ctx* ctx, int n) {
+  if (ctx->opt_ml_reduce == 1) return false;
+  return n >= 64 && n % 64 == 0 && n <= kSbRows * kThreads && sb_chase_lds(n) <= kSbLdsMax;
+}
+// QL's rotation log shares the matrix's log region with the T factors and the chase's reflector log at its tail
+int64_t sb_log_cap(int64_t log_stride, int n, int runs) {
+  return log_stride - sb_tail(n) - ((int64_t)3 * runs * (int64_t)sizeof(int) + 15) / 16;
+}
+void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
+  const int n = tp.d.Np, K = sb_npanel(n);
+  hipLaunchKernelGGL(k_sb_zero, dim3(12, nmat), dim3(kThreads), 0, st, tp);
+  auto panel = [&]() {
+    if (n <= 3 * kThreads) hipLaunchKernelGGL(k_sb_panel<3>, dim3(nmat), dim3(kThreads), 0, st, tp);
+    else hipLaunchKernelGGL(k_sb_panel<4>, dim3(nmat), dim3(kThreads), 0, st, tp);
+  };
+  for (int k = 0; k < K; ++k) {
+    tp.j = k;
+    panel();
+    const int org = (kSbB * (k + 1)) & ~15;
+    hipLaunchKernelGGL(k_sb_sweep, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
+  }
+  tp.j = K;
+  panel();
+}
+void sb_chase(const TdParams& tp, int nmat, hipStream_t st) {
+  hipLaunchKernelGGL(k_sb_chase, dim3(nmat), dim3(64 * kSbWaves), sb_chase_lds(tp.d.Np), st, tp);
 }
 
 // QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
@@ -645,6 +676,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
+    if (sb_usable(ctx, L.Np)) DMM_HIP(hipFuncSetAttribute((const void*)k_sb_chase, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_chase_lds(L.Np)));
   }
 
   std::vector<dmm_tile> tiles_c;
@@ -777,8 +809,14 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.rcond = rcond;
         tp.fail = fail_b;
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
+        tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
+        if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
         DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
-        {
+        if (tp.two_stage) {
+          dmm_prof_scope prof(ctx, DMM_PROF_BAND, ctx->stream);
+          sb_reduce(tp, nsel, ctx->stream);
+          sb_chase(tp, nsel, ctx->stream);
+        } else {
           dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, ctx->stream);
           td_reduce(tp, nsel, ctx->stream);
         }
@@ -968,14 +1006,23 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.rcond = rcond;
     tp.fail = fail_hd;
     tp.tri = n <= 2048 ? 1 : 0;
+    tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
+    if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
-    {
+    if (tp.two_stage) {
+      dmm_prof_scope prof(ctx, DMM_PROF_BAND, S1);
+      sb_reduce(tp, nmat, S1);
+    } else {
       dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, S1);
       td_reduce(tp, nmat, S1);
     }
     DMM_HIP(hipGetLastError());
     DMM_HIP(hipEventRecord(ctx->aux_ev[h], S1));
     DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
+    if (tp.two_stage) {  // the chase is one wave per matrix, as latency bound as QL: it runs beside the next chunk's sweeps too
+      dmm_prof_scope prof(ctx, DMM_PROF_BAND, S2);
+      sb_chase(tp, nmat, S2);
+    }
     {
       dmm_prof_scope prof(ctx, DMM_PROF_QL, S2);
       td_solve(tp, nmat, S2);

@@ -75,6 +75,9 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * "ml_eigen" (eigen path of the ML solve: 0 = chosen by batch size; 4 = Householder tridiagonalisation + QL kept
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give
  * up on every other matrix, which exercises the Jacobi fallback),
+ * "ml_reduce" (tridiagonal reduction of the eigen path: 0 = two-stage, dense -> band of half-width 8 on the matrix
+ * cores -> tridiagonal by bulge chasing in LDS, for orders whose band fits the LDS, one-stage Householder otherwise;
+ * 1 = one-stage always),
  * "ml_workspace_mib" / "wiener_workspace_mib" (size dmm_ml_workspace_bytes / dmm_wiener_workspace_bytes report,
  * i.e. the matrices solved per sub-batch; 0 = 20 GiB / 6 GiB), "profile" (1: time the kernel classes of the dense
  * solvers with HIP events on their launch streams, sums cleared; 0: off) */
