@@ -556,6 +556,94 @@ class PackedStoreProvider(BeamTransferProvider):
         return cls(tel, host.numpy(), pinned=bool(pin), keepalive=host)
 
 
+    # ---- one-time packing of a provider that only has per-tile ``beam_m`` (a real driftscan ``BeamTransfer``)
+    @classmethod
+    def open(cls, telescope, path, pinned=False):
+        """A store packed earlier (``pack``): the ``.npy`` file memory-mapped read-only."""
+        return cls(telescope, np.load(path, mmap_mode="r"), pinned=pinned)
+
+    @classmethod
+    def pack(cls, provider, path, dtype=np.complex128, processes=None, factory=None, chunk_bytes=256 << 20):
+        """Write ``provider``'s tiles ONCE into a ``.npy`` file in the pool's wire format and return the store over it.
+
+        For providers that only offer per-tile ``beam_m(m, fi=f)`` -- what a driftscan ``BeamTransfer`` offers
+        (``mapmaker.py:160-162``): streamed tile by tile they are host-bound (14 GB/s through the staging ring, one
+        interpreter packing under the GIL); packed once, every later day streams at the rate of a plain memory copy.
+        The packing itself runs in ``processes`` worker PROCESSES (default: the host's share, at most 16), each
+        writing its (frequency, m-range) chunks straight into the memory-mapped file.  Workers are forked, so they
+        inherit ``provider`` as it is (they never touch the GPU); where forking is not an option pass ``factory``, a
+        picklable callable that builds the provider inside a spawned worker.
+        """
+        import multiprocessing as mp
+
+        tel = provider.telescope
+        npdt = np.dtype(dtype)
+        n = cls.elements(tel)
+        np.lib.format.open_memmap(path, mode="w+", dtype=npdt, shape=(n,)).flush()
+        ntel = 2 * tel.npairs
+        per_m = np.array([ntel * tel.num_pol_sky * (tel.lmax + 1 - m) for m in range(tel.mmax + 1)], dtype=np.int64)
+        m_off = np.concatenate([[0], np.cumsum(per_m)])
+        per_freq = int(m_off[-1])
+        jobs = []
+        for f in range(tel.nfreq):
+            m0 = 0
+            while m0 <= tel.mmax:  # chunks of whole tiles of about chunk_bytes
+                m1 = int(np.searchsorted(m_off, m_off[m0] + chunk_bytes // npdt.itemsize, side="right")) - 1
+                m1 = min(max(m1, m0 + 1), tel.mmax + 1)
+                jobs.append((f, m0, m1, int(f * per_freq + m_off[m0])))
+                m0 = m1
+        if processes is None:
+            from .hoststage import default_workers
+
+            processes = default_workers()
+        processes = max(1, min(int(processes), len(jobs)))
+        if processes == 1:
+            _pack_init(provider if factory is None else factory(), path)
+            for j in jobs:
+                _pack_job(j)
+        else:
+            ctx = mp.get_context("fork" if factory is None else "spawn")
+            global _PACK_STATE
+            _PACK_STATE = (provider, path) if factory is None else None  # forked workers inherit it
+            try:
+                with ctx.Pool(processes, initializer=_pack_init_worker, initargs=(factory, path)) as pool:
+                    for _ in pool.imap_unordered(_pack_job, jobs, chunksize=1):
+                        pass
+            finally:
+                _PACK_STATE = None
+        return cls.open(tel, path)
+
+
+_PACK_STATE = None  # (provider, path) of the packing run in this process / inherited by its forked workers
+_PACK_OUT = None
+
+
+def _pack_init(provider, path):
+    global _PACK_STATE, _PACK_OUT
+    _PACK_STATE = (provider, path)
+    _PACK_OUT = np.load(path, mmap_mode="r+")
+
+
+def _pack_init_worker(factory, path):
+    _pack_init(_PACK_STATE[0] if factory is None else factory(), path)
+
+
+def _pack_job(job):
+    """Tiles m0 .. m1-1 of frequency f, packed, into the file at element offset ``off``."""
+    f, m0, m1, off = job
+    prov = _PACK_STATE[0]
+    tel = prov.telescope
+    ntel = 2 * tel.npairs
+    out = _PACK_OUT
+    pos = off
+    for m in range(m0, m1):
+        b = np.asarray(prov.beam_m(m, fi=f)).reshape(ntel, tel.num_pol_sky, tel.lmax + 1)[..., m:]
+        cnt = b.size
+        np.copyto(out[pos : pos + cnt].reshape(b.shape), b, casting="same_kind")
+        pos += cnt
+    return pos - off
+
+
 class PoolCycledProvider(BeamTransferProvider):
     """The *hbm-pool* residency policy of SURVEY 8d as a provider: frequency ``f`` uses the tiles of ``f % period``.
 

@@ -439,3 +439,52 @@ def test_cfg3_ml_early_reject_chunk_runs_beside_full_direct_batches():
     # rows of both frequencies against the oracle's SVD: certified tiles, the ill-conditioned ones of the early chunk, sky side
     _check_rows_against_oracle_svd(out, 34, mv, mw, 0, 0, (0, 120, 291, 296, 322, 330, 500), 1e-6)
     _check_rows_against_oracle_svd(out, 34, mv, mw, 1, 1, (3, 240, 293, 299, 323, 410), 1e-6)
+
+
+def test_cfg3_ml_two_stage_reduction_against_the_one_stage_reduction():
+    """The eigen path's tridiagonal reduction in both forms on one cfg-3 frequency, every tile decomposed: two-stage
+    (dense -> band of half-width 8 on the matrix cores -> tridiagonal by bulge chasing in LDS, "ml_reduce" = 0, the
+    default wherever the band fits the LDS) and one-stage Householder ("ml_reduce" = 1).  Telescope-side order 768 and
+    every sky-side order from 704 down to 64; the library's kernel-class timers say which reduction ran."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    tel = _tel(3, 1)
+    lmax = tel.lmax
+    bt = SyntheticProvider(tel, seed=35)
+    gen = torch.Generator(device=ctx.device).manual_seed(9)
+    shape = (lmax + 1, 2, 1, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) * 30.0 + 5.0
+    mw[torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) < 0.02] = 0.0
+    eng = SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED)
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    out, spans = {}, {}
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+        for red in (0, 1):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", red))
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
+            out[red] = eng.solve("ml", mv, mw, [0], lmax).cpu().numpy()
+            spans[red] = (counter(b"prof_band_n"), counter(b"prof_tridiag_n"))
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", 0))
+    assert spans[0][0] > 0 and spans[0][1] == 0, spans  # two-stage only
+    assert spans[1][0] == 0 and spans[1][1] > 0, spans  # one-stage only
+    assert np.all(np.isfinite(out[0]))
+    assert _rel(out[0], out[1]) < 1e-9
+    _check_rows_against_oracle_svd(out[0], 35, mv, mw, 0, 0, (1, 160, 323, 324, 390, 449, 497, 511), 1e-8)

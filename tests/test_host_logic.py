@@ -276,3 +276,32 @@ def test_container_save_load_keeps_datasets_and_attributes_like_the_reference(tm
     assert back.index_attrs["freq"]["alignment"] == 1
     assert tuple(back.vis.attrs["axis"]) == ("freq", "stack", "ra")
     assert np.array_equal(back.freq, ss.freq)
+
+
+def test_packed_store_pack_once_from_a_per_tile_provider(tmp_path):
+    """`PackedStoreProvider.pack`: a provider that only has per-tile `beam_m` (what a driftscan BeamTransfer offers,
+    mapmaker.py:160-162) is written ONCE, by worker processes, into a .npy file in the pool's wire format; the store
+    over the memory-mapped file returns the same tiles, `beam_block` hands out views of it, and a later process reopens
+    it without packing again."""
+    from draco_amd import _lib
+    from draco_amd.core.products import ArrayProvider, PackedStoreProvider, TransitTelescope, synth_beam_tile
+
+    lmax = 9
+    tel = TransitTelescope(np.linspace(400.0, 500.0, 3), lmax=lmax, ncyl=1, nfeed_cyl=3)
+    bt = ArrayProvider(tel, lambda m, f: synth_beam_tile(11, m, f, tel.npairs, 4, lmax))
+    for procs in (1, 3):
+        path = str(tmp_path / f"b{procs}.npy")
+        st = PackedStoreProvider.pack(bt, path, processes=procs, chunk_bytes=2048)  # many small chunks: every boundary
+        assert isinstance(st.store, np.memmap) and st.store.dtype == np.complex128
+        for f in range(tel.nfreq):
+            for m in range(lmax + 1):
+                assert np.array_equal(st.beam_m(m, fi=f), bt.beam_m(m, fi=f))
+        blk = st.beam_block(0, lmax + 1, 1, 2, np.complex128, _lib.DMM_B_PACKED)
+        assert np.shares_memory(blk, st.store)  # a view: nothing is packed again on the way to the GPU
+        ref = bt.beam_block(0, lmax + 1, 1, 2, np.complex128, _lib.DMM_B_PACKED)
+        assert np.array_equal(np.asarray(blk), ref)
+    again = PackedStoreProvider.open(tel, str(tmp_path / "b3.npy"))
+    assert np.array_equal(again.beam_m(5, fi=2), bt.beam_m(5, fi=2))
+    st64 = PackedStoreProvider.pack(bt, str(tmp_path / "c.npy"), dtype=np.complex64, processes=2)
+    assert st64.store.dtype == np.complex64
+    assert np.allclose(st64.beam_m(3, fi=0), bt.beam_m(3, fi=0), rtol=1e-6, atol=1e-7)

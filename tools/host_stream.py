@@ -81,6 +81,22 @@ def main():
             nf_small = ArrayProvider  # noqa: F841
             a = run(per_tile, b_dtype, two_freq, "per-tile beam_m provider complex128 (generic pack)", reps=1)
             assert np.array_equal(a, ref), "per-tile provider: a_lm differs"
+            # the same per-tile provider packed ONCE by worker processes into a memory-mapped .npy store: what a real
+            # driftscan product pays on the first day, and what every later day streams at
+            import tempfile
+
+            tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+            with tempfile.TemporaryDirectory(dir=tmpdir) as d:
+                path = os.path.join(d, "b_packed.npy")
+                t0 = time.perf_counter()
+                packed = PackedStoreProvider.pack(per_tile, path)
+                t_pack = time.perf_counter() - t0
+                nb = packed.store.size * packed.store.itemsize
+                out["arms"]["per-tile provider: one-time pack"] = {"seconds": t_pack, "b_GB": nb / 1e9, "GBs": nb / t_pack / 1e9, "where": d}
+                print("per-tile provider: one-time pack", json.dumps(out["arms"]["per-tile provider: one-time pack"]), flush=True)
+                a = run(packed, b_dtype, two_freq, "per-tile provider, second day: packed memory-mapped store (staged)")
+                assert np.array_equal(a, ref), "packed store: a_lm differs"
+                del packed
             del pageable, per_tile, st
         del store
         HostStager.release()
