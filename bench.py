@@ -802,7 +802,7 @@ def main():
             "b_residency": f"hbm-pool: {job.pool_freqs} frequencies' B tiles resident ({job.pool_bytes/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {job.pool_freqs}: {job.ncycle} slab(s) per day, filled once, resident across days",
             "solves_per_s": (lmax + 1) * job.nfreq_job / (elapsed / args.steps),
             "parallelism": f"freq-sharded x{world}, {args.scaling} scaling (no collective in the timed region)",
-            "alm2map": "side stream, per solved slab, beside the next slab's solves (BaseMapMaker.process)",
+            "alm2map": ("caller's stream, per solved slab, between the slabs' solves" if (args.no_overlap or args.b_dtype == "complex64") else "side stream, per solved slab, beside the next slab's solves") + " (BaseMapMaker.process; default by B storage type, DirtyMapMaker.overlap_sht)",
         },
         # SURVEY 8d asks for the stage times next to the metric; each measured alone on the GPU after warmup (in the
         # step the SHT runs beside the solves).  value_to_alm = (mmax+1) / (T_fft + T_solve): the metric with T ending

@@ -89,6 +89,10 @@ _SIGS = {
     "dmm_mmode_fill0": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "dmm_ringmap_window": (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "dmm_synth_beam_fill": (_i, [_vp, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, C.c_uint64, _vp]),
+    "dmm_comm_unique_id": (_i, [_vp]),
+    "dmm_comm_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "dmm_comm_destroy": (_i, [_vp]),
+    "dmm_allgather_map": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "dmm_beam_screen_coeffs": (_i, [C.c_uint64, _vp, _vp, _vp, _vp]),
     "dmm_beam_screen_maps": (_i, [_vp, _i, _i, _d, _d, C.c_uint64, _d, _d, _d, _d, _vp, _vp, _vp, _vp, _i, _vp]),
     "dmm_beam_screen_pack": (_i, [_vp, _vp, _i, _i, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, _i, _vp]),

@@ -58,7 +58,12 @@ class BaseMapMaker(ContainerTask):
         HBM budget for B tiles per slab (default: 60 % of free memory).
     overlap_sht : bool or None
         Run the inverse SHT of a finished slab on a side stream beside the next slab's solves (True) or on the
-        caller's stream between them (False).  None (default): beside them.  Not a reference attribute.
+        caller's stream between them (False).  None (default): beside them for complex128 B, between them for
+        complex64 B -- measured (profiles/r03_c64_overlap_ab.json): with complex128 the solves wait for HBM and the
+        SHT's FP64 work fills the gaps (+3.5 % per day); with complex64 the Dirty kernel is issue-bound (conversion +
+        FMA per 8 bytes), the SHT's waves take from it exactly what they get (0.69 instead of 0.81 of the HBM peak in
+        the step) and the day is 1.3 % slower.  Confining the SHT to a CU subset (16 / 32 / 48 CUs, round 2) lost
+        in every setting.  Not a reference attribute.
     days_in_flight : int
         How many ``process`` calls (sidereal days) the host may have queued on the GPU at once.  ``process`` never
         waits for its own day, but before it queues day ``d`` it waits -- on the host -- for day
@@ -139,7 +144,7 @@ class BaseMapMaker(ContainerTask):
         else:
             # the inverse SHT (:112) of the frequencies a slab has finished runs on a side stream
             # beside the next slab's fill + solves: it is compute-bound, they are HBM/PCIe-bound
-            overlap = True if self.overlap_sht is None else bool(self.overlap_sht)
+            overlap = (str(self.b_dtype) != "complex64") if self.overlap_sht is None else bool(self.overlap_sht)
             side = Context.side(ctx.device_index) if overlap else ctx
             main = torch.cuda.current_stream(ctx.device)
             out = {}

@@ -250,6 +250,23 @@ int dmm_analytic_beam_mmodes(dmm_ctx* ctx, int npol, int nfreq, int new_, int ne
                              const double* freq, const double* ew, const double* dec, const double* coef_a,
                              const double* coef_b, void* out);
 
+/* ------------------------------------------------ the map all-gather (the north star's one collective)
+ * The reference leaves the Map distributed over frequency (mapmaker.py:113-116: an MPIArray); a caller that wants every
+ * frequency on every rank gathers the rank-local shards [nfreq_local, 4, 12 nside^2] with ONE RCCL all-gather over xGMI.
+ * RCCL is loaded at run time (librccl.so); a single-GPU user never needs it.
+ *   dmm_comm_unique_id  rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by the caller's
+ *                       own means (MPI_Bcast, a file, torch.distributed ...)
+ *   dmm_comm_init       every rank: its context's device joins the communicator (ncclCommInitRank) -> *comm
+ *   dmm_allgather_map   full[r * count .. (r+1) * count) = rank r's shard[0 .. count), float64, on the context's stream
+ *                       (asynchronous like every kernel launch: dmm_ctx_sync before the host reads `full`); equal
+ *                       counts on all ranks (pad uneven frequency slabs)
+ *   dmm_comm_destroy    ncclCommDestroy                                                        */
+#define DMM_COMM_ID_BYTES 128
+int dmm_comm_unique_id(void* id_out /*[host, DMM_COMM_ID_BYTES]*/);
+int dmm_comm_init(dmm_ctx* ctx, const void* id /*[host]*/, int rank, int world, void** comm_out);
+int dmm_comm_destroy(void* comm);
+int dmm_allgather_map(dmm_ctx* ctx, void* comm, const double* shard /*[dev]*/, int64_t count, double* full /*[dev]*/);
+
 /* ------------------------------------------------ synthetic beam-transfer tiles
  * Fill tiles with the counter-hash generator shared with oracle/synth.py
  * (bit-identical in float64): value(seed, m, f, row, pol, l) with l<m -> 0.

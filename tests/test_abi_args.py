@@ -110,3 +110,19 @@ def test_context_calls():
     assert lib.dmm_ctx_destroy(None) == 0
     ms = C.c_float()
     _arg_error(lib.dmm_timer_stop(FAKE, None), "NULL argument")
+
+
+def test_collective_entry_points_validate_their_arguments():
+    """dmm_comm_* / dmm_allgather_map (the map all-gather of SURVEY 8e) check their arguments before RCCL is even loaded."""
+    lib = _lib.lib
+    out = C.c_void_p()
+    ident = (C.c_char * 128)()
+    _arg_error(lib.dmm_comm_unique_id(None), "NULL argument")
+    _arg_error(lib.dmm_comm_init(None, ident, 0, 1, C.byref(out)), "NULL argument")
+    _arg_error(lib.dmm_comm_init(FAKE, None, 0, 1, C.byref(out)), "NULL argument")
+    _arg_error(lib.dmm_comm_init(FAKE, ident, 2, 2, C.byref(out)), "rank 2 of 2")
+    _arg_error(lib.dmm_comm_init(FAKE, ident, 0, 0, C.byref(out)), "rank 0 of 0")
+    _arg_error(lib.dmm_allgather_map(FAKE, None, BUF, 8, BUF), "NULL argument")
+    _arg_error(lib.dmm_allgather_map(FAKE, FAKE, None, 8, BUF), "NULL argument")
+    _arg_error(lib.dmm_allgather_map(FAKE, FAKE, BUF, -1, BUF), "negative count")
+    assert lib.dmm_comm_destroy(None) == 0  # destroying nothing is fine

@@ -372,3 +372,32 @@ def test_single_polarisation_dense_solvers():
         w.make_alm(mm)
     with pytest.raises(ValueError, match="could not be broadcast"):
         w._solve_m(0, 0, mv[0, :, 0], mw[0, :, 0])
+
+
+def test_allgather_map_through_the_c_abi_on_a_one_rank_communicator():
+    """`dmm_allgather_map` (the one collective, behind the C ABI): RCCL is loaded at run time, a
+    communicator is made from an id (`dmm_comm_unique_id` / `dmm_comm_init`), and the all-gather runs on the
+    context's stream.  One GPU here, so one rank: the gathered map is the shard.  (Several ranks: the same calls, the id
+    handed round by the caller; the Python layer's gather over torch.distributed is covered in test_dist_gloo.py.)"""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.device import Context, ptr
+
+    ctx = Context.get()
+    lib = _lib.lib
+    ident = (C.c_char * 128)()
+    _lib.check(lib.dmm_comm_unique_id(ident))
+    assert bytes(ident) != bytes(128)
+    comm = C.c_void_p()
+    _lib.check(lib.dmm_comm_init(ctx.handle, ident, 0, 1, C.byref(comm)))
+    try:
+        shard = torch.randn((3, 4, 12 * 16 * 16), dtype=torch.float64, device=ctx.device)
+        full = torch.zeros_like(shard)
+        _lib.check(lib.dmm_allgather_map(ctx.handle, comm, ptr(shard), shard.numel(), ptr(full)))
+        ctx.sync()
+        assert torch.equal(full, shard)
+    finally:
+        _lib.check(lib.dmm_comm_destroy(comm))
