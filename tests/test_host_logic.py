@@ -130,11 +130,11 @@ def test_oracle_is_imported_only_where_it_may_be():
 
     for path in list((root / "draco_amd").rglob("*.py")) + list((root / "tools").rglob("*.py")):
         assert not oracle_imports(path), path
-    # bench.py: inside cpu_baseline and its worker only
+    # bench.py: inside the cpu_baseline legs (Dirty; ML / Wiener) and their workers only
     tree = ast.parse((root / "bench.py").read_text())
     allowed = set()
     for node in ast.walk(tree):
-        if isinstance(node, ast.FunctionDef) and node.name in ("cpu_baseline", "_cpu_worker"):
+        if isinstance(node, ast.FunctionDef) and node.name in ("cpu_baseline", "_cpu_worker", "cpu_baseline_dense", "_cpu_dense_worker"):
             allowed.update(range(node.lineno, node.end_lineno + 1))
     assert all(ln in allowed for ln in oracle_imports(root / "bench.py"))
     tree = ast.parse((root / "__graft_entry__.py").read_text())
