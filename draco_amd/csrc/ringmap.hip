@@ -331,6 +331,164 @@ __global__ __launch_bounds__(kThreads) void k_rm_fft(RmParams p, RmFft q) {
   }
 }
 
+// ---- the three stages in ONE pass over the m-modes (power-of-two nra, RA-space dirty beam not asked for, own-row
+// normalisation): a block owns 8 elevations of one (pol, freq) for ALL m.  Its 16 waves read the (sign, EW) terms of
+// 128 m at a time -- lane = (m, el): 64-byte pieces of the hv / bv rows, each lane 2 x nterm loads in flight --, keep the
+// sums in registers and put the map modes straight into the LDS image of the inverse FFT (two rows per complex
+// sequence, bit-reversed positions, the Hermitian mirror bins written by the odd row's lane); the per-row sums over m
+// never leave the block.  After the in-LDS FFT the RA rows go out as 64-byte pieces of map[ra][el] and weight[ra][el]:
+// the [pol, el, m] modes and the [pol, el, ra] rows of the three-kernel form (1.34 GB of scratch traffic beside 2.69 GB
+// of input and output at the CHIME-like shape) never reach HBM.  Two blocks of neighbouring elevations share every
+// 128-byte line of the input: block ids are mapped so that such a pair sits on the same XCD (same L2), 8 ids apart.
+constexpr int kFuThreads = 1024, kFuEl = 8;
+__global__ __launch_bounds__(kFuThreads) void k_rm_fused(RmParams p, RmFft q, int ntile_el) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_acc[3][kFuThreads / 64][kFuEl];
+  __shared__ double s_nrm[kFuEl], s_wv[kFuEl];
+  C<double>* buf = reinterpret_cast<C<double>*>(smem);  // [4][P]
+  C<double>* twl = buf + (size_t)4 * q.P;
+  const int N = p.nra, M = q.M, P = q.P;
+  // block -> (pf, elevation tile): ids L and L + 8 (same XCD under round-robin dispatch) take neighbouring tiles
+  const int L = blockIdx.x, grp = L >> 4, r16 = L & 15;
+  const int64_t tile_lin = (int64_t)2 * (grp * 8 + (r16 & 7)) + (r16 >> 3);
+  if (tile_lin >= (int64_t)ntile_el * p.npol * p.nfreq) return;
+  const int pf = (int)(tile_lin / ntile_el), tile = (int)(tile_lin - (int64_t)pf * ntile_el);
+  const int pol = pf / p.nfreq, f = pf - pol * p.nfreq;
+  const int el0 = tile * kFuEl;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int eli = lane & 7, ms = lane >> 3;
+  const int el = el0 + eli;
+  const bool el_ok = el < p.nel;
+  const int elc = el_ok ? el : p.nel - 1;
+  for (int k = threadIdx.x; k < (M >> 1); k += kFuThreads) twl[k] = {q.tw[k].x, q.tw[k].y};
+  const int nterm = 2 * p.new_;
+  double acc_d = 0.0, acc_q = 0.0, acc_p = 0.0;
+  // (measured, CHIME-like shape, 0.89 ms as it stands: the load phase alone takes 0.72 ms = 3.0 TB/s -- 64-byte pieces
+  // are what the LDS allows, 8 elevations x 2048 RA x 16 bytes --; two m per lane and pass, i.e. 32 loads in flight per
+  // lane: 0.93; the term weights from a table made by a pre-pass instead of in the loop: 0.95; blocks staggered over m
+  // so that they do not read the same rows at the same time: 1.07 -- lock step is what keeps the DRAM pages open.)
+  for (int mb = 0; mb < p.nm; mb += 8 * (kFuThreads / 64)) {
+    const int m = mb + wave * 8 + ms;
+    const bool m_ok = m < p.nm;
+    const int mc = m_ok ? m : p.nm - 1;
+    double sw = 0.0, mre = 0.0, mim = 0.0, sg = 0.0;
+    for (int t0 = 0; t0 < nterm; t0 += 8) {
+      // lane `eli` of the group works out the weights of term t0 + eli of its m; the group's lanes pick them up below
+      double w = 0.0, g = 0.0;
+      {
+        const int t = t0 + eli;
+        if (t < nterm) {
+          const int s = t / p.new_, e = t - s * p.new_;
+          const int64_t wbase = ((((int64_t)mc * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_;
+          double iv = (double)p.hw[wbase + e];
+          if (p.mode == 0) {
+            w = iv > 0.0 ? p.wt[e] : 0.0;
+          } else {
+            iv *= p.wt[e];
+            if (p.mode == 1) {
+              double wsumv = 0.0;
+              for (int e2 = 0; e2 < p.new_; ++e2) wsumv += (double)p.hw[wbase + e2] * p.wt[e2];
+              w = iv * (wsumv != 0.0 ? 1.0 / wsumv : 0.0);
+            } else {
+              w = iv;
+            }
+            if (!(iv > 0.0)) w = 0.0;
+          }
+          g = w * w * (iv > 0.0 ? 1.0 / iv : 0.0);
+        }
+      }
+      float2 h[8], b[8];
+      double w2[8], g2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool live = t0 + k < nterm;
+        const int tg = live ? t0 + k : nterm - 1, s = tg / p.new_, e = tg - s * p.new_;
+        const double wk = __shfl(w, (lane & ~7) + k, 64), gk = __shfl(g, (lane & ~7) + k, 64);
+        w2[k] = live ? wk : 0.0;
+        g2[k] = live ? gk : 0.0;
+        const int64_t rbase = (((((int64_t)mc * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_ + e) * p.nel + elc;
+        h[k] = p.hv[rbase];
+        b[k] = p.bv[rbase];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double br = b[k].x, bi = b[k].y, hr = h[k].x, hi = h[k].y;
+        const double b2 = br * br + bi * bi;
+        sw = fma(w2[k], b2, sw);
+        mre = fma(w2[k], br * hr + bi * hi, mre);  // conj(b) * h
+        mim = fma(w2[k], br * hi - bi * hr, mim);
+        sg = fma(g2[k], b2, sg);
+      }
+    }
+    double ar = 0.0, ai = 0.0;
+    if (m_ok && el_ok) {
+      const double cinv = p.eps[(int64_t)f * p.nm + m] + sw;  // (skip_deconvolution takes the three-kernel path)
+      const double ic = cinv != 0.0 ? 1.0 / cinv : 0.0;
+      const double win = p.window ? (double)p.window[((int64_t)f * p.nm + m) * p.nel + el] : 1.0;
+      ar = win * mre * ic;
+      ai = win * mim * ic;
+      const double rd = win * sw * ic;
+      const double qv = sqrt(sg) * win * ic / (double)(p.mmax + 1);
+      acc_d += rd;
+      acc_q += qv * qv;
+      acc_p += ((m == 0 || 2 * m == N) ? 1.0 : 2.0) * rd * rd;
+    }
+    const bool edge = m == 0 || 2 * m == N;  // DC and Nyquist bins are real, and their own mirror
+    if (edge) ai = 0.0;
+    // rows 2j (A) and 2j + 1 (B) share a transform: z = X_A + i X_B, loaded conjugated at the bit-reversed position
+    const double orr = __shfl_xor(ar, 1, 64), oi = __shfl_xor(ai, 1, 64);
+    if (m_ok) {
+      const bool odd = eli & 1;
+      const double a_r = odd ? orr : ar, a_i = odd ? oi : ai, b_r = odd ? ar : orr, b_i = odd ? ai : oi;
+      C<double>* row = buf + (size_t)(eli >> 1) * P;
+      if (!odd) row[dmm_fft::bitrev(m, q.logM)] = {a_r - b_i, -(a_i + b_r)};
+      else if (!edge) row[dmm_fft::bitrev(N - m, q.logM)] = {a_r + b_i, a_i - b_r};  // X[N - m] = conj(X[m]) of both rows
+    }
+  }
+  // the block's per-row sums over m: the 8 m of a wave by a butterfly, the waves in a fixed order
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    acc_d += __shfl_xor(acc_d, o, 64);
+    acc_q += __shfl_xor(acc_q, o, 64);
+    acc_p += __shfl_xor(acc_p, o, 64);
+  }
+  if (ms == 0) {
+    s_acc[0][wave][eli] = acc_d;
+    s_acc[1][wave][eli] = acc_q;
+    s_acc[2][wave][eli] = acc_p;
+  }
+  __syncthreads();
+  if (threadIdx.x < kFuEl) {
+    double d = 0.0, q2 = 0.0, p2 = 0.0;
+    for (int w2 = 0; w2 < kFuThreads / 64; ++w2) {
+      d += s_acc[0][w2][threadIdx.x];
+      q2 += s_acc[1][w2][threadIdx.x];
+      p2 += s_acc[2][w2][threadIdx.x];
+    }
+    const double mean = d / (double)p.nm;
+    const double nrm = mean != 0.0 ? 1.0 / mean : 0.0;
+    const double sv = 0.5 * nrm * nrm * q2;
+    s_nrm[threadIdx.x] = nrm;
+    s_wv[threadIdx.x] = sv != 0.0 ? 1.0 / sv : 0.0;
+    if (el0 + (int)threadIdx.x < p.nel) p.dbp[(int64_t)pf * p.nel + el0 + threadIdx.x] = nrm * nrm * p2 / (double)N / (double)N;  // Parseval
+  }
+  __syncthreads();
+  dmm_fft::fft_dit<double, false, kFuThreads>(buf, twl, 4, M, q.logM, P);
+  // y = conj(result) / N: even row = Re, odd row = -Im, each times its row's normalisation; 64-byte pieces of [ra][el]
+  {
+    const int e8 = threadIdx.x & 7;
+    const int ele = el0 + e8;
+    const double sc = s_nrm[e8] / (double)N, wv = s_wv[e8];
+    if (ele < p.nel)
+      for (int ra = threadIdx.x >> 3; ra < N; ra += kFuThreads / 8) {
+        const C<double> v = buf[(size_t)(e8 >> 1) * P + ra];
+        const int64_t o = ((int64_t)pf * p.nra + ra) * p.nel + ele;
+        p.map[o] = (e8 & 1) ? -v.y * sc : v.x * sc;
+        p.weight[o] = wv;
+      }
+  }
+}
+
 // [pf][el][ra] -> map[pf][ra][el] (+ dirty beam), weight[pf][ra][el] = wv[pf][el]; 32x32 tiles
 __global__ __launch_bounds__(kThreads) void k_rm_store(RmParams p) {
   __shared__ double ta[32][33], tb[32][33];
@@ -419,17 +577,6 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   q.RB = rb;
   const size_t lds = rb * row_b + (q.tw_in_lds ? tw_b : 0);
 
-  const int64_t nrow = (int64_t)npol * nfreq * nel;
-  const int nchunk = (nm + MT - 1) / MT;
-  const size_t b_map = (size_t)nrow * nm * sizeof(double2);
-  const size_t b_dirty = ((size_t)nrow * nm * sizeof(double) + 255) / 256 * 256;
-  const size_t b_psum = (size_t)npol * nfreq * nchunk * nel * sizeof(double4);
-  const size_t b_vec = ((size_t)nrow * sizeof(double) + 255) / 256 * 256;
-  const size_t b_tmp = (size_t)nrow * nra * sizeof(double);
-  void* scratch = nullptr;
-  rc = dmm_get_scratch(ctx, b_map + b_dirty + b_psum + b_vec + (dirty_beam ? 2 : 1) * b_tmp + 1024, &scratch);
-  if (rc) return rc;
-  unsigned char* sp = (unsigned char*)scratch;
   RmParams p;
   p.nm = nm;
   p.nm_beam = nm_beam;
@@ -442,28 +589,49 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   p.mode = weight_mode;
   p.skip = skip_deconvolution;
   p.iref = iref;
-  p.nchunk = nchunk;
   p.hv = (const float2*)hv;
   p.hw = hw;
   p.bv = (const float2*)bv;
   p.wt = ew_table;
   p.eps = eps;
   p.window = window;
+  p.dbp = dirty_beam_power;
+  p.map = map;
+  p.weight = weight;
+  p.db = dirty_beam;
+  // one pass over the m-modes where the whole inverse FFT of 8 elevations fits the LDS (power-of-two nra up to 2048)
+  const size_t fused_lds = (size_t)4 * q.P * sizeof(double2) + tw_b;
+  if (!dirty_beam && !skip_deconvolution && !q.blue && nra >= 8 && fused_lds <= 150 * 1024 && ctx->opt_ringmap_variant != 1) {
+    const int ntile_el = (nel + kFuEl - 1) / kFuEl;
+    const int64_t ntile = (int64_t)ntile_el * npol * nfreq;
+    DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+    hipLaunchKernelGGL(k_rm_fused, dim3((unsigned)((ntile + 15) / 16 * 16)), dim3(kFuThreads), fused_lds, ctx->stream, p, q, ntile_el);
+    DMM_HIP(hipGetLastError());
+    return DMM_OK;
+  }
+  const int64_t nrow = (int64_t)npol * nfreq * nel;
+  const int nchunk = (nm + MT - 1) / MT;
+  const size_t b_map = (size_t)nrow * nm * sizeof(double2);
+  const size_t b_dirty = ((size_t)nrow * nm * sizeof(double) + 255) / 256 * 256;
+  const size_t b_psum = (size_t)npol * nfreq * nchunk * nel * sizeof(double4);
+  const size_t b_vec = ((size_t)nrow * sizeof(double) + 255) / 256 * 256;
+  const size_t b_tmp = (size_t)nrow * nra * sizeof(double);
+  void* scratch = nullptr;
+  rc = dmm_get_scratch(ctx, b_map + b_dirty + b_psum + b_vec + (dirty_beam ? 2 : 1) * b_tmp + 1024, &scratch);
+  if (rc) return rc;
+  unsigned char* sp = (unsigned char*)scratch;
+  p.nchunk = nchunk;
   p.s_map = (double2*)sp;
   sp += b_map;
   p.s_dirty = (double*)sp;
   sp += b_dirty;
   p.psum = (double4*)sp;
   sp += b_psum;
-  p.dbp = dirty_beam_power;
   p.wv = (double*)sp;
   sp += b_vec;
   p.tmp_map = (double*)sp;
   sp += b_tmp;
   p.tmp_db = dirty_beam ? (double*)sp : nullptr;
-  p.map = map;
-  p.weight = weight;
-  p.db = dirty_beam;
 
   // (two elevations per lane with 16-byte loads were tried: 715 instead of 630 us for this kernel at the CHIME-like
   // shape -- half as many resident waves; the kernel is latency bound on its 16 loads per m)

@@ -75,6 +75,7 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * "ml_eigen" (eigen path of the ML solve: 0 = chosen by batch size; 4 = Householder tridiagonalisation + QL kept
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give
  * up on every other matrix, which exercises the Jacobi fallback),
+ * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies),
  * "ml_reduce" (tridiagonal reduction of the eigen path: 0 = two-stage, dense -> band of half-width 8 on the matrix
  * cores -> tridiagonal by bulge chasing in LDS, for orders whose band fits the LDS, one-stage Householder otherwise;
  * 1 = one-stage always),

@@ -218,3 +218,43 @@ def test_analytic_beam_vs_oracle(mmax, oddra, nel, nfreq):
     assert np.all(got[0, 1] == 0)
     if not oddra:
         assert np.all(got[mmax, 1] == 0)
+
+
+def test_single_pass_kernel_against_the_three_kernel_form():
+    """The single-pass kernel (power-of-two nra, no RA-space dirty beam, own-row normalisation: reduce, inverse FFT and
+    the [ra][el] store in one pass over the m-modes, 8 elevations per block) against the three-kernel form on the same
+    inputs ("ringmap_variant" = 1), at a shape with several m passes, partial elevation tiles and an odd row count."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.device import Context, ptr
+
+    ctx = Context.get()
+    nm, npol, nfreq, new, nel = 257, 2, 3, 4, 77
+    nra = 2 * (nm - 1)
+    gen = torch.Generator(device=ctx.device).manual_seed(3)
+    shp = (nm, 2, npol, nfreq, new, nel)
+    hv = torch.randn(shp, dtype=torch.complex64, device=ctx.device, generator=gen)
+    bv = torch.randn(shp, dtype=torch.complex64, device=ctx.device, generator=gen)
+    hw = torch.rand(shp[:-1], dtype=torch.float32, device=ctx.device, generator=gen) + 0.5
+    hw[torch.rand(shp[:-1], device=ctx.device, generator=gen) < 0.1] = 0
+    table = ctx.to_device(np.array([0.0, 1.0, 1.0, 1.0]), np.float64)  # first cylinder pair excluded
+    eps = ctx.to_device(np.full((nfreq, nm), 1e-2), np.float64)
+    win = torch.rand((nfreq, nm, nel), dtype=torch.float32, device=ctx.device, generator=gen)
+    out = {}
+    try:
+        for variant in (0, 1):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ringmap_variant", variant))
+            for mode in (0, 1, 2):
+                rmap = ctx.zeros((1, npol, nfreq, nra, nel), np.float64)
+                rwgt = ctx.zeros((npol, nfreq, nra, nel), np.float64)
+                rdbp = ctx.zeros((1, npol, nfreq, nel), np.float64)
+                _lib.check(_lib.lib.dmm_ringmap_deconvolve(ctx.handle, nm, nm, npol, nfreq, new, nel, nra, mode, 0, 0, ptr(hv), ptr(hw), ptr(bv),
+                                                           ptr(table), ptr(eps), ptr(win), ptr(rmap), ptr(rwgt), ptr(rdbp), None))
+                out[variant, mode] = [x.cpu().numpy() for x in (rmap, rwgt, rdbp)]
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ringmap_variant", 0))
+    for mode in (0, 1, 2):
+        for a, b in zip(out[0, mode], out[1, mode]):
+            assert np.all(np.isfinite(a))
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), mode
