@@ -89,6 +89,10 @@ _SIGS = {
     "dmm_mmode_fill0": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "dmm_ringmap_window": (_i, [_vp, _i, _i, _i, _vp, _vp, C.POINTER(C.c_double), _vp]),
     "dmm_synth_beam_fill": (_i, [_vp, C.POINTER(dmm_tile), _i64, _i, _i, _i, _i, _i, C.c_uint64, _vp]),
+    "dmm_calc_redundancy": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "dmm_vis_grid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dmm_beamform_ns": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dmm_beamform_ew": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dmm_comm_unique_id": (_i, [_vp]),
     "dmm_comm_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "dmm_comm_destroy": (_i, [_vp]),

@@ -69,6 +69,8 @@ class Dataset:
                 torch.complex128: np.complex128,
                 torch.float32: np.float32,
                 torch.float64: np.float64,
+                torch.int32: np.int32,
+                torch.uint8: np.uint8,
             }[self._dev_t.dtype]
         )
 
@@ -330,6 +332,19 @@ class SiderealStream(ContainerBase, _FreqMixin, _VisMixin):
     def ra(self):
         return self.index_map["ra"]
 
+    @property
+    def prodstack(self):
+        """The representative input pair of every stack entry, conjugation applied (``containers.py:211-229``)."""
+        prod = self.index_map["prod"]
+        stack = self.index_map.get("stack")
+        if stack is None or stack.dtype.names is None or "prod" not in stack.dtype.names:
+            return prod
+        t = prod[stack["prod"]].copy()
+        conj = stack["conjugate"].astype(bool)
+        t["input_a"] = np.where(conj, prod[stack["prod"]]["input_b"], prod[stack["prod"]]["input_a"])
+        t["input_b"] = np.where(conj, prod[stack["prod"]]["input_a"], prod[stack["prod"]]["input_b"])
+        return t
+
 
 class MContainer(ContainerBase):
     """m-mode containers: axes ``m``, ``msign`` and the ``oddra`` attribute (``containers.py:422-467``)."""
@@ -373,10 +388,51 @@ class HybridVisStream(ContainerBase, _FreqMixin, _VisMixin):
         "vis_weight": {"axes": ["pol", "freq", "ew", "ra"], "dtype": np.float32},
     }
 
+    _optional_spec = {"dirty_beam": {"axes": ["pol", "freq", "ew", "el", "ra"], "dtype": np.float32}}  # containers.py:1409-1417
+
     def __init__(self, ra=None, **kwargs):
         if isinstance(ra, (int, np.integer)):
             ra = np.linspace(0.0, 360.0, int(ra), endpoint=False)
+        self._dataset_spec = dict(type(self)._dataset_spec)
         super().__init__(ra=ra, **kwargs)
+
+    def add_dataset(self, name, allocate=False):
+        self._dataset_spec[name] = self._optional_spec[name]
+        if allocate:
+            self.datasets[name] = Dataset(host=np.zeros(self.dataset_shape(name), dtype=self._optional_spec[name]["dtype"]))
+
+    @property
+    def dirty_beam(self):
+        return self.datasets["dirty_beam"]
+
+
+class VisGridStream(ContainerBase, _FreqMixin, _VisMixin):
+    """Visibilities on the (pol, ew, ns) baseline grid: ``vis [pol, freq, ew, ns, ra]`` c64, ``vis_weight`` f32, optional
+    ``redundancy [pol, ew, ns, ra]`` int32 (``containers.py:1245-1299``)."""
+
+    _axes = ("pol", "freq", "ew", "ns", "ra")
+    _dataset_spec = {
+        "vis": {"axes": ["pol", "freq", "ew", "ns", "ra"], "dtype": np.complex64},
+        "vis_weight": {"axes": ["pol", "freq", "ew", "ns", "ra"], "dtype": np.float32},
+    }
+    _optional_spec = {"redundancy": {"axes": ["pol", "ew", "ns", "ra"], "dtype": np.int32}}
+
+    def __init__(self, ra=None, **kwargs):
+        if isinstance(ra, (int, np.integer)):
+            ra = np.linspace(0.0, 360.0, int(ra), endpoint=False)
+        self._dataset_spec = dict(type(self)._dataset_spec)
+        super().__init__(ra=ra, **kwargs)
+
+    def add_dataset(self, name, allocate=False):
+        self._dataset_spec[name] = self._optional_spec[name]
+        if allocate:
+            self.datasets[name] = Dataset(host=np.zeros(self.dataset_shape(name), dtype=np.int32))
+
+    @property
+    def redundancy(self):
+        if "redundancy" in self.datasets:
+            return self.datasets["redundancy"]
+        raise KeyError("Dataset 'redundancy' not initialised.")
 
 
 class HybridVisMModes(MContainer, _FreqMixin, _VisMixin):
@@ -402,6 +458,7 @@ class RingMap(ContainerBase, _FreqMixin):
     _optional_spec = {
         "dirty_beam": {"axes": ["beam", "pol", "freq", "ra", "el"], "dtype": np.float64},
         "dirty_beam_power": {"axes": ["beam", "pol", "freq", "el"], "dtype": np.float64},
+        "rms": {"axes": ["pol", "freq", "ra"], "dtype": np.float64},  # containers.py:1643-1650
     }
 
     def __init__(self, ra=None, **kwargs):
@@ -430,6 +487,10 @@ class RingMap(ContainerBase, _FreqMixin):
     @property
     def dirty_beam_power(self):
         return self.datasets["dirty_beam_power"]
+
+    @property
+    def rms(self):
+        return self.datasets["rms"]
 
 
 class SVDSpectrum(ContainerBase):

@@ -68,7 +68,16 @@ def synth_beam_tile(seed, m, f, npairs, npol, lmax):
 class TransitTelescope:
     """The telescope attributes the path reads (driftscan ``TransitTelescope`` [3P])."""
 
-    def __init__(self, frequencies, lmax, mmax=None, num_pol_sky=4, ncyl=1, nfeed_cyl=8, npol_feed=2, npairs=None):
+    cyl_sep = 22.0      # metres between cylinder centres (east-west)
+    feed_sep = 0.3048   # metres between feed positions along a cylinder (north-south)
+
+    def __init__(self, frequencies, lmax, mmax=None, num_pol_sky=4, ncyl=1, nfeed_cyl=8, npol_feed=2, npairs=None, pair_rule="canonical"):
+        #: how a redundancy class picks its representative pair.  "canonical" (default): the smaller of the pair's key and
+        #: its conjugate's -- XY at separation d and YX at -d are one class.  "halfplane": the member whose separation
+        #: pos_a - pos_b lies in the half plane x > 0 (x = 0: y > 0; same position: feed order) -- every class then has
+        #: x >= 0 and all four polarisation pairs occur, the layout MakeVisGrid (ringmapmaker.py:81-176) expects of
+        #: driftscan's `uniquepairs` / `baselines`
+        self.pair_rule = str(pair_rule)
         self.frequencies = np.asarray(frequencies, dtype=np.float64)
         self.nfreq = len(self.frequencies)
         self.lmax = int(lmax)
@@ -101,7 +110,12 @@ class TransitTelescope:
                 key = (pi, pj, cj - ci, yj - yi)
                 ckey = (pj, pi, ci - cj, yi - yj)
                 conj = 0
-                if ckey < key:
+                if self.pair_rule == "halfplane":
+                    # separation of the oriented pair (a, b) = pos_a - pos_b: (i, j) has (ci - cj, yi - yj)
+                    sx, sy = ci - cj, yi - yj
+                    if sx < 0 or (sx == 0 and sy < 0):
+                        key, conj = ckey, 1
+                elif ckey < key:
                     key, conj = ckey, 1
                 groups.setdefault(key, []).append((len(prod), conj))
                 prod.append((i, j))
@@ -127,6 +141,20 @@ class TransitTelescope:
         self.redundancy = np.array([len(groups[k]) for k in keys], dtype=np.float64)
         up = self.index_map_prod[self.index_map_stack["prod"]]
         self.uniquepairs = np.stack([up["input_a"].astype(int), up["input_b"].astype(int)], axis=1)
+        # geometry of the regular grid (driftscan's `feedpositions`, `polarisation`, `baselines`, `prodstack` [3P], as
+        # MakeVisGrid reads them, ringmapmaker.py:81-106): cylinders `cyl_sep` metres apart east-west, feeds `feed_sep`
+        # apart north-south, polarisation X / Y alternating per position
+        self.feedpositions = np.array([(c * self.cyl_sep, y * self.feed_sep) for c, y, _ in pos], dtype=np.float64)
+        self.polarisation = np.array(["XY"[pl % 2] for _, _, pl in pos])
+        # `prodstack`: the pair each stack entry's DATA belongs to -- the representative product with its inputs swapped
+        # where the stack entry is the conjugate (containers.py:211-229 applies the same rule to a stream's prodstack);
+        # `baselines` follows it, so that polarisation pair, separation and data of a stack entry agree
+        ps = up.copy()
+        cj = self.index_map_stack["conjugate"].astype(bool)
+        ps["input_a"] = np.where(cj, up["input_b"], up["input_a"])
+        ps["input_b"] = np.where(cj, up["input_a"], up["input_b"])
+        self.prodstack = ps
+        self.baselines = self.feedpositions[ps["input_a"].astype(int)] - self.feedpositions[ps["input_b"].astype(int)]
 
 
 _NPDT = {_lib.DMM_C128: np.complex128, _lib.DMM_C64: np.complex64}

@@ -74,6 +74,13 @@ __device__ __forceinline__ void cfmac(double2& a, double2 b, double2 c) {
   a.y = __builtin_fma(b.x, c.y, __builtin_fma(-b.y, c.x, a.y));
 }
 
+// 1 / x from the hardware seed (~2^-26) and one cubically convergent correction: full double precision for normal x
+// (a true division is ~10 dependent instructions twice per reflector on the chase's critical path)
+__device__ __forceinline__ double sb_rcp(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, __builtin_fma(e, e, e), y);
+}
 // The zlarfg rule: H^H (alpha; x) = (beta; 0), H = I - tau (1; v)(1; v)^H, v = x * scale, beta real.
 struct SbRefl {
   double2 tau, scale;
@@ -84,9 +91,9 @@ __device__ __forceinline__ SbRefl sb_larfg(double2 alpha, double xnorm2) {
   const bool id = xnorm2 == 0.0 && alpha.y == 0.0;
   const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2);
   const double b = alpha.x >= 0.0 ? -nrm : nrm;
-  const double ib = 1.0 / b;
+  const double ib = sb_rcp(b);
   const double2 dn = make_double2(alpha.x - b, alpha.y);
-  const double q = 1.0 / (dn.x * dn.x + dn.y * dn.y);
+  const double q = sb_rcp(dn.x * dn.x + dn.y * dn.y);
   r.tau = make_double2(id ? 0.0 : (b - alpha.x) * ib, id ? 0.0 : -alpha.y * ib);
   r.scale = make_double2(id ? 0.0 : dn.x * q, id ? 0.0 : -dn.y * q);
   r.beta = id ? alpha.x : b;
@@ -453,19 +460,59 @@ __global__ __launch_bounds__(kThreads) void k_sb_sweep(TdParams tp) {
 // (pitch n + 1: the 8 lanes of a column spread over the banks), bulge triangles bg[s][i (i - 1) / 2 + c], c < i <= 6, in
 // the coordinates of the sweep that reads them.  Blocks of sweep j: D_s = rows / columns R_s = [j + 1 + 8 s, + 8),
 // O_s = rows R_{s+1} x columns R_s.
-__device__ __forceinline__ double2 sb_sum_over_c(double2 v) {  // sum over the lanes of equal i (c = lane >> 3)
-  v.x += __shfl_xor(v.x, 8), v.y += __shfl_xor(v.y, 8);
-  v.x += __shfl_xor(v.x, 16), v.y += __shfl_xor(v.y, 16);
-  v.x += __shfl_xor(v.x, 32), v.y += __shfl_xor(v.y, 32);
-  return v;
+// Cross-lane traffic of the chase without the LDS crossbar (ds_bpermute: ~150 cycles each in a dependent chain, 84 of
+// them per iteration in the first version): the sums over 8 lanes are DPP moves (quad permutes, half-row mirror, row
+// rotation by 8) and, across the 16-lane rows, gfx950's v_permlane16_swap / v_permlane32_swap -- all vector-ALU
+// instructions.  Checked lane by lane against plain sums in tools/probe/dpp_probe.hip.
+typedef unsigned sb_v2u __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double sb_dpp(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double2 sb_sum_over_i(double2 v) {  // sum over the lanes of equal c (i = lane & 7)
-  v.x += __shfl_xor(v.x, 1), v.y += __shfl_xor(v.y, 1);
-  v.x += __shfl_xor(v.x, 2), v.y += __shfl_xor(v.y, 2);
-  v.x += __shfl_xor(v.x, 4), v.y += __shfl_xor(v.y, 4);
-  return v;
+__device__ __forceinline__ double sb_add_x16(double x) {  // x + x(lane ^ 16)
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const sb_v2u a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
+__device__ __forceinline__ double sb_add_x32(double x) {  // x + x(lane ^ 32)
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const sb_v2u a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double sb_sum8_c(double x) {  // sum over the 8 lanes of equal i (c = lane >> 3): every lane gets it
+  x += sb_dpp<0x128>(x);  // row_ror:8  (lane ^ 8 within the 16-lane row)
+  x = sb_add_x16(x);
+  return sb_add_x32(x);
+}
+__device__ __forceinline__ double sb_sum8_i(double x) {  // sum over the 8 lanes of equal c (i = lane & 7)
+  x += sb_dpp<0xB1>(x);   // quad_perm [1, 0, 3, 2]
+  x += sb_dpp<0x4E>(x);   // quad_perm [2, 3, 0, 1]
+  x += sb_dpp<0x141>(x);  // row_half_mirror: the other quad of the 8
+  return x;
+}
+__device__ __forceinline__ double2 sb_sum_over_c(double2 v) { return make_double2(sb_sum8_c(v.x), sb_sum8_c(v.y)); }
+__device__ __forceinline__ double2 sb_sum_over_i(double2 v) { return make_double2(sb_sum8_i(v.x), sb_sum8_i(v.y)); }
 __device__ __forceinline__ double2 sb_shfl2(double2 v, int src) { return make_double2(__shfl(v.x, src), __shfl(v.y, src)); }
+// the value of lane 0 in every lane (lane 0 is always active here): through a scalar register
+__device__ __forceinline__ double sb_lane0(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ double2 sb_lane0(double2 v) { return make_double2(sb_lane0(v.x), sb_lane0(v.y)); }
+// lanes 0..7 (c = 0) hold v_i: give every lane (i, c) its v_i.  Second half of row 0 by a row rotation, then row 0 into
+// the other three rows by the two swaps (what rows 1..3 held is irrelevant)
+__device__ __forceinline__ double sb_bcast_c0(double x, int lane) {
+  const double r = sb_dpp<0x128>(x);
+  x = (lane & 8) ? r : x;
+  unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  lo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[0];
+  hi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false)[0];
+  lo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[0];
+  hi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false)[0];
+  return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ double2 sb_bcast_c0(double2 v, int lane) { return make_double2(sb_bcast_c0(v.x, lane), sb_bcast_c0(v.y, lane)); }
 
 // kSbWaves waves per matrix, wave w taking the sweeps j = w, w + W, ...: sweep j may run iteration s once sweep j - 1 has
 // finished its iteration s + 2 (iteration s of sweep j touches the indices j + 1 + 8 s .. j + 8 s + 16, the iterations
@@ -522,14 +569,14 @@ __global__ __launch_bounds__(64 * kSbWaves) void k_sb_chase(TdParams tp) {
     double2 tau, vi;
     {
       const double2 xx = make_double2((c == 0 && i > 0) ? x.x * x.x + x.y * x.y : 0.0, 0.0);
-      const double xn2 = __shfl(sb_sum_over_i(xx).x, 0);
-      const double2 alpha = sb_shfl2(x, 0);
+      const double xn2 = sb_lane0(sb_sum8_i(xx.x));
+      const double2 alpha = sb_lane0(x);
       const SbRefl rf = sb_larfg(alpha, xn2);
       tau = rf.tau;
       const double2 scale = rf.scale;
       const double beta = rf.beta;
       const double2 vv = sel2(i == 0, make_double2(1.0, 0.0), cmul(x, scale));  // valid in lanes c = 0
-      vi = sb_shfl2(vv, i);                                                   // v_i for every lane
+      vi = sb_bcast_c0(vv, lane);                                             // v_i for every lane
       if (r0 + i >= n) vi = SB_ZERO;
       if (lane == 0) {
         ab[1 * pitch + j] = make_double2(beta, 0.0);
@@ -557,7 +604,7 @@ __global__ __launch_bounds__(64 * kSbWaves) void k_sb_chase(TdParams tp) {
         u = sb_sum_over_c(u);  // u_i
         double2 vhu = SB_ZERO;
         if (c == 0) cfmac(vhu, vi, u);
-        const double h = __shfl(sb_sum_over_i(vhu).x, 0);  // v^H u (real)
+        const double h = sb_lane0(sb_sum8_i(vhu.x));  // v^H u (real)
         const double t2 = 0.5 * (tau.x * tau.x + tau.y * tau.y) * h;
         double2 wi = cmul(tau, u);
         wi.x -= t2 * vi.x, wi.y -= t2 * vi.y;
@@ -582,13 +629,13 @@ __global__ __launch_bounds__(64 * kSbWaves) void k_sb_chase(TdParams tp) {
       cfma(ov, cmul(tau, tv), make_double2(-vc.x, vc.y));
       // reflector of the block's first column
       const double2 xx = make_double2((c == 0 && i > 0) ? ov.x * ov.x + ov.y * ov.y : 0.0, 0.0);
-      const double xn2 = __shfl(sb_sum_over_i(xx).x, 0);
-      const double2 alpha = sb_shfl2(ov, 0);
+      const double xn2 = sb_lane0(sb_sum8_i(xx.x));
+      const double2 alpha = sb_lane0(ov);
       const SbRefl rf = sb_larfg(alpha, xn2);
       const double2 tau2 = rf.tau, scale = rf.scale;
       const double beta = rf.beta;
       const double2 vv = sel2(i == 0, make_double2(1.0, 0.0), cmul(ov, scale));  // valid in lanes c = 0
-      double2 v2 = sb_shfl2(vv, i);
+      double2 v2 = sb_bcast_c0(vv, lane);
       if (q0 + i >= n) v2 = SB_ZERO;
       // O <- H2^H O = O - conj(tau2) v2 (v2^H O)
       double2 sc = SB_ZERO;

@@ -19,6 +19,8 @@ _NP2TORCH = {
     np.dtype(np.complex128): torch.complex128,
     np.dtype(np.float32): torch.float32,
     np.dtype(np.float64): torch.float64,
+    np.dtype(np.int32): torch.int32,
+    np.dtype(np.uint8): torch.uint8,
 }
 
 

@@ -268,6 +268,36 @@ int dmm_comm_init(dmm_ctx* ctx, const void* id /*[host]*/, int rank, int world, 
 int dmm_comm_destroy(void* comm);
 int dmm_allgather_map(dmm_ctx* ctx, void* comm, const double* shard /*[dev]*/, int64_t count, double* full /*[dev]*/);
 
+/* ------------------------------------------------ ring-map chain: MakeVisGrid -> BeamformNS -> BeamformEW
+ * (reference ringmapmaker.py:38-534; the producers of the HybridVisStream the deconvolving makers start from).
+ * dmm_calc_redundancy: tools.calculate_redundancy (tools.py:313-356): redundancy[s, t] = sum over the products stacked into
+ *   s of flags[a, t] flags[b, t] (all_good: every flag counts as 1, the reference's rule when no flag is set).
+ *   input_flags [dev] float [ninput, nra]; prod_a / prod_b / stack_index [dev] int32 [nprod]; redundancy [dev] float [nstack, nra]
+ * dmm_vis_grid: the grid of MakeVisGrid.process (:166-176) as a gather: cell c of polarisation pol takes stack src[c]
+ *   (conjugated where conj[c]) or stays empty (src < 0).
+ *   vis [dev] complex64 [nfreq, nstack, nra], weight float same; src / conj [dev] [npol * ncell_pol];
+ *   grid_vis [dev] complex64 [npol, nfreq, ncell_pol (= ew x ns), nra], grid_weight float same, grid_red int32 [npol, ncell_pol, nra] or NULL
+ * dmm_beamform_ns: BeamformNS.process (:299-346) for all frequencies of the slab. weight_mode 0 inverse variance, 1 natural
+ *   (redundancy), 2 a window table ns_window [dev] double [nfreq, ny] (window_generalised of the scaled baseline, made by the
+ *   caller); the weights are masked by weight > 0, the autos dropped unless include_auto, normalised over ns.
+ *   nspos [dev] double [ny] metres, el [dev] double [npix], inv_wavelength [host] double [nfreq] (1/m);
+ *   hv [dev] complex64 [npol, nfreq, nx, npix, nra], hw float [npol, nfreq, nx, nra], dirty_beam float like hv or NULL.
+ *   float64 arithmetic (the reference's `precision = 64`), float32 stores like the reference's containers.
+ * dmm_beamform_ew: BeamformEW.process (:455-495): pol_rotation [dev] complex128 [npol_out, npol_in], weight_ew [dev] double
+ *   [nx] (normalised; single_beam: the central beam only); map [dev] double [nbeam, npol_out, nfreq, nra, nel],
+ *   weight [npol_out, nfreq, nra, nel], rms [npol_out, nfreq, nra]; dirty beam in (float, real) / out (like map) or both NULL. */
+int dmm_calc_redundancy(dmm_ctx* ctx, const float* input_flags, int ninput, int nra, const int32_t* prod_a, const int32_t* prod_b,
+                        const int32_t* stack_index, int64_t nprod, int nstack, int all_good, float* redundancy);
+int dmm_vis_grid(dmm_ctx* ctx, const void* vis, const float* weight, const float* redundancy, int nfreq, int nstack, int nra, int npol,
+                 int ncell_pol, const int32_t* src, const uint8_t* conj, void* grid_vis, float* grid_weight, int32_t* grid_red);
+int dmm_beamform_ns(dmm_ctx* ctx, int npol, int nfreq, int nx, int ny, int nra, int npix, int weight_mode, int include_auto,
+                    const void* grid_vis, const float* grid_weight, const int32_t* grid_red, const double* ns_window,
+                    const double* nspos, const double* el, const double* inv_wavelength /*[host]*/, void* hv, float* hw,
+                    float* dirty_beam);
+int dmm_beamform_ew(dmm_ctx* ctx, int npol_in, int npol_out, int nfreq, int nx, int nel, int nra, int single_beam, const void* hv,
+                    const float* hw, const float* dirty_beam_in, const void* pol_rotation, const double* weight_ew, double* map,
+                    double* weight, double* rms, double* dirty_beam_out);
+
 /* ------------------------------------------------ synthetic beam-transfer tiles
  * Fill tiles with the counter-hash generator shared with oracle/synth.py
  * (bit-identical in float64): value(seed, m, f, row, pol, l) with l<m -> 0.

@@ -1375,6 +1375,222 @@ def gen_fgfilter(out):
     np.savez_compressed(os.path.join(out, "fgfilter.npz"), **cases)
 
 
+
+# --------------------------------------------------------------------------- ring-map chain (MakeVisGrid, BeamformNS, BeamformEW)
+class _GridDS(_DS):
+    """Dataset stub whose `[:]` has `local_array` and `enumerate(axis)` (one rank)."""
+
+    class _A(_Arr):
+        def enumerate(self, axis):
+            return [(i, i) for i in range(self.shape[axis])]
+
+    def __init__(self, arr):
+        self.arr = arr.view(_GridDS._A)
+
+
+class FakeGridIn(_FakeCont):
+    """The SiderealStream MakeVisGrid.process reads (ringmapmaker.py:68-176)."""
+
+    def __init__(self, vis, weight, prodstack, prod, rev_stack, input_flags, ra, freq):
+        self.vis = _GridDS(vis)
+        self.weight = _GridDS(weight)
+        self.prodstack = prodstack
+        self.input_flags = _DS(input_flags)
+        self.index_map = {"prod": prod, "ra": ra, "freq": freq}
+        self.reverse_map = {"stack": rev_stack}
+        self.ra = ra
+        self.attrs = {"tag": "chain"}
+        self.freq = freq
+
+
+class FakeVisGridStream(_FakeCont):
+    def __init__(self, pol=None, ew=None, ns=None, ra=None, axes_from=None, attrs_from=None):
+        nfreq = axes_from.vis.shape[0]
+        self.index_map = {"pol": np.asarray(pol), "ew": np.asarray(ew), "ns": np.asarray(ns), "ra": np.asarray(ra), "freq": axes_from.freq}
+        shp = (len(pol), nfreq, len(ew), len(ns), len(ra))
+        self.vis = _GridDS(np.zeros(shp, np.complex64))
+        self.weight = _GridDS(np.zeros(shp, np.float32))
+        self.datasets = {"vis": self.vis, "vis_weight": self.weight}
+        self.freq = np.asarray(axes_from.freq, dtype=float)
+        self.attrs = dict(attrs_from.attrs)
+
+    def add_dataset(self, name):
+        assert name == "redundancy"
+        p, _, e, n, r = self.vis.shape
+        self.redundancy = _GridDS(np.zeros((p, e, n, r), np.int32))
+        self.datasets["redundancy"] = self.redundancy
+
+
+class FakeHybridOut(_FakeCont):
+    def __init__(self, el=None, axes_from=None, attrs_from=None):
+        g = axes_from
+        p, f, e, _, r = g.vis.shape
+        self.index_map = dict(g.index_map)
+        self.index_map["el"] = np.asarray(el)
+        self.vis = _GridDS(np.zeros((p, f, e, len(el), r), np.complex64))
+        self.weight = _GridDS(np.zeros((p, f, e, r), np.float32))
+        self.datasets = {"vis": self.vis, "vis_weight": self.weight}
+        self.freq = g.freq
+        self.attrs = dict(attrs_from.attrs)
+
+    def add_dataset(self, name):
+        assert name == "dirty_beam"
+        self.dirty_beam = _GridDS(np.zeros(self.vis.shape, np.float32))
+        self.datasets["dirty_beam"] = self.dirty_beam
+
+
+class FakeChainRingMap(_FakeCont):
+    def __init__(self, beam=None, pol=None, axes_from=None, attrs_from=None):
+        h = axes_from
+        _, f, _, nel, nra = h.vis.shape
+        self.index_map = dict(h.index_map)
+        self.index_map["pol"] = np.asarray(pol)
+        self._shape = (beam, len(pol), f, nra, nel)
+        self.map = _GridDS(np.zeros(self._shape, np.float64))  # (containers.py:1597-1645: float64 datasets)
+        self.weight = _GridDS(np.zeros(self._shape[1:], np.float64))
+        self.attrs = dict(attrs_from.attrs)
+
+    def add_dataset(self, name):
+        shp = {"rms": self._shape[1:4], "dirty_beam": self._shape}[name]
+        setattr(self, name, _GridDS(np.zeros(shp, np.float64)))
+
+
+class _ChainTel:
+    """The telescope attributes MakeVisGrid reads: a two-cylinder grid, two polarisations, stacked products."""
+
+    def __init__(self, ncyl=2, nfeed_cyl=4, cyl_sep=22.0, feed_sep=0.3048):
+        pos, pol = [], []
+        for c in range(ncyl):
+            for y in range(nfeed_cyl):
+                for pl in "XY":
+                    pos.append((c * cyl_sep, y * feed_sep))
+                    pol.append(pl)
+        self.feedpositions = np.array(pos)
+        self.polarisation = np.array(pol)
+        n = len(pos)
+        groups, prod = {}, []
+        for i in range(n):
+            for j in range(i, n):
+                d = self.feedpositions[i] - self.feedpositions[j]
+                key = (pol[i], pol[j], round(d[0], 4), round(d[1], 4))
+                groups.setdefault(key, []).append(len(prod))
+                prod.append((i, j))
+        self.prod = np.array(prod, dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        keys = list(groups)
+        self.uniquepairs = np.array([prod[groups[k][0]] for k in keys])
+        self.baselines = np.array([self.feedpositions[i] - self.feedpositions[j] for i, j in self.uniquepairs])
+        self.prodstack = np.array([tuple(x) for x in self.uniquepairs], dtype=[("input_a", "<u2"), ("input_b", "<u2")])
+        rev = np.zeros(len(prod), dtype=[("stack", "<u4"), ("conjugate", "u1")])
+        for s_, k in enumerate(keys):
+            for pidx in groups[k]:
+                rev[pidx] = (s_, 0)
+        self.reverse_stack = rev
+        self.nfeed = n
+
+
+def gen_ringmap_chain(out):
+    """MakeVisGrid.process (ringmapmaker.py:68-176), BeamformNS.process (:230-346), BeamformEW.process (:372-497) run
+    from the reference source on duck-typed containers.  `tools.calculate_redundancy`'s compiled helper is the NumPy
+    loop used for CollateProducts above."""
+    import importlib
+    import types
+
+    from draco.analysis import ringmapmaker as rmk
+
+    ft = importlib.import_module("draco.util._fast_tools")
+
+    def _calc_redundancy(input_flags, pm, stack_index, nstack, redundancy):
+        for ii in range(pm.shape[0]):
+            ist = stack_index[ii]
+            if 0 <= ist < nstack:
+                redundancy[ist] += input_flags[pm[ii, 0]] * input_flags[pm[ii, 1]]
+
+    rmk.tools._calc_redundancy = _calc_redundancy
+    rmk.containers = type("NS", (), {"VisGridStream": FakeVisGridStream, "HybridVisStream": FakeHybridOut, "RingMap": FakeChainRingMap})
+    rmk.io.get_telescope = lambda t: t
+    rmk.MPI = types.SimpleNamespace(MAX="max")
+    rng = np.random.default_rng(8008)
+    cases = {}
+    tel = _ChainTel()
+    nfreq, nra = 3, 10
+    freq = np.array([420.0, 610.0, 780.0])
+    fmap = np.zeros(nfreq, dtype=[("centre", float), ("width", float)])
+    fmap["centre"], fmap["width"] = freq, 10.0
+    ra = np.linspace(0.0, 360.0, nra, endpoint=False)
+    nstack = len(tel.prodstack)
+    vis = crandn(rng, (nfreq, nstack, nra), np.complex64)
+    w = rng.uniform(0.5, 1.5, (nfreq, nstack, nra)).astype(np.float32)
+    w[rng.uniform(size=w.shape) < 0.1] = 0.0
+    flags = (rng.uniform(size=(tel.nfeed, nra)) > 0.15).astype(np.float32)
+    cases["freq"], cases["ra"], cases["vis"], cases["weight"], cases["input_flags"] = freq, ra, vis, w, flags
+    cases["feedpositions"], cases["polarisation"] = tel.feedpositions, tel.polarisation
+    cases["prod"], cases["uniquepairs"], cases["rev_stack"] = tel.prod, tel.uniquepairs, tel.reverse_stack["stack"]
+
+    class _Comm:
+        def allreduce(self, x, op=None):
+            return x
+
+    grids = {}
+    for centered in (False, True):
+        t = rmk.MakeVisGrid.__new__(rmk.MakeVisGrid)
+        t.centered, t.save_redundancy, t.telescope = centered, True, tel
+        sin = FakeGridIn(vis.copy(), w.copy(), tel.prodstack, tel.prod, tel.reverse_stack, flags.copy(), ra, freq)
+        sin.freq = freq
+        g = t.process(sin)
+        grids[centered] = g
+        k = f"grid{int(centered)}"
+        cases[k + "_vis"], cases[k + "_weight"] = g.vis.arr.view(np.ndarray), g.weight.arr.view(np.ndarray)
+        cases[k + "_red"] = g.redundancy.arr.view(np.ndarray)
+        cases[k + "_pol"], cases[k + "_ew"], cases[k + "_ns"] = g.index_map["pol"], g.index_map["ew"], g.index_map["ns"]
+    # BeamformNS on the (uncentred) grid, every weight scheme
+    idx = 0
+    hybrids = []
+    for weight, scaled, include_auto, sdb, npix, span in (("natural", False, False, True, 9, 1.0), ("uniform", False, True, False, 8, 0.8),
+                                                          ("inverse_variance", False, False, True, 7, 1.0), ("hann", True, False, False, 6, 0.9),
+                                                          ("blackman_harris", False, True, True, 5, 1.0)):
+        t = rmk.BeamformNS.__new__(rmk.BeamformNS)
+        t.npix, t.span, t.weight, t.scaled, t.include_auto, t.save_dirty_beam, t.precision = npix, span, weight, scaled, include_auto, sdb, 64
+        t.comm, t.log = _Comm(), _Log()
+        g = grids[False]
+        hv = t.process(g)
+        k = f"ns{idx}"
+        cases[k + "_opts"] = np.array([weight, str(int(scaled)), str(int(include_auto)), str(int(sdb)), str(npix), repr(span)])
+        cases[k + "_vis"], cases[k + "_weight"], cases[k + "_el"] = hv.vis.arr.view(np.ndarray), hv.weight.arr.view(np.ndarray), hv.index_map["el"]
+        if sdb:
+            cases[k + "_db"] = hv.dirty_beam.arr.view(np.ndarray)
+        cases[k + "_nsmax"] = np.float64(hv.attrs["beamform_ns_nsmax"])
+        hybrids.append(hv)
+        idx += 1
+    cases["n_ns"] = np.int64(idx)
+    # BeamformEW on two of the hybrid streams
+    idx = 0
+    for hvi, excl, single, wew, flag in ((0, False, False, "natural", None), (1, True, False, "uniform", None), (2, False, True, "natural", None),
+                                         (4, False, False, "natural", np.array([True, False]))):
+        t = rmk.BeamformEW.__new__(rmk.BeamformEW)
+        t.exclude_intracyl, t.single_beam, t.weight_ew, t.flag_ew = excl, single, wew, flag
+        hin = hybrids[hvi]
+        if "dirty_beam" in hin.datasets:
+            # with a dirty beam in the input the reference fails on its own broadcast (ringmapmaker.py:489: weight_ew has
+            # already been reshaped at :426): recorded once, then the case runs without the dirty beam
+            if "ew_db_error" not in cases:
+                try:
+                    t.process(hin)
+                    cases["ew_db_error"] = np.array("none")
+                except Exception as exc:  # noqa: BLE001
+                    cases["ew_db_error"] = np.array(type(exc).__name__)
+            hin.datasets.pop("dirty_beam")
+        rm = t.process(hin)
+        k = f"ew{idx}"
+        cases[k + "_opts"] = np.array([str(hvi), str(int(excl)), str(int(single)), wew, "" if flag is None else "".join(str(int(x)) for x in flag)])
+        cases[k + "_map"], cases[k + "_weight"], cases[k + "_rms"] = rm.map.arr.view(np.ndarray), rm.weight.arr.view(np.ndarray), rm.rms.arr.view(np.ndarray)
+        cases[k + "_pol"] = rm.index_map["pol"]
+        if hasattr(rm, "dirty_beam"):
+            cases[k + "_db"] = rm.dirty_beam.arr.view(np.ndarray)
+        idx += 1
+    cases["n_ew"] = np.int64(idx)
+    np.savez_compressed(os.path.join(out, "ringmap_chain.npz"), **cases)
+
+
 def main():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle._refstub import load_reference
@@ -1407,6 +1623,8 @@ def main():
         gen_stream_simulate(GOLDEN)
     if not only or "--only-process" in only:
         gen_mapmaker_process(mapmaker, GOLDEN)
+    if not only or "--only-ringmap-chain" in only:
+        gen_ringmap_chain(GOLDEN)
     for f in sorted(os.listdir(GOLDEN)):
         print(f, os.path.getsize(os.path.join(GOLDEN, f)))
 

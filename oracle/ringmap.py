@@ -182,3 +182,186 @@ def analytic_beam_mmodes(freq, ew, el, pol, latitude, mmax, oddra):
         b = np.exp(2.0j * np.pi * u_dec[None, :, :, None] * np.sin(phi)) * amp
         out[:, :, :, fi] = make_marray(b.conj(), mmax=mmax, dtype=np.complex64)
     return out
+
+
+# ------------------------------------------------------------------ the ring-map chain: MakeVisGrid -> BeamformNS -> BeamformEW
+def window_generalised_full(x, window="nuttall"):
+    """``tools.window_generalised`` with every name it knows (``tools.py:547-601``): cosine sums, 'triangular', 'tukey-0.X'."""
+    x = np.asarray(x, dtype=float)
+    if window == "triangular":
+        w = 1.0 - 2.0 * np.abs(x - 0.5)
+    elif window.startswith("tukey"):
+        alpha = 0.5 * float(window.split("-")[1])
+        w = np.ones_like(x)
+        b = x < alpha
+        w[b] = 0.5 * (1.0 + np.cos(np.pi * (x[b] - alpha) / alpha))
+        e = x >= 1.0 - alpha
+        w[e] = 0.5 * (1.0 + np.cos(np.pi * (x[e] - (1.0 - alpha)) / alpha))
+    else:
+        return window_generalised(x, window)
+    return np.where((x >= 0) & (x <= 1), w, 0)
+
+
+def find_grid_indices(baselines):
+    """``find_basis`` + ``find_grid_indices`` (``ringmapmaker.py:1715-1771``): grid index of every baseline, grid spacings."""
+    bl = np.sum(baselines**2, axis=1)
+    bl[bl == 0] = 1e30
+    e1 = baselines[np.argmin(bl)]
+    e2 = np.array([e1[1], -e1[0]])
+    xh, yh = (e1, e2) if abs(e1[0]) > abs(e2[0]) else (e2, e1)
+    xh = xh / np.dot(xh, xh) ** 0.5 * np.sign(xh[0])
+    yh = yh / np.dot(yh, yh) ** 0.5 * np.sign(yh[1])
+
+    def inds(s):
+        sa = np.abs(s)
+        d = sa[sa > 1e-4].min()
+        return np.rint(s / d).astype(np.int64), d
+
+    xind, dx = inds(baselines @ xh)
+    yind, dy = inds(baselines @ yh)
+    return xind, yind, dx, dy
+
+
+def calculate_redundancy(input_flags, prod, stack_index, nstack):
+    """``tools.calculate_redundancy`` (``tools.py:313-356``; its compiled inner loop restated): good-input pairs per stack."""
+    flags = np.asarray(input_flags, dtype=np.float32)
+    if not np.any(flags):
+        flags = np.ones_like(flags)
+    red = np.zeros((nstack, flags.shape[1]), dtype=np.float32)
+    for (a, b), s in zip(prod, stack_index):
+        if 0 <= s < nstack:
+            red[s] += flags[a] * flags[b]
+    return red
+
+
+def make_vis_grid(vis, weight, uniquepairs, polarisation, baselines, input_flags, prod, stack_index, centered=False):
+    """``MakeVisGrid.process`` (``ringmapmaker.py:68-176``): stacked visibilities onto the (pol, ew, ns) grid, the
+    intra-cylinder row filled on both sides of ns = 0 (conjugate, swapped polarisation pair)."""
+    polpair = np.char.add(polarisation[uniquepairs[:, 0]], polarisation[uniquepairs[:, 1]])
+    pol, pind = np.unique(polpair, return_inverse=True)
+    if len(pol) != 4:
+        raise RuntimeError(f"Expected to find four polarisations. Got {pol}")
+    pconjmap = np.unique([pj + pi for pi, pj in pol], return_inverse=True)[1]
+    xind, yind, dx, dy = find_grid_indices(np.asarray(baselines, dtype=float))
+    nx = np.abs(xind).max() + 1
+    max_y = np.abs(yind).max()
+    ny = 2 * max_y + 1
+    ew = np.arange(nx) * dx
+    if centered:
+        ns, off = np.arange(-max_y, max_y + 1) * dy, max_y
+    else:
+        ns, off = np.fft.fftfreq(ny, d=1.0 / (ny * dy)), 0
+    nfreq, nstack, nra = vis.shape
+    red = calculate_redundancy(input_flags, prod, stack_index, nstack)
+    gv = np.zeros((4, nfreq, nx, ny, nra), np.complex64)
+    gw = np.zeros((4, nfreq, nx, ny, nra), np.float32)
+    gr = np.zeros((4, nx, ny, nra), np.int32)
+    for vi, (p, x, y) in enumerate(zip(pind, xind, yind)):
+        gv[p, :, x, off + y, :] = vis[:, vi]
+        gw[p, :, x, off + y, :] = weight[:, vi]
+        gr[p, x, off + y, :] = red[vi]
+        if x == 0:
+            pc = pconjmap[p]
+            gv[pc, :, x, off - y, :] = vis[:, vi].conj()
+            gw[pc, :, x, off - y, :] = weight[:, vi]
+            gr[pc, x, off - y, :] = red[vi]
+    return gv, gw, gr, pol, ew, ns
+
+
+def beamform_ns(gv, gw, gr, nspos, freq, npix=512, span=1.0, weight="natural", scaled=False, include_auto=False, precision=64):
+    """``BeamformNS.process`` (``ringmapmaker.py:230-346``): weights over ns, normalised; the DFT in the NS direction to
+    `npix` elevations; noise weights.  Returns (vis c64, weight f32, dirty_beam f32, el, nsmax)."""
+    cdt = np.complex128 if precision == 64 else np.complex64
+    rdt = np.float64 if precision == 64 else np.float32
+    el = span * np.linspace(-1.0, 1.0, npix)
+    npol, nfreq, nx, ny, nra = gv.shape
+    present = np.any(gw > 0, axis=(0, 1, 2, 4))
+    nsmax = np.abs(nspos[present]).max() if present.sum() > 0 else 0.0
+    phase = (2.0 * np.pi * nspos[np.newaxis] * el[:, np.newaxis]).astype(cdt)
+    hv = np.zeros((npol, nfreq, nx, npix, nra), np.complex64)
+    hw = np.zeros((npol, nfreq, nx, nra), np.float32)
+    hb = np.zeros((npol, nfreq, nx, npix, nra), np.float32)
+    for fi in range(nfreq):
+        iwv = freq[fi] * 1e6 / scipy.constants.c
+        vpos = nspos * iwv
+        vmax = nsmax * (freq.min() * 1e6 / scipy.constants.c if scaled else iwv)
+        if weight == "inverse_variance":
+            w = gw[:, fi].copy()
+        elif weight == "natural":
+            w = gr.astype(np.float32)
+        else:
+            x = 0.5 * (vpos / vmax + 1)
+            nsw = window_generalised_full(x, window=weight).astype(rdt)
+            w = (gw[:, fi] > 0) * nsw[np.newaxis, np.newaxis, :, np.newaxis]
+        w = w * (gw[:, fi] > 0)
+        if not include_auto:
+            w[..., 0, 0, :] = 0.0
+        norm = np.sum(w, axis=-2)
+        w = w * invert_no_zero(norm)[..., np.newaxis, :]
+        F = np.exp(-1.0j * phase * iwv)
+        hv[:, fi] = np.matmul(F, gv[:, fi] * w)
+        hb[:, fi] = np.matmul(F, w * np.ones_like(gv[:, fi])).real
+        t = np.sum(invert_no_zero(gw[:, fi]) * w**2, axis=-2)
+        hw[:, fi] = invert_no_zero(t)
+    return hv, hw, hb, el, nsmax
+
+
+def ew_pol_rotation(pols):
+    """``BeamformEW._get_pol`` (``ringmapmaker.py:499-530``)."""
+    pols = list(pols)
+    if ("XY" in pols) or ("YX" in pols):
+        if ("XY" in pols) ^ ("YX" in pols):
+            raise ValueError(f"If cross-pols exist, both XY and YX must be present. Got {pols}.")
+        dpol = ["reXY", "imXY"]
+    else:
+        dpol = []
+    if "XX" in pols:
+        dpol = ["XX", *dpol]
+    if "YY" in pols:
+        dpol.append("YY")
+    P = np.eye(len(dpol), dtype=np.complex64)
+    if "reXY" in dpol:
+        i = dpol.index("reXY")
+        P[i, i : i + 2] = [0.5, 0.5]
+        P[i + 1, i : i + 2] = [-0.5j, 0.5j]
+    return np.array(dpol, dtype="U4"), P
+
+
+def beamform_ew(hv, hw, pols, exclude_intracyl=False, single_beam=False, weight_ew="natural", flag_ew=None, dirty_beam=None):
+    """``BeamformEW.process`` (``ringmapmaker.py:372-497``): polarisation rotation, EW weights, inverse real FFT over the
+    EW baselines into `2 n_ew - 1` beams (or the central one), variance propagation.  The dirty beam is transformed the
+    same way (the reference's own line for it, :489, fails to broadcast)."""
+    n_ew = hv.shape[2]
+    nbeam = 1 if single_beam else 2 * n_ew - 1
+    w = np.ones(n_ew) if weight_ew == "uniform" else (n_ew - np.arange(n_ew)).astype(float)
+    if exclude_intracyl:
+        w[0] = 0.0
+    if flag_ew is not None and np.size(flag_ew) == n_ew:
+        w = w * np.asarray(flag_ew).astype(bool).astype(w.dtype)
+    if single_beam:
+        w[1:] *= 2
+    w = w / w.sum()
+    pol, P = ew_pol_rotation(pols)
+    P2 = np.abs(P) ** 2
+    npolo, nfreq = len(pol), hv.shape[1]
+    nel, nra = hv.shape[3], hv.shape[4]
+    rmm = np.zeros((nbeam, npolo, nfreq, nra, nel))
+    rmw = np.zeros((npolo, nfreq, nra, nel))
+    rmr = np.zeros((npolo, nfreq, nra))
+    rmb = np.zeros_like(rmm) if dirty_beam is not None else None
+
+    def beams(v):
+        v = v * w[:, np.newaxis, np.newaxis]
+        if single_beam:
+            return np.sum(v.real, axis=1)[:, np.newaxis]
+        return np.fft.irfft(v, nbeam, axis=1) * nbeam
+
+    for fi in range(nfreq):
+        rmm[:, :, fi] = beams(np.tensordot(P, hv[:, fi], axes=(1, 0))).transpose(1, 0, 3, 2)
+        var = np.tensordot(P2, invert_no_zero(hw[:, fi]), axes=(1, 0))
+        rm_var = 0.5 * np.sum((w[:, np.newaxis] ** 2) * var, axis=1)
+        rmw[:, fi] = invert_no_zero(rm_var[..., np.newaxis])
+        rmr[:, fi] = rm_var**0.5
+        if dirty_beam is not None:
+            rmb[:, :, fi] = beams(np.tensordot(P, dirty_beam[:, fi], axes=(1, 0))).transpose(1, 0, 3, 2)
+    return rmm, rmw, rmr, pol, rmb
