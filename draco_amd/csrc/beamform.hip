@@ -139,25 +139,30 @@ __global__ __launch_bounds__(kThreads) void k_bf_gemm(BfParams p) {
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // staging: thread t holds, per operand, 4 complex values of a chunk -- F: row t / 4, columns 4 (t % 4) ..; X: ns row
+  // t / 16, ra columns 4 (t % 16) .. (contiguous in memory) -- fetched into registers under the previous chunk's MFMAs
+  const int fr = threadIdx.x >> 2, fc = (threadIdx.x & 3) * 4;
+  const int xk = threadIdx.x >> 4, xt = (threadIdx.x & 15) * 4;
+  double2 fv[4], xv[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      fv[c] = (e0 + fr < p.npix && k0 + fc + c < p.ny) ? p.F[(int64_t)(e0 + fr) * p.ny + k0 + fc + c] : make_double2(0.0, 0.0);
+      xv[c] = (t0 + xt + c < p.nra && k0 + xk < p.ny) ? X[(int64_t)(k0 + xk) * p.nra + t0 + xt + c] : make_double2(0.0, 0.0);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < p.ny; k0 += KC) {
-    __syncthreads();
-    // F tile: rows e0 .. e0+63, columns k0 .. k0+15 (row-contiguous in ns)
-    for (int idx = threadIdx.x; idx < 64 * KC; idx += kThreads) {
-      const int r = idx / KC, c = idx - r * KC;
-      double2 v = make_double2(0.0, 0.0);
-      if (e0 + r < p.npix && k0 + c < p.ny) v = p.F[(int64_t)(e0 + r) * p.ny + k0 + c];
-      fs[r * LP + 2 * c] = v.x;
-      fs[r * LP + 2 * c + 1] = v.y;
-    }
-    // X tile: columns (ra) t0 .. t0+63 of rows (ns) k0 .. k0+15, stored transposed: [ra][ns]
-    for (int idx = threadIdx.x; idx < 64 * KC; idx += kThreads) {
-      const int c = idx / 64, r = idx - c * 64;  // r: ra (contiguous in memory), c: ns
-      double2 v = make_double2(0.0, 0.0);
-      if (t0 + r < p.nra && k0 + c < p.ny) v = X[(int64_t)(k0 + c) * p.nra + t0 + r];
-      xs[r * LP + 2 * c] = v.x;
-      xs[r * LP + 2 * c + 1] = v.y;
+    __syncthreads();  // the previous chunk's MFMAs have read LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      fs[fr * LP + 2 * (fc + c)] = fv[c].x;
+      fs[fr * LP + 2 * (fc + c) + 1] = fv[c].y;
+      xs[(xt + c) * LP + 2 * xk] = xv[c].x;  // transposed: [ra][ns]
+      xs[(xt + c) * LP + 2 * xk + 1] = xv[c].y;
     }
     __syncthreads();
+    if (k0 + KC < p.ny) fetch(k0 + KC);
 #pragma unroll
     for (int kk = 0; kk < 2 * KC; kk += 4) {
       double a[2], b[2], b2[2];
