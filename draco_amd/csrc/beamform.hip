@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kThreads) void k_vis_grid(const float2* __restrict_
 
 struct BfParams {
   int npol, nfreq, nx, ny, nra, npix;
+  int ny_p, nra_p, npix_p;  // scratch pitches: ny to a multiple of 16, nra and npix to 64 (zero padded: the GEMM has no predicates)
   int mode;          // 0: inverse variance, 1: natural (redundancy), 2: window table
   int include_auto;
   int f;             // frequency of the slab being processed
@@ -107,20 +108,20 @@ __global__ __launch_bounds__(kThreads) void k_bf_weights(BfParams p) {
     const double w = bf_weight(p, pol, x, y, t, gsw) * inorm;
     const float2 v = p.gv[base + (int64_t)y * p.nra];
     // (the dirty beam's operand is the weight itself: real part only)
-    p.xw[((int64_t)pe * p.ny + y) * p.nra + t] = DIRTY ? make_double2(w, 0.0) : make_double2((double)v.x * w, (double)v.y * w);
+    p.xw[((int64_t)pe * p.ny_p + y) * p.nra_p + t] = DIRTY ? make_double2(w, 0.0) : make_double2((double)v.x * w, (double)v.y * w);
     if (!DIRTY && gsw != 0.f) tsum += w * w / (double)gsw;
   }
   if (!DIRTY) p.hw[(((int64_t)pol * p.nfreq + p.f) * p.nx + x) * p.nra + t] = tsum != 0.0 ? (float)(1.0 / tsum) : 0.f;
 }
 
-__global__ __launch_bounds__(kThreads) void k_bf_phase(int npix, int ny, const double* __restrict__ el, const double* __restrict__ nspos,
-                                                       double iwv, double2* __restrict__ F) {
+__global__ __launch_bounds__(kThreads) void k_bf_phase(int npix, int ny, int npix_p, int ny_p, const double* __restrict__ el,
+                                                       const double* __restrict__ nspos, double iwv, double2* __restrict__ F) {
   const int idx = blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= npix * ny) return;
-  const int e = idx / ny, y = idx - e * ny;
-  double s, c;
-  sincos(2.0 * M_PI * nspos[y] * el[e] * iwv, &s, &c);
-  F[idx] = make_double2(c, -s);
+  if (idx >= npix_p * ny_p) return;
+  const int e = idx / ny_p, y = idx - e * ny_p;
+  double s = 0.0, c = 0.0;
+  if (e < npix && y < ny) sincos(2.0 * M_PI * nspos[y] * el[e] * iwv, &s, &c);
+  F[idx] = make_double2(c, -s);  // (zero in the padding)
 }
 
 // C[el, ra] = sum_ns F[el, ns] X[ns, ra] for every (pol, ew): 64 x 64 output tile per block, 4 waves x (2 x 2) MFMA tiles,
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_bf_gemm(BfParams p) {
   const int e0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const double2* X = p.xw + (int64_t)pe * p.ny * p.nra;
+  const double2* X = p.xw + (int64_t)pe * p.ny_p * p.nra_p;
   v4d cre[2][2], cim[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -144,15 +145,17 @@ __global__ __launch_bounds__(kThreads) void k_bf_gemm(BfParams p) {
   const int fr = threadIdx.x >> 2, fc = (threadIdx.x & 3) * 4;
   const int xk = threadIdx.x >> 4, xt = (threadIdx.x & 15) * 4;
   double2 fv[4], xv[4];
-  auto fetch = [&](int k0) {
+  const double2* fp = p.F + (int64_t)(e0 + fr) * p.ny_p + fc;
+  const double2* xp = X + (int64_t)xk * p.nra_p + t0 + xt;
+  auto fetch = [&](int k0) {  // (both scratch arrays are zero padded to the tile sizes: no predicates)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      fv[c] = (e0 + fr < p.npix && k0 + fc + c < p.ny) ? p.F[(int64_t)(e0 + fr) * p.ny + k0 + fc + c] : make_double2(0.0, 0.0);
-      xv[c] = (t0 + xt + c < p.nra && k0 + xk < p.ny) ? X[(int64_t)(k0 + xk) * p.nra + t0 + xt + c] : make_double2(0.0, 0.0);
+      fv[c] = fp[k0 + c];
+      xv[c] = xp[(int64_t)k0 * p.nra_p + c];
     }
   };
   fetch(0);
-  for (int k0 = 0; k0 < p.ny; k0 += KC) {
+  for (int k0 = 0; k0 < p.ny_p; k0 += KC) {
     __syncthreads();  // the previous chunk's MFMAs have read LDS
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void k_bf_gemm(BfParams p) {
       xs[(xt + c) * LP + 2 * xk + 1] = xv[c].y;
     }
     __syncthreads();
-    if (k0 + KC < p.ny) fetch(k0 + KC);
+    if (k0 + KC < p.ny_p) fetch(k0 + KC);
 #pragma unroll
     for (int kk = 0; kk < 2 * KC; kk += 4) {
       double a[2], b[2], b2[2];
@@ -340,12 +343,14 @@ int dmm_beamform_ns(dmm_ctx* ctx, int npol, int nfreq, int nx, int ny, int nra, 
   DMM_REQUIRE(weight_mode != 1 || grid_red, "dmm_beamform_ns: natural weights need the redundancy grid");
   DMM_REQUIRE(weight_mode != 2 || ns_window, "dmm_beamform_ns: window weights need the [nfreq, ns] table");
   DMM_HIP(hipSetDevice(ctx->device));
-  const size_t b_x = (size_t)npol * nx * ny * nra * sizeof(double2), b_f = ((size_t)npix * ny * sizeof(double2) + 255) / 256 * 256;
+  const int ny_p = (ny + 15) / 16 * 16, nra_p = (nra + 63) / 64 * 64, npix_p = (npix + 63) / 64 * 64;
+  const size_t b_x = (size_t)npol * nx * ny_p * nra_p * sizeof(double2), b_f = ((size_t)npix_p * ny_p * sizeof(double2) + 255) / 256 * 256;
   void* scratch = nullptr;
   int rc = dmm_get_scratch(ctx, b_x + b_f + 256, &scratch);
   if (rc) return rc;
   BfParams p;
   p.npol = npol, p.nfreq = nfreq, p.nx = nx, p.ny = ny, p.nra = nra, p.npix = npix;
+  p.ny_p = ny_p, p.nra_p = nra_p, p.npix_p = npix_p;
   p.mode = weight_mode, p.include_auto = include_auto;
   p.gv = (const float2*)grid_vis, p.gw = grid_weight, p.gr = grid_red;
   p.F = (double2*)scratch;
@@ -353,11 +358,12 @@ int dmm_beamform_ns(dmm_ctx* ctx, int npol, int nfreq, int nx, int ny, int nra, 
   p.hv = (float2*)hv, p.hw = hw, p.hb = dirty_beam;
   const int64_t nw = (int64_t)npol * nx * nra;
   const dim3 ggrid((nra + 63) / 64, (npix + 63) / 64, npol * nx);
+  if (ny_p != ny || nra_p != nra) DMM_HIP(hipMemsetAsync(p.xw, 0, b_x, ctx->stream));  // the padding stays zero: the weight kernel writes the rest
   for (int f = 0; f < nfreq; ++f) {
     p.f = f;
     p.nsw = ns_window ? ns_window + (size_t)f * ny : nullptr;
-    hipLaunchKernelGGL(k_bf_phase, dim3((npix * ny + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream, npix, ny, el, nspos,
-                       inv_wavelength[f], (double2*)scratch);
+    hipLaunchKernelGGL(k_bf_phase, dim3((npix_p * ny_p + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream, npix, ny, npix_p, ny_p, el,
+                       nspos, inv_wavelength[f], (double2*)scratch);
     hipLaunchKernelGGL(k_bf_weights<false>, dim3((unsigned)((nw + kThreads - 1) / kThreads)), dim3(kThreads), 0, ctx->stream, p);
     hipLaunchKernelGGL(k_bf_gemm<false>, ggrid, dim3(kThreads), 0, ctx->stream, p);
     if (dirty_beam) {
