@@ -213,93 +213,116 @@ struct EwParams {
   double* rms;        // [pol_out, freq, ra]
 };
 
-// 32 (el) x 32 (ra) tile of one (pol_out, freq): rotate, weight, inverse real DFT over ew, transposed store
-template <bool DIRTY>
+// 32 (el) x 32 (ra) tile of one (pol_out, freq): rotate, weight, inverse real DFT over ew, transposed store.  A thread
+// owns four elements (rows j = ty, ty + 8, ...): all their loads are issued before anything is consumed; the beams stay in
+// registers and go through ONE 32 x 33 LDS tile, beam by beam (8.4 KB per block instead of nbeam x that: the LDS no longer
+// limits the resident waves).
+template <bool DIRTY, int NB>  // NB: most beams (8: up to four EW separations, 16: up to eight)
 __global__ __launch_bounds__(kThreads) void k_bf_ew(EwParams p) {
-  extern __shared__ double tile[];  // [nbeam][32][33]
+  __shared__ double tile[32][33];
   __shared__ double s_var[32];
-  __shared__ double2 s_tw[8 * 16];   // e^{2 pi i x b / nbeam}
-  if (threadIdx.x < 8 * 16) {
-    const int x = threadIdx.x >> 4, b = threadIdx.x & 15;
+  __shared__ double2 s_tw[8 * NB];   // e^{2 pi i x b / nbeam}
+  __shared__ double2 s_P[4];         // this output polarisation's row of the rotation
+  const int pf = blockIdx.z, po = pf / p.nfreq, f = pf - po * p.nfreq;
+  const int e0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  if (threadIdx.x < 8 * NB) {
+    const int x = threadIdx.x / NB, b = threadIdx.x % NB;
     double s = 0.0, c = 1.0;
     if (!p.single && x < p.nx && b < p.nbeam) sincospi(2.0 * (double)((x * b) % p.nbeam) / (double)p.nbeam, &s, &c);
     s_tw[threadIdx.x] = make_double2(c, s);
   }
+  if (threadIdx.x < 4) s_P[threadIdx.x] = threadIdx.x < p.npol_in ? p.P[po * p.npol_in + threadIdx.x] : make_double2(0.0, 0.0);
   __syncthreads();
-  const int pf = blockIdx.z, po = pf / p.nfreq, f = pf - po * p.nfreq;
-  const int e0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  for (int j = ty; j < 32; j += 8) {
-    const int e = e0 + j, t = t0 + tx;
-    double acc[16];
-#pragma unroll
-    for (int b = 0; b < 16; ++b) acc[b] = 0.0;
-    if (e < p.nel && t < p.nra) {
-      for (int x = 0; x < p.nx; ++x) {
-        double vr = 0.0, vi = 0.0;
-        for (int pi = 0; pi < p.npol_in; ++pi) {
-          const double2 c = p.P[po * p.npol_in + pi];
-          if (c.x == 0.0 && c.y == 0.0) continue;
-          const int64_t o = ((((int64_t)pi * p.nfreq + f) * p.nx + x) * p.nel + e) * p.nra + t;
-          double hr, hi;
-          if (DIRTY) {
-            hr = (double)p.hb[o];
-            hi = 0.0;
-          } else {
-            const float2 h = p.hv[o];
-            hr = (double)h.x;
-            hi = (double)h.y;
-          }
-          vr += c.x * hr - c.y * hi;
-          vi += c.x * hi + c.y * hr;
-        }
-        vr *= p.wew[x];
-        vi *= p.wew[x];
-        // irfft(v, n)[b] * n = v_0.re + 2 sum_{k >= 1} Re(v_k e^{2 pi i k b / n})   (n = 2 nx - 1 odd: no Nyquist term);
-        // single beam: the b = 0 term alone, the weights already carrying the factor 2 (ringmapmaker.py:415-417)
-        const double fac = (x == 0 || p.single) ? 1.0 : 2.0;
-#pragma unroll
-        for (int b = 0; b < 16; ++b)
-          if (b < p.nbeam) {
-            const double2 tw = s_tw[x * 16 + b];
-            acc[b] += fac * (vr * tw.x - vi * tw.y);
-          }
+  // the (at most two) input polarisations this output draws on
+  int pin[2] = {0, 0};
+  double2 pc[2] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+  {
+    int n = 0;
+    for (int pi = 0; pi < p.npol_in && pi < 4; ++pi)
+      if (n < 2 && (s_P[pi].x != 0.0 || s_P[pi].y != 0.0)) {
+        pin[n] = pi;
+        pc[n] = s_P[pi];
+        ++n;
       }
-    }
+  }
+  double acc[4][NB];
 #pragma unroll
-    for (int b = 0; b < 16; ++b)
-      if (b < p.nbeam) tile[(b * 32 + j) * 33 + tx] = acc[b];
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[u][b] = 0.0;
+  const int t = t0 + tx;
+  for (int x = 0; x < p.nx; ++x) {
+    float2 h[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e = e0 + ty + 8 * u;
+        h[u][q] = make_float2(0.f, 0.f);
+        if (e < p.nel && t < p.nra && (pc[q].x != 0.0 || pc[q].y != 0.0)) {
+          const int64_t o = ((((int64_t)pin[q] * p.nfreq + f) * p.nx + x) * p.nel + e) * p.nra + t;
+          if (DIRTY) h[u][q].x = p.hb[o];
+          else h[u][q] = p.hv[o];
+        }
+      }
+    const double wx = p.wew[x];
+    // irfft(v, n)[b] * n = v_0.re + 2 sum_{k >= 1} Re(v_k e^{2 pi i k b / n})   (n = 2 nx - 1 odd: no Nyquist term);
+    // single beam: the b = 0 term alone, the weights already carrying the factor 2 (ringmapmaker.py:415-417)
+    const double fac = (x == 0 || p.single) ? wx : 2.0 * wx;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double vr = 0.0, vi = 0.0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const double hr = (double)h[u][q].x, hi = (double)h[u][q].y;
+        vr += pc[q].x * hr - pc[q].y * hi;
+        vi += pc[q].x * hi + pc[q].y * hr;
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (b < p.nbeam) {
+          const double2 tw = s_tw[x * NB + b];
+          acc[u][b] += fac * (vr * tw.x - vi * tw.y);
+        }
+    }
   }
   // variance propagation (per ra): 0.5 sum_ew w^2 sum_pin |P|^2 / hw
   if (!DIRTY && threadIdx.x < 32) {
-    const int t = t0 + threadIdx.x;
+    const int tt = t0 + threadIdx.x;
     double rv = 0.0;
-    if (t < p.nra) {
+    if (tt < p.nra) {
       for (int x = 0; x < p.nx; ++x) {
         double var = 0.0;
-        for (int pi = 0; pi < p.npol_in; ++pi) {
-          const double2 c = p.P[po * p.npol_in + pi];
-          const double p2 = c.x * c.x + c.y * c.y;
+        for (int q = 0; q < 2; ++q) {
+          const double p2 = pc[q].x * pc[q].x + pc[q].y * pc[q].y;
           if (p2 == 0.0) continue;
-          const float w = p.hw[(((int64_t)pi * p.nfreq + f) * p.nx + x) * p.nra + t];
+          const float w = p.hw[(((int64_t)pin[q] * p.nfreq + f) * p.nx + x) * p.nra + tt];
           var += p2 * (w != 0.f ? 1.0 / (double)w : 0.0);
         }
         rv += p.wew[x] * p.wew[x] * var;
       }
       rv *= 0.5;
-      if (blockIdx.y == 0) p.rms[((int64_t)po * p.nfreq + f) * p.nra + t] = sqrt(rv);
+      if (blockIdx.y == 0) p.rms[((int64_t)po * p.nfreq + f) * p.nra + tt] = sqrt(rv);
     }
     s_var[threadIdx.x] = rv != 0.0 ? 1.0 / rv : 0.0;
   }
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    const int t = t0 + j, e = e0 + tx;
-    if (e < p.nel && t < p.nra) {
-      for (int b = 0; b < p.nbeam; ++b)
-        p.map[((((int64_t)b * p.npol_out + po) * p.nfreq + f) * p.nra + t) * p.nel + e] = tile[(b * 32 + tx) * 33 + j];
-      if (!DIRTY) p.weight[(((int64_t)po * p.nfreq + f) * p.nra + t) * p.nel + e] = s_var[j];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b < p.nbeam) {  // (uniform over the block; written this way the loop unrolls and acc[][] stays in registers)
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tile[ty + 8 * u][tx] = acc[u][b];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tr = t0 + ty + 8 * u, e = e0 + tx;
+        if (e < p.nel && tr < p.nra) {
+          p.map[((((int64_t)b * p.npol_out + po) * p.nfreq + f) * p.nra + tr) * p.nel + e] = tile[tx][ty + 8 * u];
+          if (!DIRTY && b == 0) p.weight[(((int64_t)po * p.nfreq + f) * p.nra + tr) * p.nel + e] = s_var[ty + 8 * u];
+        }
+      }
     }
-  }
 }
 
 }  // namespace
@@ -380,7 +403,7 @@ int dmm_beamform_ew(dmm_ctx* ctx, int npol_in, int npol_out, int nfreq, int nx, 
                     double* weight, double* rms, double* dirty_beam_out) {
   DMM_REQUIRE(ctx && hv && hw && pol_rotation && weight_ew && map && weight && rms, "dmm_beamform_ew: NULL argument");
   DMM_REQUIRE(npol_in >= 1 && npol_out >= 1 && nfreq >= 1 && nx >= 1 && nel >= 1 && nra >= 1, "dmm_beamform_ew: bad sizes");
-  DMM_REQUIRE(single_beam || 2 * nx - 1 <= 16, "dmm_beamform_ew: more than 8 EW baselines (%d) are not supported", nx);
+  DMM_REQUIRE(nx <= 8 && npol_in <= 4, "dmm_beamform_ew: more than 8 EW baselines (%d) or 4 input polarisations (%d) are not supported", nx, npol_in);
   DMM_REQUIRE(!dirty_beam_out == !dirty_beam_in, "dmm_beamform_ew: dirty beam in and out go together");
   DMM_HIP(hipSetDevice(ctx->device));
   EwParams p;
@@ -391,13 +414,12 @@ int dmm_beamform_ew(dmm_ctx* ctx, int npol_in, int npol_out, int nfreq, int nx, 
   p.P = (const double2*)pol_rotation, p.wew = weight_ew;
   p.map = map, p.weight = weight, p.rms = rms;
   const dim3 grid((nra + 31) / 32, (nel + 31) / 32, npol_out * nfreq);
-  const size_t lds = (size_t)p.nbeam * 32 * 33 * sizeof(double);
-  DMM_HIP(hipFuncSetAttribute((const void*)k_bf_ew<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_bf_ew<false>, grid, dim3(kThreads), lds, ctx->stream, p);
+  if (p.nbeam <= 8) hipLaunchKernelGGL((k_bf_ew<false, 8>), grid, dim3(kThreads), 0, ctx->stream, p);
+  else hipLaunchKernelGGL((k_bf_ew<false, 16>), grid, dim3(kThreads), 0, ctx->stream, p);
   if (dirty_beam_out) {
     p.map = dirty_beam_out;
-    DMM_HIP(hipFuncSetAttribute((const void*)k_bf_ew<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_bf_ew<true>, grid, dim3(kThreads), lds, ctx->stream, p);
+    if (p.nbeam <= 8) hipLaunchKernelGGL((k_bf_ew<true, 8>), grid, dim3(kThreads), 0, ctx->stream, p);
+    else hipLaunchKernelGGL((k_bf_ew<true, 16>), grid, dim3(kThreads), 0, ctx->stream, p);
   }
   DMM_HIP(hipGetLastError());
   return DMM_OK;
