@@ -934,6 +934,49 @@ def extras(args, cfg, job):
             extra["ml_eigen_ms_per_solve"] = (time.perf_counter() - t0) * 1e3 / (nf_w * (lmax + 1))
         finally:
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        # (3b) the same two makers on PHYSICALLY STRUCTURED tiles (BeamScreenProvider: none of them passes the ML certificate,
+        # every tile is eigen-decomposed through the two-stage reduction), 8 frequencies through the task classes;
+        # `python bench.py --maker ml|wiener` is the full-day form of this with rooflines and CPU baselines
+        try:
+            import ctypes as C
+
+            from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker, WienerMapMaker
+            from draco_amd.core.products import BeamScreenProvider
+
+            nf_s = min(8, nfreq)
+            tel_s = TransitTelescope(wl.frequencies(nfreq)[:nf_s], lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+            bs = BeamScreenProvider(tel_s, seed=3003)
+            per_f = sum(2 * tel_s.npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * 16
+            mm_s = containers.MModes(mmax=lmax, freq=tel_s.frequencies, stack=tel_s.npairs, allocate=False)
+            mm_s.attach("vis", mv1[:, :, :nf_s].contiguous())
+            mm_s.attach("vis_weight", (mw1[:, :, :nf_s] * 20.0).contiguous())
+
+            def counter(name):
+                v = C.c_int64()
+                _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+                return int(v.value)
+
+            st = {}
+            for kind, cls in (("wiener", WienerMapMaker), ("ml", MaximumLikelihoodMapMaker)):
+                task = cls(nside=64, pool_bytes=nf_s * per_f + (1 << 20))
+                task.setup(bs)
+                task.make_alm(mm_s)  # (generates the tiles: B resident afterwards)
+                ctx.sync()
+                e0, d0 = counter(b"ml_tiles_eigen"), counter(b"ml_tiles_direct")
+                t0 = time.perf_counter()
+                task.make_alm(mm_s)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                st[kind + "_ms_per_solve"] = dt * 1e3 / (nf_s * (lmax + 1))
+                if kind == "ml":
+                    st["ml_tiles_eigen_decomposed"] = counter(b"ml_tiles_eigen") - e0
+                    st["ml_tiles_certified"] = counter(b"ml_tiles_direct") - d0
+                del task
+            st["sample"] = f"all {lmax + 1} m of {nf_s} frequencies, BeamScreenProvider tiles, B resident"
+            extra["structured_tiles"] = st
+            del bs, mm_s
+        except Exception as e:  # noqa: BLE001
+            extra["structured_tiles"] = {"error": repr(e)[:300]}
         extra["dense_sample"] = f"all {lmax + 1} m of {nf_w} frequencies, B resident"
         del eng2, mv1, mw1, vis1, w1
         _solve.release_pools()
