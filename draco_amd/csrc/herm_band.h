@@ -50,6 +50,8 @@ __device__ __forceinline__ double2* sb_X(const TdParams& tp, int mat) { return s
 __device__ __forceinline__ double2* sb_Z(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)3 * tp.d.Np * kSbB; }
 // [waves of the last sweep][256]: their pieces of V^H Z (16 x 16 real blocks [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]])
 __device__ __forceinline__ double* sb_Mp(const TdParams& tp, int mat) { return reinterpret_cast<double*>(sb_base(tp, mat) + (int64_t)4 * tp.d.Np * kSbB); }
+// lower-triangle sweeps (k_sb_sweep_lo): the row contributions to Z of every 64-column block, [block][n][8 re | 8 im]
+__device__ __forceinline__ double* sb_Zp(const TdParams& tp, int mat) { return sb_Mp(tp, mat) + (int64_t)(tp.d.Np / 16) * 256; }
 __device__ __forceinline__ double2* sb_T(const TdParams& tp, int mat) { return sb_base(tp, mat) + tp.log_stride - sb_tail(tp.d.Np); }
 __device__ __forceinline__ double2* sb_rlog(const TdParams& tp, int mat) { return sb_T(tp, mat) + (int64_t)sb_npanel(tp.d.Np) * 64; }
 
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
   if (k > 0) {
     const int org_prev = (kSbB * k) & ~15;
-    const int nw = (n - org_prev) / 16;
+    const int nw = tp.sb_lower ? 4 * ((n - org_prev + 63) / 64) : (n - org_prev) / 16;
+    const double* const Zpa = sb_Zp(tp, mat);
     double acc = 0.0;
     for (int w = 0; w < nw; ++w) acc += Mpa[(int64_t)w * 256 + t];
     s_red[t] = acc;
@@ -194,6 +197,20 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       for (int c = 0; c < 8; ++c) {
         z[c] = Za[(int64_t)r * kSbB + c];
         v[c] = Vold[(int64_t)r * kSbB + c];
+      }
+      if (tp.sb_lower) {  // + the row contributions of the column blocks left of this row's tile (in block order)
+        const int nb = ((r - org_prev) / 16 * 16 + 63) / 64;
+        for (int b = 0; b < nb; ++b) {
+          const double2* zp = reinterpret_cast<const double2*>(Zpa + ((int64_t)b * n + r) * 16);
+          double2 w[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) w[c] = zp[c];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            z[2 * c].x += w[c].x, z[2 * c + 1].x += w[c].y;
+            z[2 * c].y += w[4 + c].x, z[2 * c + 1].y += w[4 + c].y;
+          }
+        }
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -451,6 +468,170 @@ __global__ __launch_bounds__(kThreads) void k_sb_sweep(TdParams tp) {
     mp = __builtin_amdgcn_mfma_f64_16x16x4f64(lo ? vj.x : vj.y, z[reg], mp, 0, 0, 0);
   }
   double* Mw = sb_Mp(tp, mat) + (int64_t)((c0 - org) / 16) * 256;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) Mw[(lk + 4 * reg) * 16 + lr] = mp[reg];
+}
+
+// ------------------------------------------------------------------------------- stage 1: sweep, lower triangle only
+// The same sweep over the tiles (I, J), I >= J, only: the trailing matrix is Hermitian, so a tile below the diagonal
+// also stands for its mirror image -- Z_J += C^H V'_I as above and, for I > J, Z_I += C V'_J.  The second product
+// contracts over the tile's COLUMNS, which the accumulator layout does not offer as an MFMA operand: the updated tile
+// is transposed through a private 16 x 17 LDS image of the wave (conflict-free both ways).  Who sums what, without any
+// synchronisation inside the loop: a block owns 64 columns and its wave w the row steps w, w + 4, ... -- ALL (up to four)
+// tiles of a row step, so the row contribution of the step is one accumulator chain in that wave (written as this
+// block's partial for those 16 rows: 0.5 KB per tile; the panel kernel adds the partials of a row in block order),
+// and the four column contributions are per-wave accumulators, summed over the block's waves once at the end.
+// 8.5 KB of HBM traffic and 32 MFMAs per tile where the full sweep has 16 KB and 48 for the tile and its mirror image;
+// the upper triangle is never touched again (the reflectors of finished panels stay there).
+// The J-side operands (X, V of update k-1, V' of panel k for the block's 64 columns) sit in LDS in the lane order of
+// the MFMA B operands.
+__global__ __launch_bounds__(kThreads) void k_sb_sweep_lo(TdParams tp) {
+  __shared__ double sJ[4][kSbB][64];   // Xr, Xi, Vr, Vi: [q][column]
+  __shared__ double sB[2][64][16];     // per column [V'r | V'i] and [-V'i | V'r] (entries q = 0..7 each)
+  __shared__ double sT[4][2][16 * 17]; // per wave: the tile transposed, real and imaginary plane; at the end the reduction buffer
+  const DenseParams& p = tp.d;
+  const int n = p.Np, k = tp.j;
+  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
+  double2* A = p.A + (int64_t)mat * n * n;
+  const double2* Vold = sb_V(tp, mat, k + 1);
+  const double2* Vnew = sb_V(tp, mat, k);
+  const double2* X = sb_X(tp, mat);
+  const int org = (kSbB * (k + 1)) & ~15;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int cb0 = org + 64 * blockIdx.x;     // first column of the block (< n by the grid)
+  const int ntile = min(4, (n - cb0) / 16);  // its column tiles
+  for (int idx = threadIdx.x; idx < 64 * kSbB; idx += kThreads) {
+    const int col = idx >> 3, q = idx & 7;
+    double2 x = make_double2(0.0, 0.0), v = x, vn = x;
+    if (cb0 + col < n) {
+      x = X[(int64_t)(cb0 + col) * kSbB + q];
+      v = Vold[(int64_t)(cb0 + col) * kSbB + q];
+      vn = Vnew[(int64_t)(cb0 + col) * kSbB + q];
+    }
+    sJ[0][q][col] = x.x, sJ[1][q][col] = x.y, sJ[2][q][col] = v.x, sJ[3][q][col] = v.y;
+    sB[0][col][q] = vn.x, sB[0][col][8 + q] = vn.y;
+    sB[1][col][q] = -vn.y, sB[1][col][8 + q] = vn.x;
+  }
+  __syncthreads();
+  const bool lo = lr < 8;
+  const int vq = lr & 7;
+  double* const tre = &sT[wave][0][0];
+  double* const tim = &sT[wave][1][0];
+  double* const Zp = sb_Zp(tp, mat) + (int64_t)blockIdx.x * n * 16;
+  v4d zc[4], mp = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) zc[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+  const int nstep = (n - cb0) / 16;
+  double2 cc[4];
+  if (wave < nstep) {
+    const double2* cp = A + (int64_t)(cb0 + 16 * wave + lk) * n + cb0 + lr;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) cc[reg] = cp[(int64_t)4 * reg * n];
+  }
+  for (int t = wave; t < nstep; t += 4) {
+    const int r0 = cb0 + 16 * t;
+    const int ncb = min(t + 1, ntile);  // tiles of this row step; tile t (if it exists) is the diagonal one
+    double2* const rowp = A + (int64_t)(r0 + lk) * n + cb0 + lr;
+    // I side of the step: rows r0 + lr of V, X (update), rows r0 + lk + 4 reg of V' (column product)
+    double nvr[2], nvi[2], pvr[2], nxr[2], nxi[2], pxr[2], b1[4], b2[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double2 v = Vold[(int64_t)(r0 + lr) * kSbB + lk + 4 * h], x = X[(int64_t)(r0 + lr) * kSbB + lk + 4 * h];
+      nvr[h] = -v.x, nvi[h] = -v.y, pvr[h] = v.x;
+      nxr[h] = -x.x, nxi[h] = -x.y, pxr[h] = x.x;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const double2 vn = Vnew[(int64_t)(r0 + lk + 4 * reg) * kSbB + vq];
+      b1[reg] = lo ? vn.x : vn.y;
+      b2[reg] = lo ? vn.y : -vn.x;
+    }
+    v4d zr = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      if (cb < ncb) {
+        v4d cre, cim;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cre[reg] = cc[reg].x, cim[reg] = cc[reg].y;
+        {  // the next tile's loads fly under this tile's MFMAs
+          const double2* nx = cb + 1 < ncb ? rowp + 16 * (cb + 1) : rowp + (int64_t)64 * n;
+          if (cb + 1 < ncb || t + 4 < nstep) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cc[reg] = nx[(int64_t)4 * reg * n];
+          }
+        }
+        // C -= V_I X_J^H + X_I V_J^H:  Re = Vr Xr + Vi Xi + Xr Vr + Xi Vi,  Im = Vi Xr - Vr Xi + Xi Vr - Xr Vi
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = lk + 4 * h, c = 16 * cb + lr;
+          const double jxr = sJ[0][q][c], jxi = sJ[1][q][c], jvr = sJ[2][q][c], jvi = sJ[3][q][c];
+          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvr[h], jxr, cre, 0, 0, 0);
+          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxr, cim, 0, 0, 0);
+          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxi, cre, 0, 0, 0);
+          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pvr[h], jxi, cim, 0, 0, 0);
+          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxr[h], jvr, cre, 0, 0, 0);
+          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvr, cim, 0, 0, 0);
+          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvi, cre, 0, 0, 0);
+          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pxr[h], jvi, cim, 0, 0, 0);
+        }
+        double2* const cur = rowp + 16 * cb;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cur[(int64_t)4 * reg * n] = make_double2(cre[reg], cim[reg]);
+        // Z_J += C^H V'_I
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          zc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cre[reg], b1[reg], zc[cb], 0, 0, 0);
+          zc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cim[reg], b2[reg], zc[cb], 0, 0, 0);
+        }
+        if (cb < t) {  // below the diagonal: Z_I += C V'_J
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            tre[lr * 17 + 4 * reg + lk] = cre[reg];
+            tim[lr * 17 + 4 * reg + lk] = cim[reg];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: the LDS serves its requests in order)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double are = tre[(4 * s + lk) * 17 + lr], aim = tim[(4 * s + lk) * 17 + lr];
+            const double r1 = sB[0][16 * cb + 4 * s + lk][lr], r2 = sB[1][16 * cb + 4 * s + lk][lr];
+            zr = __builtin_amdgcn_mfma_f64_16x16x4f64(are, r1, zr, 0, 0, 0);
+            zr = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, r2, zr, 0, 0, 0);
+          }
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+    if (t > 0) {  // the step's row contribution: this block's partial for rows r0 .. r0 + 15, and its share of M = V'^H Z
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        Zp[(int64_t)(r0 + lk + 4 * reg) * 16 + lr] = zr[reg];
+        mp = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[reg], zr[reg], mp, 0, 0, 0);
+      }
+    }
+  }
+  // column contributions: summed over the block's waves in wave order, wave cb finishes column tile cb
+  __syncthreads();
+  double* const sR = &sT[0][0][0];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sR[wave * 256 + reg * 64 + lane] = zc[cb][reg];
+    __syncthreads();
+    if (wave == cb && cb < ntile) {
+      const int c0 = cb0 + 16 * cb;
+      double* Zd = reinterpret_cast<double*>(sb_Z(tp, mat));
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const double zs = (sR[reg * 64 + lane] + sR[256 + reg * 64 + lane]) + (sR[512 + reg * 64 + lane] + sR[768 + reg * 64 + lane]);
+        Zd[((int64_t)(c0 + lk + 4 * reg) * kSbB + vq) * 2 + (lo ? 0 : 1)] = zs;
+        const double2 vj = Vnew[(int64_t)(c0 + lk + 4 * reg) * kSbB + vq];
+        mp = __builtin_amdgcn_mfma_f64_16x16x4f64(lo ? vj.x : vj.y, zs, mp, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  double* Mw = sb_Mp(tp, mat) + (int64_t)(4 * blockIdx.x + wave) * 256;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) Mw[(lk + 4 * reg) * 16 + lr] = mp[reg];
 }

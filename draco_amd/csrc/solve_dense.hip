@@ -106,7 +106,8 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
     tp.j = k;
     panel();
     const int org = (kSbB * (k + 1)) & ~15;
-    hipLaunchKernelGGL(k_sb_sweep, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
+    if (tp.sb_lower) hipLaunchKernelGGL(k_sb_sweep_lo, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
+    else hipLaunchKernelGGL(k_sb_sweep, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
   }
   tp.j = K;
   panel();
@@ -810,6 +811,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.fail = fail_b;
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
+        tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
         DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
         if (tp.two_stage) {
@@ -1007,6 +1009,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.fail = fail_hd;
     tp.tri = n <= 2048 ? 1 : 0;
     tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
+    tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
     if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
     if (tp.two_stage) {
