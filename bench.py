@@ -396,6 +396,8 @@ def main_dense(args, cpu):
     ctx = Context.get()
     cfg = wl.CONFIGS[args.config]
     kind = args.maker
+    if os.environ.get("DMM_ML_REDUCE"):  # (A/B switch of the eigen path's reduction: see include/draco_amd.h)
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", int(os.environ["DMM_ML_REDUCE"])))
     tiles = args.tiles or "screen"
     nfreq_cfg, nra, lmax, nside = cfg["nfreq"], cfg["nra"], cfg["lmax"], cfg["nside"]
     nfreq = args.freqs if args.freqs > 0 else nfreq_cfg

@@ -4,22 +4,25 @@
 // A one-stage Householder reduction multiplies the trailing matrix by a vector once per column: n^3/6 * 20 bytes of HBM
 // traffic per matrix whatever the blocking.  Here:
 //
-//   stage 1  dense -> band of half-width kSbB = 8, panel by panel (k_sb_panel, k_sb_sweep).  Per panel of 8 columns:
+//   stage 1  dense -> band of half-width kSbB = 8, panel by panel (k_sb_panel, k_sb_sweep_lo).  Per panel of 8 columns:
 //            QR of the sub-panel below the band (reflectors V, triangular factor T; one block per matrix, the panel in
-//            registers), then ONE sweep over the trailing matrix that applies the previous panel's two-sided update
-//            A -= V X^H + X V^H and forms Z = A V of the new panel from the freshly updated tiles -- both on
-//            v_mfma_f64_16x16x4_f64, the updated tile never leaving the accumulators in between: its D layout
-//            (row = (lane >> 4) + 4 reg, column = lane & 15) IS a valid A-operand layout for the product over the
-//            tile's rows, which by Hermitian symmetry is the product the next panel needs.  32 bytes per trailing
-//            element and 8 columns instead of 20 per column.
+//            registers), then ONE sweep over the lower triangle of the trailing matrix that applies the previous
+//            panel's two-sided update A -= V X^H + X V^H and forms Z = A V of the new panel from the freshly updated
+//            tiles -- both on v_mfma_f64_16x16x4_f64, the updated tile never leaving the accumulators in between: its
+//            D layout (row = (lane >> 4) + 4 reg, column = lane & 15) IS a valid A-operand layout for the product over
+//            the tile's rows; the mirror image's share (product over the tile's columns) takes the tile through a
+//            16 x 17 LDS transposition.  8.5 KB per 16 x 16 tile below the diagonal and 8 columns, where a one-stage
+//            reduction moves 20 bytes per element and column.  (k_sb_sweep: the same over the full matrix, the A/B.)
 //   stage 2  band -> real tridiagonal by bulge chasing with length-8 reflectors, the whole band in LDS (k_sb_chase):
-//            9 diagonals + the 21-entry bulge triangle each block position keeps between sweeps = 143 KB at n = 768.
+//            9 diagonals + the 21-entry bulge triangle each block position keeps between sweeps = 144 KB at n = 768;
+//            a wave works on eight consecutive sweeps at once, a lane holding one column of its sweep's 8 x 8 block.
 //            Every reflector is logged (8 complex values) for the back-transformation.
 //   apply    z = Q2^H Q1^H b before the QL solve, x = Q1 Q2 y after it (sb_apply_q1 / sb_apply_q2, called from
 //            k_td_solve): Q1 panel by panel (block reflectors), Q2 sweep by sweep -- the reflectors of one sweep act
 //            on disjoint index ranges, so a whole sweep is applied at once.
 //
-// Storage.  A [n][n] full Hermitian on entry (both triangles).  On exit of stage 1 the LOWER band holds the band
+// Storage.  A [n][n] Hermitian on entry: the lower triangle and the 16 x 16 tiles on the diagonal in full (k_sb_sweep: both
+// triangles).  On exit of stage 1 the LOWER band holds the band
 // matrix, row 8k + c of the upper triangle (columns >= 8 (k + 1)) column c of panel k's V.  The work arrays live in the
 // matrix's rotation-log region, which is free until the QL solve: the operand arrays V[2], X, Z ([n][8] each, indexed
 // by GLOBAL row, zero outside their support -- no tile of the sweep needs a mask) at its head, the T factors and the
@@ -41,7 +44,7 @@ __host__ __device__ constexpr int64_t sb_nlog(int n) { return sb_total(n - 1); }
 // double2 units at the tail of a matrix's log region: T factors [npanel][64], then the reflector log [nlog][8]
 __host__ __device__ constexpr int64_t sb_tail(int n) { return (int64_t)sb_npanel(n) * 64 + sb_nlog(n) * kSbB; }
 // LDS of the chase kernel: band [9][n+1] + bulge triangles [n/8 + 2][21], double2
-__host__ __device__ constexpr size_t sb_chase_lds(int n) { return ((size_t)(kSbB + 1) * (n + 1) + (size_t)(n / kSbB + 2) * 21) * sizeof(double2); }
+__host__ __device__ constexpr size_t sb_chase_lds(int n) { return ((size_t)(kSbB + 1) * (n + 2) + (size_t)(n / kSbB + 2) * 21) * sizeof(double2); }
 
 // where a matrix's work arrays live in its log region (single pointers: a struct of them ends up in scratch / LDS)
 __device__ __forceinline__ double2* sb_base(const TdParams& tp, int mat) { return tp.log_cs + (int64_t)mat * tp.log_stride; }
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_sweep(TdParams tp) {
 // the upper triangle is never touched again (the reflectors of finished panels stay there).
 // The J-side operands (X, V of update k-1, V' of panel k for the block's 64 columns) sit in LDS in the lane order of
 // the MFMA B operands.
-__global__ __launch_bounds__(kThreads) void k_sb_sweep_lo(TdParams tp) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_sb_sweep_lo(TdParams tp) {
   __shared__ double sJ[4][kSbB][64];   // Xr, Xi, Vr, Vi: [q][column]
   __shared__ double sB[2][64][16];     // per column [V'r | V'i] and [-V'i | V'r] (entries q = 0..7 each)
   __shared__ double sT[4][2][16 * 17]; // per wave: the tile transposed, real and imaginary plane; at the end the reduction buffer
@@ -637,218 +640,246 @@ __global__ __launch_bounds__(kThreads) void k_sb_sweep_lo(TdParams tp) {
 }
 
 // ---------------------------------------------------------------------------------------------------- stage 2: chase
-// One wave per matrix (64 lanes = one 8 x 8 block: row i = lane & 7, column c = lane >> 3).  Band ab[d][col] = A[col+d][col]
-// (pitch n + 1: the 8 lanes of a column spread over the banks), bulge triangles bg[s][i (i - 1) / 2 + c], c < i <= 6, in
-// the coordinates of the sweep that reads them.  Blocks of sweep j: D_s = rows / columns R_s = [j + 1 + 8 s, + 8),
-// O_s = rows R_{s+1} x columns R_s.
-// Cross-lane traffic of the chase without the LDS crossbar (ds_bpermute: ~150 cycles each in a dependent chain, 84 of
-// them per iteration in the first version): the sums over 8 lanes are DPP moves (quad permutes, half-row mirror, row
-// rotation by 8) and, across the 16-lane rows, gfx950's v_permlane16_swap / v_permlane32_swap -- all vector-ALU
+// Cross-lane sums of the chase without the LDS crossbar: DPP moves (quad permutes, half-row mirror) -- vector-ALU
 // instructions.  Checked lane by lane against plain sums in tools/probe/dpp_probe.hip.
-typedef unsigned sb_v2u __attribute__((ext_vector_type(2)));
 template <int CTRL>
 __device__ __forceinline__ double sb_dpp(double x) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double sb_add_x16(double x) {  // x + x(lane ^ 16)
-  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-  const sb_v2u a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-}
-__device__ __forceinline__ double sb_add_x32(double x) {  // x + x(lane ^ 32)
-  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-  const sb_v2u a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-}
-__device__ __forceinline__ double sb_sum8_c(double x) {  // sum over the 8 lanes of equal i (c = lane >> 3): every lane gets it
-  x += sb_dpp<0x128>(x);  // row_ror:8  (lane ^ 8 within the 16-lane row)
-  x = sb_add_x16(x);
-  return sb_add_x32(x);
-}
-__device__ __forceinline__ double sb_sum8_i(double x) {  // sum over the 8 lanes of equal c (i = lane & 7)
+__device__ __forceinline__ double sb_sum8_i(double x) {  // sum over the 8 lanes of an aligned group of 8: every lane gets it
   x += sb_dpp<0xB1>(x);   // quad_perm [1, 0, 3, 2]
   x += sb_dpp<0x4E>(x);   // quad_perm [2, 3, 0, 1]
   x += sb_dpp<0x141>(x);  // row_half_mirror: the other quad of the 8
   return x;
 }
-__device__ __forceinline__ double2 sb_sum_over_c(double2 v) { return make_double2(sb_sum8_c(v.x), sb_sum8_c(v.y)); }
 __device__ __forceinline__ double2 sb_sum_over_i(double2 v) { return make_double2(sb_sum8_i(v.x), sb_sum8_i(v.y)); }
 __device__ __forceinline__ double2 sb_shfl2(double2 v, int src) { return make_double2(__shfl(v.x, src), __shfl(v.y, src)); }
-// the value of lane 0 in every lane (lane 0 is always active here): through a scalar register
-__device__ __forceinline__ double sb_lane0(double x) {
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
-}
-__device__ __forceinline__ double2 sb_lane0(double2 v) { return make_double2(sb_lane0(v.x), sb_lane0(v.y)); }
-// lanes 0..7 (c = 0) hold v_i: give every lane (i, c) its v_i.  Second half of row 0 by a row rotation, then row 0 into
-// the other three rows by the two swaps (what rows 1..3 held is irrelevant)
-__device__ __forceinline__ double sb_bcast_c0(double x, int lane) {
-  const double r = sb_dpp<0x128>(x);
-  x = (lane & 8) ? r : x;
-  unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-  lo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false)[0];
-  hi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false)[0];
-  lo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[0];
-  hi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false)[0];
-  return __hiloint2double((int)hi, (int)lo);
-}
-__device__ __forceinline__ double2 sb_bcast_c0(double2 v, int lane) { return make_double2(sb_bcast_c0(v.x, lane), sb_bcast_c0(v.y, lane)); }
+#define SB_ZERO make_double2(0.0, 0.0)
 
-// kSbWaves waves per matrix, wave w taking the sweeps j = w, w + W, ...: sweep j may run iteration s once sweep j - 1 has
-// finished its iteration s + 2 (iteration s of sweep j touches the indices j + 1 + 8 s .. j + 8 s + 16, the iterations
-// >= s + 3 of sweep j - 1 only j + 8 s + 24 and beyond), so the waves follow each other down the band three iterations
-// apart.  A wave publishes (sweep, iterations done) in LDS after its writes have landed; its successor spins on it.
-constexpr int kSbWaves = 16;
-// Ordering between the waves of the chase goes through LDS only, and the LDS serves a CU's requests in the order they
-// were issued: what a wave has to do before it publishes its progress is to have ISSUED its band writes (in order, one
-// queue) -- `s_waitcnt lgkmcnt(0)` plus a compiler barrier.  (__threadfence_block() also waits for the global stores of
-// the reflector log, ~2 us each: measured 4x on the whole kernel.)
-#define SB_LDS_FENCE()                          \
-  do {                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-  } while (0)
-__global__ __launch_bounds__(64 * kSbWaves) void k_sb_chase(TdParams tp) {
+// Blocks of sweep j: D_s = rows / columns R_s = [j + 1 + 8 s, + 8), O_s = rows R_{s+1} x columns R_s.  Band
+// ab[d][col] = A[col + d][col] (pitch n + 2), bulge triangles bg[s][i (i - 1) / 2 + c], c < i <= 6, in the coordinates of the
+// sweep that reads them.  Per iteration: D <- H^H D H, O <- O H, the reflector H2 of O's first column, O <- H2^H O.
+//
+// Lane = (slot g, column c): a wave works on EIGHT consecutive sweeps at once -- slot g on sweep 8 G + g, kSbLag
+// iterations behind slot g - 1 -- and a lane holds a whole COLUMN of its slot's 8 x 8 block in registers.  Everything
+// that runs down a column is then register arithmetic: u = D v through the Hermitian symmetry (u_c = sum_i conj(D_ic)
+// v_i), v2^H O, the norm of the new reflector, both rank-one updates.  Across the 8 lanes of a slot go only: v^H u
+// (one sum), w (all-gather through 8 LDS entries), O v (sums of 8 complex values: DPP butterflies inside the 8-lane
+// group), and the block's first column (broadcast through LDS).  (The first version -- one 8 x 8 block per wave, one
+// element per lane, 16 waves -- spent ~450 instructions per block iteration, most of them on cross-lane sums and
+// broadcasts, at four waves a SIMD: 17 ms per matrix of order 768; this one 5.7 ms.)
+//
+// The lag.  Iteration s of sweep j touches the elements of D_s and O_s: rows and columns up to j + 8 s + 16, but of row
+// j + 8 s + 16 only the columns of R_s.  Iteration s + 2 of sweep j - 1 starts at row AND column j + 8 s + 16: no
+// element in common -- so sweep j may run iteration s once sweep j - 1 has finished iteration s + 1, two iterations
+// behind (the index ranges overlap in that one row, which is why three looks necessary at first sight).  The chain
+// of 767 sweeps is then 2 x 767 block iterations long instead of 3 x 767 -- and it is that chain, not the work, that
+// the kernel's time is: with the waits taken out (wrong results) it runs only 20 % faster.  Inside a wave the lag is
+// plain lockstep; four waves cover the 32 sweeps that fit on the band at once, wave w + 1 follows wave w 16 steps
+// behind through a progress counter in LDS (ordering between waves: the LDS serves a CU's requests in the order they
+// were issued, `s_waitcnt lgkmcnt(0)` plus a compiler barrier before the counter is enough; __threadfence_block()
+// would also wait for the reflector log's global stores).
+//
+// The kernel keeps a CU's LDS to itself: while it runs, the CU takes no Gram or sweep block (measured: side by side
+// with the next chunk's Gram launch both take as long as one after the other).  What it costs the pass is therefore
+// its own duration: 28 ms per 1180 matrices.
+constexpr int kSbCW = 4;
+constexpr int kSbLag = 2;  // iterations between consecutive sweeps (see the kernel's comment)
+__host__ __device__ constexpr int sb_pitch(int n) { return n + 2; }  // a column's 8 lanes (stride pitch - 1 or pitch) spread over the banks
+__global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
   extern __shared__ __align__(16) unsigned char smem_sb[];
-  __shared__ int s_prog[kSbWaves];
+  __shared__ int s_prog[kSbCW];
+  __shared__ __align__(16) double2 s_scr[kSbCW][64];
   const DenseParams& p = tp.d;
-  const int n = p.Np, pitch = n + 1;
+  const int n = p.Np, pitch = sb_pitch(n);
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
   const double2* A = p.A + (int64_t)mat * n * n;
   double2* ab = reinterpret_cast<double2*>(smem_sb);
-  double2* bg = ab + (int64_t)(kSbB + 1) * pitch;
+  const int bg0 = (kSbB + 1) * pitch;  // the bulge triangles follow the band
   double2* const rlog = sb_rlog(tp, mat);
   double2* vbm = tp.vec + (int64_t)mat * td_slots(n) * n;
   double* dd = reinterpret_cast<double*>(vbm + 5 * n);
   double* ee = dd + n;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 7, c = lane >> 3;
-#define SB_ZERO make_double2(0.0, 0.0)
-  for (int e = threadIdx.x; e < (kSbB + 1) * n; e += 64 * kSbWaves) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, c = lane & 7;
+#define SB_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  for (int e = threadIdx.x; e < (kSbB + 1) * n; e += 64 * kSbCW) {
     const int d = e / n, col = e - d * n;
     ab[d * pitch + col] = col + d < n ? A[(int64_t)(col + d) * n + col] : SB_ZERO;
   }
-  for (int e = threadIdx.x; e < (n / kSbB + 2) * 21; e += 64 * kSbWaves) bg[e] = SB_ZERO;
-  if (threadIdx.x < kSbWaves) s_prog[threadIdx.x] = 0;
+  for (int e = threadIdx.x; e < (n / kSbB + 2) * 21; e += 64 * kSbCW) ab[bg0 + e] = SB_ZERO;
+  if (threadIdx.x < kSbCW) s_prog[threadIdx.x] = 0;
   __syncthreads();
   volatile int* prog = s_prog;
-  const int pred = (wave + kSbWaves - 1) % kSbWaves;
-  for (int j = wave; j < n - 1; j += kSbWaves) {
-    int64_t lpos = sb_log_prefix(n, j);
-    // the predecessor (sweep j - 1) must have finished iterations <= it + 2 before iteration `it` here; the first
-    // reflector counts as part of iteration 0
-#define SB_WAIT_FOR(IT)                                                               \
-  if (j > 0) {                                                                       \
-    const int need = ((j - 1) << 12) + (IT) + 3; /* iterations done >= it + 3 */      \
-    while (prog[pred] < need) __builtin_amdgcn_s_sleep(1);                           \
-    SB_LDS_FENCE();                                                           \
-  }
-    SB_WAIT_FOR(0)
-    // ---- first reflector of the sweep: from column j below the diagonal, rows r0 = j + 1 .. j + 8
-    int r0 = j + 1;
-    double2 x = SB_ZERO;
-    if (c == 0 && r0 + i < n) x = ab[(1 + i) * pitch + j];  // lanes c = 0 hold x_i
-    double2 tau, vi;
-    {
-      const double2 xx = make_double2((c == 0 && i > 0) ? x.x * x.x + x.y * x.y : 0.0, 0.0);
-      const double xn2 = sb_lane0(sb_sum8_i(xx.x));
-      const double2 alpha = sb_lane0(x);
-      const SbRefl rf = sb_larfg(alpha, xn2);
-      tau = rf.tau;
-      const double2 scale = rf.scale;
-      const double beta = rf.beta;
-      const double2 vv = sel2(i == 0, make_double2(1.0, 0.0), cmul(x, scale));  // valid in lanes c = 0
-      vi = sb_bcast_c0(vv, lane);                                             // v_i for every lane
-      if (r0 + i >= n) vi = SB_ZERO;
-      if (lane == 0) {
-        ab[1 * pitch + j] = make_double2(beta, 0.0);
-        ee[j] = beta;
-        dd[j] = ab[j].x;
+  double2* const scr = &s_scr[wave][8 * g];  // the slot's 8 entries
+  const int pred = (wave + kSbCW - 1) % kSbCW;
+  const int ngroup = (n - 2) / 8 + 1;  // sweeps 0 .. n - 2
+  // No branches inside a step (every one of them would end in a wait for its loads, with one wave per SIMD and nothing
+  // to hide it): a load that is masked out reads a spare bulge entry that stays zero, a store that is masked out goes to
+  // one of 16 spare entries nobody reads.
+  const int zero_at = bg0 + (n / kSbB + 1) * 21 + 16, junk_at = bg0 + (n / kSbB + 1) * 21 + (lane & 15);
+  for (int G = wave; G < ngroup; G += kSbCW) {
+    const int j = 8 * G + g;
+    const int Tj = j <= n - 2 ? (n - 2 - j) / 8 + 1 : 0;  // iterations of the slot's sweep (the last one has no block below it)
+    const int nstep = (n - 2 - 8 * G) / 8 + 1 + 7 * kSbLag;
+    int64_t lpos = sb_log_prefix(n, min(j, n - 2));
+    double2 tau = SB_ZERO, vown = SB_ZERO, v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = SB_ZERO;
+    for (int S = 0; S < nstep; ++S) {
+      if (G > 0) {  // sweep 8 G at iteration S needs sweep 8 G - 1 (slot 7 of the group before) through iteration S + 2
+        const int need = ((G - 1) << 12) + S + 8 * kSbLag;
+        while (prog[pred] < need) __builtin_amdgcn_s_sleep(1);
+        SB_FENCE();
       }
-      if (c == 0 && i > 0 && r0 + i < n) ab[(1 + i) * pitch + j] = SB_ZERO;
-      if (c == 0) rlog[lpos * kSbB + i] = sel2(i == 0, tau, vi);
-      ++lpos;
-    }
-    for (int s = 0;; ++s) {
-      if (s > 0) SB_WAIT_FOR(s)
-      const double2 vc = sb_shfl2(vi, c);  // v_c (lane c holds i = c, column 0)
+      const int it = S - kSbLag * g;
+      const bool act = it >= 0 && it < Tj;
+      const int r0 = j + 1 + 8 * it;
+      if (act && it == 0) {  // ---- first reflector of the sweep: column j below the diagonal (no cross-lane traffic in here)
+        double2 x[8];
+        double xn2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          x[i] = ab[r0 + i < n ? (1 + i) * pitch + j : zero_at];
+          if (i > 0) xn2 += x[i].x * x[i].x + x[i].y * x[i].y;
+        }
+        const SbRefl rf = sb_larfg(x[0], xn2);
+        tau = rf.tau;
+        v[0] = make_double2(1.0, 0.0);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[i] = cmul(x[i], rf.scale);
+        vown = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) vown = sel2(c == i, v[i], vown);
+        if (c == 0) {
+          ee[j] = rf.beta;
+          dd[j] = ab[j].x;
+          ab[1 * pitch + j] = make_double2(rf.beta, 0.0);
+#pragma unroll
+          for (int i = 1; i < 8; ++i) ab[r0 + i < n ? (1 + i) * pitch + j : junk_at] = SB_ZERO;
+          rlog[lpos * kSbB] = tau;
+#pragma unroll
+          for (int i = 1; i < 8; ++i) rlog[lpos * kSbB + i] = v[i];
+        }
+        ++lpos;
+      }
       // ---- D <- H^H D H on rows / columns r0 .. r0 + 7:  u = D v,  w = tau u - (|tau|^2 (v^H u) / 2) v,  D -= w v^H + v w^H
       {
-        const bool in = r0 + i < n && r0 + c < n;
-        double2 dv = SB_ZERO;
-        if (in) {
-          const double2 raw = ab[(i >= c ? i - c : c - i) * pitch + r0 + (i >= c ? c : i)];
-          dv = make_double2(raw.x, i >= c ? raw.y : -raw.y);
+        const bool inc = act && r0 + c < n;
+        double2 D[8];
+        int at[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool in = inc && r0 + i < n;
+          at[i] = in ? (i >= c ? (i - c) * pitch + r0 + c : (c - i) * pitch + r0 + i) : zero_at;
+          D[i] = ab[at[i]];
         }
-        if (i == c) dv.y = 0.0;
         double2 u = SB_ZERO;
-        cfma(u, dv, vc);
-        u = sb_sum_over_c(u);  // u_i
-        double2 vhu = SB_ZERO;
-        if (c == 0) cfmac(vhu, vi, u);
-        const double h = sb_lane0(sb_sum8_i(vhu.x));  // v^H u (real)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          D[i].y = i > c ? D[i].y : (i == c ? 0.0 : -D[i].y);
+          cfmac(u, D[i], v[i]);  // u_c = sum_i conj(D_ic) v_i
+        }
+        const double h = sb_sum8_i(vown.x * u.x + vown.y * u.y);  // v^H u (real)
         const double t2 = 0.5 * (tau.x * tau.x + tau.y * tau.y) * h;
-        double2 wi = cmul(tau, u);
-        wi.x -= t2 * vi.x, wi.y -= t2 * vi.y;
-        const double2 wc = sb_shfl2(wi, c);
-        cfma(dv, wi, make_double2(-vc.x, vc.y));  // - w_i conj(v_c)
-        cfma(dv, vi, make_double2(-wc.x, wc.y));  // - v_i conj(w_c)
-        if (in && i >= c) ab[(i - c) * pitch + r0 + c] = make_double2(dv.x, i == c ? 0.0 : dv.y);
+        double2 wc = cmul(tau, u);
+        wc.x -= t2 * vown.x, wc.y -= t2 * vown.y;
+        scr[c] = wc;
+        SB_FENCE();
+        double2 w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = scr[i];
+        const double2 nvc = make_double2(-vown.x, vown.y), nwc = make_double2(-wc.x, wc.y);  // - conj(v_c), - conj(w_c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          cfma(D[i], w[i], nvc);
+          cfma(D[i], v[i], nwc);
+          ab[i >= c && at[i] != zero_at ? at[i] : junk_at] = make_double2(D[i].x, i == c ? 0.0 : D[i].y);
+        }
+        SB_FENCE();
       }
-      const int q0 = r0 + kSbB;
-      if (q0 >= n) break;
       // ---- O = rows q0 .. q0 + 7 x columns r0 .. r0 + 7: band part (i <= c), the bulge the previous sweep left (c < i <= 6)
-      const bool oin = q0 + i < n && r0 + c < n;
-      double2 ov = SB_ZERO;
-      if (oin) {
-        if (i <= c) ov = ab[(kSbB + i - c) * pitch + r0 + c];
-        else if (i <= kSbB - 2) ov = bg[s * 21 + i * (i - 1) / 2 + c];
+      {
+        const bool oact = act && it < Tj - 1;
+        const int q0 = r0 + kSbB;
+        const bool inc = oact && r0 + c < n;
+        double2 O[8], tv[8];
+        int at[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool in = inc && q0 + i < n;
+          at[i] = in ? (i <= c ? (kSbB + i - c) * pitch + r0 + c : bg0 + it * 21 + i * (i - 1) / 2 + c) : zero_at;
+          O[i] = ab[in && (i <= c || i <= kSbB - 2) ? at[i] : zero_at];
+        }
+        // O <- O H = O - tau (O v) v^H
+        const double2 nvc = make_double2(-vown.x, vown.y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = cmul(O[i], vown);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          tv[i] = make_double2(sb_sum8_i(tv[i].x), sb_sum8_i(tv[i].y));
+          cfma(O[i], cmul(tau, tv[i]), nvc);
+        }
+        // the block's first column to every lane of the slot; its reflector
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(c == 0 ? scr + i : ab + junk_at) = O[i];
+        SB_FENCE();
+        double2 x[8], v2[8];
+        double xn2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          x[i] = scr[i];
+          if (i > 0) xn2 += x[i].x * x[i].x + x[i].y * x[i].y;
+        }
+        const double2 xown = scr[c];
+        SB_FENCE();
+        const SbRefl rf = sb_larfg(x[0], xn2);  // (nothing below the diagonal, or an idle slot: tau2 = 0, v2 = e_0)
+        const double2 tau2 = rf.tau;
+        v2[0] = make_double2(1.0, 0.0);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v2[i] = cmul(x[i], rf.scale);  // (rows beyond the matrix are zero rows of O)
+        const double2 v2own = c == 0 ? make_double2(1.0, 0.0) : cmul(xown, rf.scale);
+        // O <- H2^H O = O - conj(tau2) v2 (v2^H O)
+        double2 sc = SB_ZERO;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cfmac(sc, v2[i], O[i]);
+        const double2 f = cmul(cconj2(tau2), sc);
+        const double2 nf = make_double2(-f.x, -f.y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          cfma(O[i], nf, v2[i]);
+          if (i == 0) O[0] = sel2(c == 0, make_double2(rf.beta, 0.0), O[0]);
+          // band part back in place; below it (c >= 1) the bulge, in the next sweep's coordinates (i - 1, c - 1)
+          const int to = i <= c ? at[i] : bg0 + it * 21 + (i - 1) * (i - 2) / 2 + c - 1;
+          ab[at[i] != zero_at && (i <= c || c >= 1) ? to : junk_at] = O[i];
+        }
+        if (c == 0 && oact) {
+          rlog[lpos * kSbB] = tau2;
+#pragma unroll
+          for (int i = 1; i < 8; ++i) rlog[lpos * kSbB + i] = v2[i];
+        }
+        lpos += oact ? 1 : 0;
+        tau = tau2;  // (an idle or finished slot's state is never used: the first iteration of a sweep sets all of it)
+        vown = v2own;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v2[i];
       }
-      // O <- O H = O - tau (O v) v^H
-      double2 tv = SB_ZERO;
-      cfma(tv, ov, vc);
-      tv = sb_sum_over_c(tv);
-      cfma(ov, cmul(tau, tv), make_double2(-vc.x, vc.y));
-      // reflector of the block's first column
-      const double2 xx = make_double2((c == 0 && i > 0) ? ov.x * ov.x + ov.y * ov.y : 0.0, 0.0);
-      const double xn2 = sb_lane0(sb_sum8_i(xx.x));
-      const double2 alpha = sb_lane0(ov);
-      const SbRefl rf = sb_larfg(alpha, xn2);
-      const double2 tau2 = rf.tau, scale = rf.scale;
-      const double beta = rf.beta;
-      const double2 vv = sel2(i == 0, make_double2(1.0, 0.0), cmul(ov, scale));  // valid in lanes c = 0
-      double2 v2 = sb_bcast_c0(vv, lane);
-      if (q0 + i >= n) v2 = SB_ZERO;
-      // O <- H2^H O = O - conj(tau2) v2 (v2^H O)
-      double2 sc = SB_ZERO;
-      cfmac(sc, v2, ov);
-      sc = sb_sum_over_i(sc);
-      cfma(ov, cmul(cconj2(tau2), sc), make_double2(-v2.x, -v2.y));
-      if (c == 0) ov = make_double2(i == 0 ? beta : 0.0, 0.0);
-      if (oin) {
-        if (i <= c) ab[(kSbB + i - c) * pitch + r0 + c] = ov;
-        else if (c >= 1) bg[s * 21 + (i - 1) * (i - 2) / 2 + c - 1] = ov;  // next sweep's coordinates (i - 1, c - 1)
-      }
-      if (c == 0) rlog[lpos * kSbB + i] = sel2(i == 0, tau2, v2);
-      ++lpos;
-      r0 = q0;
-      tau = tau2;
-      vi = v2;
-      // iteration s is done: its LDS writes first, then the counter
-      SB_LDS_FENCE();
-      if (lane == 0) prog[wave] = (j << 12) + s + 1;
+      // step S is done: its LDS writes first, then the counter
+      SB_FENCE();
+      if (lane == 0) prog[wave] = (G << 12) + S + 1;
     }
-    SB_LDS_FENCE();
-    if (lane == 0) prog[wave] = (j << 12) + 4095;  // the whole sweep
-#undef SB_WAIT_FOR
+    SB_FENCE();
+    if (lane == 0) prog[wave] = (G << 12) + 4095;  // the whole group
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     dd[n - 1] = ab[n - 1].x;
     ee[n - 1] = 0.0;
   }
+#undef SB_FENCE
 }
 #undef SB_ZERO
-#undef SB_LDS_FENCE
 
 // ---------------------------------------------------------------------------------------------------- applications
 // b (LDS, n entries) <- Q1^H b (ADJ) or Q1 b,  Q1 = prod_k (I - V_k T_k V_k^H);  256 threads, `red`: >= 5 * 16 doubles

@@ -89,7 +89,7 @@ void td_reduce(TdParams& tp, int nmat, hipStream_t st) {
 constexpr size_t kSbLdsMax = 160 * 1024;
 bool sb_usable(const dmm_ctx* ctx, int n) {
   if (ctx->opt_ml_reduce == 1) return false;
-  return n >= 64 && n % 64 == 0 && n <= kSbRows * kThreads && sb_chase_lds(n) <= kSbLdsMax;
+  return n >= 64 && n % 64 == 0 && n <= kSbRows * kThreads && sb_chase_lds(n) + 4608 <= kSbLdsMax;  // (+ the chase kernel's static scratch)
 }
 // QL's rotation log shares the matrix's log region with the T factors and the chase's reflector log at its tail
 int64_t sb_log_cap(int64_t log_stride, int n, int runs) {
@@ -113,7 +113,7 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   panel();
 }
 void sb_chase(const TdParams& tp, int nmat, hipStream_t st) {
-  hipLaunchKernelGGL(k_sb_chase, dim3(nmat), dim3(64 * kSbWaves), sb_chase_lds(tp.d.Np), st, tp);
+  hipLaunchKernelGGL(k_sb_chase, dim3(nmat), dim3(64 * kSbCW), sb_chase_lds(tp.d.Np), st, tp);
 }
 
 // QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
@@ -993,7 +993,9 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       } else {
         hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
       }
-      hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, S1, p);
+      // (the lower-triangle band reduction reads the upper triangle only inside the diagonal tiles, which the Gram
+      // kernel writes in full)
+      if (!(sb_usable(ctx, n) && ctx->opt_ml_reduce != 2)) hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, S1, p);
     }
     TdParams tp;
     tp.d = p;
