@@ -455,7 +455,7 @@ def main_dense(args, cpu):
     elapsed = time.perf_counter() - t0
     mem1 = torch.cuda.memory_stats()
     prof = {k: {"ms": counter(f"prof_{k}_us".encode()) / 1e3 / args.steps, "spans": counter(f"prof_{k}_n".encode()) // max(args.steps, 1)}
-            for k in ("gram", "chol", "tridiag", "band", "ql", "backproj")}
+            for k in ("gram", "chol", "tridiag", "band", "chase", "ql", "backproj")}
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
     c1 = {k: counter(k) for k in c0}
     assert eng.fills == fills_before or args.warmup == 0, "B was generated inside the timed region"
@@ -470,18 +470,32 @@ def main_dense(args, cpu):
     secondary = []
     if kind == "ml" and (prof["tridiag"]["ms"] > 0 or prof["band"]["ms"] > 0):
         ntel = 2 * npairs
-        # one-stage Householder reduction: every column sweeps the upper triangle of its trailing matrix once, 16 B read
-        # per element and 16 B more on the sweeps that apply the pending rank-2 updates (every fourth): n^3/6 * 20 B
-        red_ms = prof["tridiag"]["ms"] + prof["band"]["ms"]
-        by = 0.0
-        for m in range(lmax + 1):
-            k = min(ntel, 4 * (lmax + 1 - m))
-            by += k**3 / 6.0 * 20.0
-        by *= nfreq * (n_eigen / max(n_direct + n_eigen, 1))
-        secondary.append({"kernel": "Hermitian tridiagonal reduction of the decomposed tiles (k_td_col + k_td_trail_tri; two-stage: dense -> band -> tridiagonal)",
-                          "bound": "hbm", "achieved": by / (red_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": by / (red_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_day": red_ms,
-                          "note": "bytes = the ONE-STAGE algorithm's n^3/6 * 20 B per decomposed tile (the yardstick VERDICT r2 used); a two-stage reduction moves fewer bytes, its fraction on this yardstick may exceed what its own traffic would give"})
+        frac_eig = n_eigen / max(n_direct + n_eigen, 1)
+        if prof["band"]["ms"] > 0:
+            # stage 1 of the two-stage reduction (k_sb_panel + k_sb_sweep_lo): per panel of 8 columns every 16 x 16 tile of
+            # the trailing matrix's lower triangle is read and written once (8 KB) and leaves 0.5 KB of row partials
+            by = 0.0
+            for m in range(lmax + 1):
+                n = -(-min(ntel, 4 * (lmax + 1 - m)) // 64) * 64
+                for k in range(n // 8 - 1):
+                    t = (n - ((8 * (k + 1)) & ~15)) // 16
+                    by += t * (t + 1) / 2 * 8.5 * 1024
+            by *= nfreq * frac_eig
+            ms = prof["band"]["ms"]
+            secondary.append({"kernel": "two-stage reduction, stage 1: dense -> band (k_sb_sweep_lo + k_sb_panel)",
+                              "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_day": ms,
+                              "note": "bytes = 8.5 KB per lower-triangle tile and panel (DESIGN 5.5); the time is the whole class, panel kernels (latency bound, about a fifth of it) included, measured inside the step with the chase and QL of the previous chunk beside it"})
+            secondary.append({"kernel": "two-stage reduction, stage 2: band -> tridiagonal (k_sb_chase, side stream)", "bound": "latency",
+                              "ms_per_day": prof["chase"]["ms"], "note": "a dependency chain of 2 (n - 1) block iterations per matrix, the band in LDS: no roofline applies"})
+        if prof["tridiag"]["ms"] > 0:
+            # one-stage Householder reduction (orders whose band does not fit the LDS, or ml_reduce = 1): n^3/6 * 20 B
+            by = sum(min(ntel, 4 * (lmax + 1 - m)) ** 3 / 6.0 * 20.0 for m in range(lmax + 1)) * nfreq * frac_eig
+            ms = prof["tridiag"]["ms"]
+            secondary.append({"kernel": "one-stage Hermitian tridiagonal reduction (k_td_col + k_td_trail_tri)",
+                              "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_day": ms,
+                              "note": "bytes = n^3/6 * 20 B per decomposed tile (a fraction is only meaningful when every tile went this way)"})
     out = {
         "metric": f"m-modes/sec through MModeTransform+{cls.__name__} (128-feed, 256-freq)",
         "value": value, "unit": "m-modes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,

@@ -14,7 +14,7 @@ int dmm_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-static const char* const kProfNames[DMM_PROF_NSLOT] = {"gram", "chol", "tridiag", "ql", "backproj", "band"};
+static const char* const kProfNames[DMM_PROF_NSLOT] = {"gram", "chol", "tridiag", "ql", "backproj", "band", "chase"};
 
 // read every finished span into the per-class sums (waits for spans still running)
 static void prof_collect(dmm_ctx* c) {

@@ -815,8 +815,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
         DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
         if (tp.two_stage) {
-          dmm_prof_scope prof(ctx, DMM_PROF_BAND, ctx->stream);
-          sb_reduce(tp, nsel, ctx->stream);
+          {
+            dmm_prof_scope prof(ctx, DMM_PROF_BAND, ctx->stream);
+            sb_reduce(tp, nsel, ctx->stream);
+          }
+          dmm_prof_scope prof(ctx, DMM_PROF_CHASE, ctx->stream);
           sb_chase(tp, nsel, ctx->stream);
         } else {
           dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, ctx->stream);
@@ -1025,7 +1028,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipEventRecord(ctx->aux_ev[h], S1));
     DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
     if (tp.two_stage) {  // the chase is one wave per matrix, as latency bound as QL: it runs beside the next chunk's sweeps too
-      dmm_prof_scope prof(ctx, DMM_PROF_BAND, S2);
+      dmm_prof_scope prof(ctx, DMM_PROF_CHASE, S2);
       sb_chase(tp, nmat, S2);
     }
     {
