@@ -132,10 +132,12 @@ __global__ __launch_bounds__(kThreads) void k_mfft_pack(MfftParams p) {
       im = (s ? -(double)v.y : (double)v.y) * sc;
     }
     const int64_t o = (int64_t)ms * p.nrow + r0 + r;
-    if (p.out_c128)
-      reinterpret_cast<double2*>(p.out)[o] = make_double2(re, im);
-    else
+    if (p.out_c128) {  // written once, read by a later kernel
+      __builtin_nontemporal_store(re, reinterpret_cast<double*>(p.out) + 2 * o);
+      __builtin_nontemporal_store(im, reinterpret_cast<double*>(p.out) + 2 * o + 1);
+    } else {
       reinterpret_cast<float2*>(p.out)[o] = make_float2((float)re, (float)im);
+    }
   }
 }
 
@@ -337,14 +339,23 @@ __global__ __launch_bounds__(kThreads) void k_mmode_weight(const float* __restri
   __shared__ double ws[kWRows];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * kWRows;
+  const bool vec = (nra & 3) == 0;  // rows 16-byte aligned: four weights per load
   for (int rr = wave; rr < kWRows; rr += kThreads / 64) {
     const int64_t r = r0 + rr;
     double acc = 0.0;
     if (r < nrow) {
       const float* row = w + r * (int64_t)nra;
-      for (int k = lane; k < nra; k += 64) {
-        const float x = row[k];
-        acc += (x != 0.f) ? 1.0 / (double)x : 0.0;
+      if (vec) {
+        for (int k = lane; k < (nra >> 2); k += 64) {
+          const float4 x = reinterpret_cast<const float4*>(row)[k];
+          acc += ((x.x != 0.f) ? 1.0 / (double)x.x : 0.0) + ((x.y != 0.f) ? 1.0 / (double)x.y : 0.0);
+          acc += ((x.z != 0.f) ? 1.0 / (double)x.z : 0.0) + ((x.w != 0.f) ? 1.0 / (double)x.w : 0.0);
+        }
+      } else {
+        for (int k = lane; k < nra; k += 64) {
+          const float x = row[k];
+          acc += (x != 0.f) ? 1.0 / (double)x : 0.0;
+        }
       }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -352,6 +363,17 @@ __global__ __launch_bounds__(kThreads) void k_mmode_weight(const float* __restri
   }
   __syncthreads();
   const int nslot = (mmax + 1) * 2;
+  if ((nrow & 1) == 0) {  // slots 16-byte aligned: two rows per store
+    for (int idx = threadIdx.x; idx < nslot * (kWRows / 2); idx += kThreads) {
+      const int rr = 2 * (idx % (kWRows / 2)), ms = idx / (kWRows / 2);
+      if (r0 + rr >= nrow) continue;
+      const double sc = wscale ? wscale[ms >> 1] : 1.0;
+      double* dst = &out[(int64_t)ms * nrow + r0 + rr];
+      __builtin_nontemporal_store(ws[rr] * sc, dst);  // written once, read by a later kernel
+      __builtin_nontemporal_store(ws[rr + 1] * sc, dst + 1);
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < nslot * kWRows; idx += kThreads) {
     const int rr = idx % kWRows, ms = idx / kWRows;
     if (r0 + rr >= nrow) continue;
