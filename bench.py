@@ -396,8 +396,9 @@ def main_dense(args, cpu):
     ctx = Context.get()
     cfg = wl.CONFIGS[args.config]
     kind = args.maker
-    if os.environ.get("DMM_ML_REDUCE"):  # (A/B switch of the eigen path's reduction: see include/draco_amd.h)
-        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", int(os.environ["DMM_ML_REDUCE"])))
+    for opt in ("ml_reduce", "gram_stage"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
+        if os.environ.get("DMM_" + opt.upper()):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt.encode(), int(os.environ["DMM_" + opt.upper()])))
     tiles = args.tiles or "screen"
     nfreq_cfg, nra, lmax, nside = cfg["nfreq"], cfg["nra"], cfg["lmax"], cfg["nside"]
     nfreq = args.freqs if args.freqs > 0 else nfreq_cfg

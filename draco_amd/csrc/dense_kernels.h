@@ -37,6 +37,7 @@ struct DenseParams {
   // gram sources
   const void* B;
   int b_c128, full_layout;
+  int gram_dma;            // 1: the beam Gram product stages its operands by LDS-DMA (k_gram_dma), where the tile layout allows it
   int npairs, npol, lmax, nfreq;
   const double2* mvis;
   const double* mweight;
@@ -338,6 +339,149 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
           *dst = make_double2(re, im);
         }
       }
+}
+
+// ---- the beam Gram product with operands DMA'd into LDS (packed complex128 tiles): the A/B form, option "gram_stage" = 1
+// Same tiling and epilogue as k_nt<MODE_GRAM>; what changes is how a chunk of complex columns gets into LDS:
+// `global_load_lds_dwordx4` -- no staging registers, no conversion or store pass on the vector ALU, 115 registers
+// instead of 151: four blocks per CU.  The DMA writes a wave's 64 x 16 bytes contiguously, so the swizzle is put on the
+// SOURCE address: a piece is 8 rows x 128 bytes, complex (row, kc) of the chunk lives at row * 8 + (kc ^ ((row >> 1) & 7))
+// -- the 16 rows a lane group reads for one MFMA operand then cover all 64 banks (SQ_LDS_BANK_CONFLICT = 0).  A lane
+// reads a whole complex value (ds_read_b128) and feeds its two halves to two MFMA steps: k-slot lk of a step is column
+// 4 j + lk of the chunk, real parts in one step, imaginary parts in the next.  The prior (or, with none, the mask of the
+// last partial chunk, whose out-of-range columns are read from column K - 1) multiplies the X operand after the LDS
+// read.  Two buffers of 8 columns, ONE barrier per chunk: behind it this chunk's DMAs have landed and nobody reads the
+// other buffer any more, so the next chunk's DMAs fly under this chunk's MFMAs.
+// Measured (cfg 3, structured tiles, 4 x 1296 telescope-side tiles per launch, tools/prof_ml.sh with MAKER=wiener):
+// 71.3 ms per launch against 68.7 for k_nt<MODE_GRAM> -- 0.75 against 0.78 of the FP64 MFMA peak; the single-buffer form
+// with 16-column chunks the same, k_nt without its register prefetch at four waves per SIMD 69.4.  The staging is not
+// what holds the kernel: matrix pipe busy 0.82-0.86 of the cycles at 2.33 GHz whatever feeds the LDS.
+constexpr int GK = 8;  // complex columns per chunk and buffer
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_gram_dma(DenseParams p) {
+  __shared__ __align__(16) double2 xs[2][TB * GK];
+  __shared__ __align__(16) double2 ys[2][TB * GK];
+  const int mat = blockIdx.y;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  const int tt = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= tt) ++bi;
+  while (bi * (bi + 1) / 2 > tt) --bi;
+  const int bj = tt - bi * (bi + 1) / 2;
+  const int I0 = bi * TB, J0 = bj * TB;
+  const int K = p.npol * (p.lmax + 1 - tile.m);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int quad = (wave + blockIdx.x + blockIdx.y) & 3;  // (see k_nt)
+  const int wr = quad >> 1, wc = quad & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const bool dead = bi == bj && wc > wr;
+  v4d cre[2][2], cim[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // loader: piece j of this wave = rows 16 wave + 8 j .. + 7 of both operands (8 rows x 128 bytes); lane -> (row, slot),
+  // column slot ^ ((row >> 1) & 7)
+  const double2* base = reinterpret_cast<const double2*>(p.B) + tile.b_off;
+  int xrow[2], yrow[2], kc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rl = 16 * wave + 8 * j + (lane >> 3);
+    kc[j] = (lane & 7) ^ ((rl >> 1) & 7);
+    xrow[j] = min(I0 + rl, p.N - 1) * K;
+    yrow[j] = min(J0 + rl, p.N - 1) * K;
+  }
+  const double* sk = p.Sk ? p.Sk + (int64_t)tile.m * p.sk_pitch : nullptr;
+  double s[2], sn[2];
+  auto issue = [&](int k0, int buf) {  // DMAs of the chunk at k0 into buffer buf, and its prior values
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = min(k0 + kc[j], K - 1);
+      glds16(base + xrow[j] + k, &xs[buf][64 * (2 * wave + j)]);
+      glds16(base + yrow[j] + k, &ys[buf][64 * (2 * wave + j)]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + 4 * j + lk;
+      sn[j] = sk ? sk[k] : (k < K ? 1.0 : 0.0);  // (the table is zero beyond K)
+    }
+  };
+  issue(0, 0);
+  const int sw = (lr >> 1) & 7;  // (rows of an MFMA operand: 32 w + 16 t + lr, so (row >> 1) & 7 = lr >> 1)
+  for (int k0 = 0, buf = 0; k0 < K; k0 += GK, buf ^= 1) {
+    // one barrier per chunk: behind it this chunk's DMAs have landed (every wave waited for its own first) and nobody
+    // reads the other buffer any more -- the next chunk's DMAs go there and fly under this chunk's MFMAs
+    __syncthreads();
+    s[0] = sn[0], s[1] = sn[1];
+    if (k0 + GK < K) issue(k0 + GK, buf ^ 1);
+    if (dead) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      double2 a[2], b[2];
+      double nbi[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = xs[buf][(32 * wr + 16 * t + lr) * GK + ((4 * j + lk) ^ sw)];
+        b[t] = ys[buf][(32 * wc + 16 * t + lr) * GK + ((4 * j + lk) ^ sw)];
+        a[t].x *= s[j], a[t].y *= s[j];
+        nbi[t] = -b[t].y;
+      }
+      // x conj(y): Re = xr yr + xi yi, Im = xi yr - xr yi (two rounds over the eight accumulators: a chain's two MFMAs eight apart)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti].x, b[tj].x, cre[ti][tj], 0, 0, 0);
+          cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti].y, b[tj].x, cim[ti][tj], 0, 0, 0);
+        }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti].y, b[tj].y, cre[ti][tj], 0, 0, 0);
+          cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti].x, nbi[tj], cim[ti][tj], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  if (dead) return;
+  // epilogue (as k_nt<MODE_GRAM>): lane holds rows (lk + 4*reg), column lr of each 16x16 tile
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = I0 + 32 * wr + 16 * ti + lk + 4 * reg;
+        const int j = J0 + 32 * wc + 16 * tj + lr;
+        double re = cre[ti][tj][reg], im = cim[ti][tj][reg];
+        double di = 0.0, dj = 0.0;
+        if (i < p.N) {
+          const int sg = i >= p.npairs, pp = i - sg * p.npairs;
+          di = sqrt(p.mweight[(((int64_t)tile.m * 2 + sg) * p.nfreq + tile.f) * p.npairs + pp]);
+        }
+        if (j < p.N) {
+          const int sg = j >= p.npairs, pp = j - sg * p.npairs;
+          dj = sqrt(p.mweight[(((int64_t)tile.m * 2 + sg) * p.nfreq + tile.f) * p.npairs + pp]);
+        }
+        re *= di * dj;
+        im *= di * dj;
+        if (i >= p.N || j >= p.N) re = im = 0.0;  // (clamped rows carry copies of the last row, not zeros)
+        if (i == j) {
+          im = 0.0;
+          if (p.add_identity) re += 1.0;
+        }
+        p.A[((int64_t)mat * p.Np + i) * p.Np + j] = make_double2(re, im);
+      }
+}
+// the beam Gram launch: the DMA form where the tile layout allows it
+inline void launch_gram(const DenseParams& p, int nmat, hipStream_t st) {
+  const bool dma = p.gram_dma && p.b_c128 && !p.full_layout && (int64_t)p.N * p.npol * (p.lmax + 1) < 0x7fffffff;
+  if (dma) hipLaunchKernelGGL(k_gram_dma, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, st, p);
 }
 
 // 1/x and 1/sqrt(x) in double from the hardware seeds (~2^-26) and one cubically convergent correction (full precision

@@ -50,6 +50,7 @@ struct dmm_ctx {
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
   int64_t ml_tiles_ql_failed = 0;          // ... of the latter: QL gave up, the tile was redone by the Jacobi solver
   int opt_ringmap_variant = 0;             // 1: always the three-kernel form of the ring-map maker (A/B, tests)
+  int opt_gram_stage = 0;                  // operand staging of the beam Gram kernel: 0 = through registers (k_nt), 1 = LDS-DMA (k_gram_dma, complex128 packed tiles)
   int opt_ml_reduce = 0;                   // tridiagonal reduction of the ML eigen path: 0 = two-stage (dense -> band -> tridiagonal) where the band fits the LDS, 1 = one-stage Householder
   int opt_profile = 0;                     // 1: dmm_prof_scope records event pairs (bench.py's live kernel timing)
   std::vector<dmm_prof_span> prof_open;    // spans whose events have not been read yet

@@ -408,6 +408,7 @@ DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, cons
   p.B = B;
   p.b_c128 = pl->b_dtype == DMM_C128;
   p.full_layout = pl->b_layout == DMM_B_FULL;
+  p.gram_dma = pl->ctx->opt_gram_stage == 1;
   p.npairs = pl->npairs;
   p.npol = pl->npol;
   p.lmax = pl->lmax;
@@ -563,7 +564,7 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
       p.Sk = Sk;
       p.sk_pitch = L.sk_pitch;
       p.add_identity = 1;
-      hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+      launch_gram(p, nmat, ctx->stream);
     }
     {
       dmm_prof_scope prof(ctx, DMM_PROF_CHOL, ctx->stream);
@@ -739,7 +740,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
       } else {
-        hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
+        launch_gram(p, nmat, ctx->stream);
       }
       if (mirror) hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, ctx->stream, p);
     };
@@ -994,7 +995,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, S1, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
       } else {
-        hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+        launch_gram(p, nmat, S1);
       }
       // (the lower-triangle band reduction reads the upper triangle only inside the diagonal tiles, which the Gram
       // kernel writes in full)

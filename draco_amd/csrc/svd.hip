@@ -284,6 +284,7 @@ int dmm_mmode_svd(dmm_ctx* ctx, void* mvis, const double* mweight, int n_m, int 
     hipLaunchKernelGGL(k_svd_gather, egrid, dim3(kThreads), 0, ctx->stream, sp);
 
     DenseParams p;
+    p.gram_dma = 0;
     memset(&p, 0, sizeof(p));
     p.tiles = tiles_d;
     p.nmat = nmat;

@@ -77,8 +77,10 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * up on every other matrix, which exercises the Jacobi fallback),
  * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies),
  * "ml_reduce" (tridiagonal reduction of the eigen path: 0 = two-stage, dense -> band of half-width 8 on the matrix
- * cores -> tridiagonal by bulge chasing in LDS, for orders whose band fits the LDS, one-stage Householder otherwise;
- * 1 = one-stage always),
+ * cores over the lower triangle -> tridiagonal by bulge chasing in LDS, for orders whose band fits the LDS, one-stage
+ * Householder otherwise; 1 = one-stage always; 2 = two-stage with sweeps over both triangles, the first form),
+ * "gram_stage" (operand staging of the beam Gram kernel of the Wiener / ML solves: 0 = through registers, 1 = LDS-DMA
+ * `global_load_lds_dwordx4` into a source-swizzled image, complex128 packed tiles only: the A/B of DESIGN 5.3),
  * "ml_workspace_mib" / "wiener_workspace_mib" (size dmm_ml_workspace_bytes / dmm_wiener_workspace_bytes report,
  * i.e. the matrices solved per sub-batch; 0 = 20 GiB / 6 GiB), "profile" (1: time the kernel classes of the dense
  * solvers with HIP events on their launch streams, sums cleared; 0: off) */

@@ -91,6 +91,41 @@ def test_alm_vs_oracle(kind, tol, nfreq, lmax, ncyl, nfeed, b_dtype):
     assert _rel(alm, ref) < tol
 
 
+@pytest.mark.parametrize("kind,tol", [("wiener", 1e-10), ("ml", 1e-8)])
+def test_gram_operands_by_lds_dma_vs_oracle(kind, tol):
+    """The A/B form of the beam Gram kernel (`gram_stage` = 1: operands DMA'd into a source-swizzled LDS image, the
+    prior applied after the LDS read, the last partial chunk masked) against the oracle: ntel = 182 (three row tiles,
+    padding), K = 4 (lmax + 1 - m) from 164 down to 4, so every m has a partial last chunk of a different length."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker, WienerMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    nfreq, lmax = 2, 40
+    tel = _tel(nfreq, lmax, 2, 4)
+    bt = SyntheticProvider(tel, seed=540)
+    rng = np.random.default_rng(41)
+    mv = rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs)) + 1j * rng.standard_normal((lmax + 1, 2, nfreq, tel.npairs))
+    mw = rng.uniform(0.5, 1.5, mv.shape) * 30.0
+    mw[rng.uniform(size=mw.shape) < 0.1] = 0.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    ctx = Context.get()
+    _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"gram_stage", 1))
+    try:
+        task = (WienerMapMaker(prior_amp=2.5, prior_tilt=1.25) if kind == "wiener" else MaximumLikelihoodMapMaker())
+        task.setup(bt)
+        alm = task.alm_square(task.make_alm(mm))
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"gram_stage", 0))
+    beam = lambda m, f: osyn.beam_tile(540, m, f, tel.npairs, 4, lmax)  # noqa: E731
+    kw = dict(prior_amp=2.5, prior_tilt=1.25) if kind == "wiener" else {}
+    ref = omm.solve_alm(kind, beam, mv, mw, lmax, tel.mmax, list(range(nfreq)), **kw)
+    assert _rel(alm, ref) < tol
+
+
 def _counter(ctx, name):
     import ctypes as C
 

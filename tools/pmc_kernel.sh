@@ -6,7 +6,7 @@ KERN=$1; OUT=$2; shift 2
 mkdir -p "$REPO/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_ml
-timeout -k 10 500 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_ml -o ml -- python3 "$REPO/bench.py" --maker ml --steps 1 --warmup 0 --freqs 4 --no-cpu-baseline > /tmp/pmc.log 2>&1 || { tail -5 /tmp/pmc.log; exit 1; }
+timeout -k 10 500 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_ml -o ml -- python3 "$REPO/bench.py" --maker ${MAKER:-ml} --steps 1 --warmup 0 --freqs 4 --no-cpu-baseline > /tmp/pmc.log 2>&1 || { tail -5 /tmp/pmc.log; exit 1; }
 cd "$REPO"
 python - "$KERN" $(find /tmp/pmc_ml -name '*counter_collection.csv' | head -1) > "gpurun_out/$OUT" <<'PY'
 import csv, sys, collections
