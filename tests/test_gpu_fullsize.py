@@ -488,3 +488,55 @@ def test_cfg3_ml_two_stage_reduction_against_the_one_stage_reduction():
     assert np.all(np.isfinite(out[0]))
     assert _rel(out[0], out[1]) < 1e-9
     _check_rows_against_oracle_svd(out[0], 35, mv, mw, 0, 0, (1, 160, 323, 324, 390, 449, 497, 511), 1e-8)
+
+
+def test_ml_two_stage_reduction_at_the_largest_order_the_lds_takes():
+    """Orders 832 (the largest whose band plus the chase kernel's scratch fits the 160 KB of LDS) down to 64 in one
+    pass: ntel = 820 on the telescope side (m <= 6), every sky-side order below it.  The three reductions against each
+    other -- lower-triangle sweeps (default), sweeps over both triangles ("ml_reduce" = 2), one-stage ("ml_reduce" = 1)
+    -- and sampled rows against the oracle's SVD."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider, TransitTelescope
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    lmax = 210
+    tel = TransitTelescope(osyn.frequencies(1), lmax=lmax, ncyl=1, nfeed_cyl=3, npairs=410)
+    assert 2 * tel.npairs == 820
+    bt = SyntheticProvider(tel, seed=36)
+    gen = torch.Generator(device=ctx.device).manual_seed(10)
+    shape = (lmax + 1, 2, 1, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) * 30.0 + 5.0
+    mw[torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) < 0.02] = 0.0
+    eng = SolveEngine(bt, ctx, _lib.DMM_C128, _lib.DMM_B_PACKED)
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    out, spans = {}, {}
+    try:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
+        for red in (0, 2, 1):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", red))
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
+            out[red] = eng.solve("ml", mv, mw, [0], lmax).cpu().numpy()
+            spans[red] = (counter(b"prof_band_n"), counter(b"prof_chase_n"), counter(b"prof_tridiag_n"))
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", 0))
+    for red in (0, 2):
+        assert spans[red][0] > 0 and spans[red][1] > 0 and spans[red][2] == 0, spans  # two-stage only
+    assert spans[1][0] == 0 and spans[1][2] > 0, spans  # one-stage only
+    assert np.all(np.isfinite(out[0]))
+    assert _rel(out[0], out[1]) < 1e-9
+    assert _rel(out[2], out[1]) < 1e-9
+    _check_rows_against_oracle_svd(out[0], 36, mv, mw, 0, 0, (0, 6, 7, 100, 195, 209, 210), 1e-8)
