@@ -98,8 +98,11 @@ int64_t sb_log_cap(int64_t log_stride, int n, int runs) {
 void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   const int n = tp.d.Np, K = sb_npanel(n);
   hipLaunchKernelGGL(k_sb_zero, dim3(12, nmat), dim3(kThreads), 0, st, tp);
-  auto panel = [&]() {
-    if (n <= 3 * kThreads) hipLaunchKernelGGL(k_sb_panel<3>, dim3(nmat), dim3(kThreads), 0, st, tp);
+  auto panel = [&]() {  // rows per thread by what is left of the matrix: the later panels take fewer registers (more blocks per CU)
+    const int rows = (n - kSbB * tp.j + kThreads - 1) / kThreads;
+    if (rows <= 1) hipLaunchKernelGGL(k_sb_panel<1>, dim3(nmat), dim3(kThreads), 0, st, tp);
+    else if (rows == 2) hipLaunchKernelGGL(k_sb_panel<2>, dim3(nmat), dim3(kThreads), 0, st, tp);
+    else if (rows == 3) hipLaunchKernelGGL(k_sb_panel<3>, dim3(nmat), dim3(kThreads), 0, st, tp);
     else hipLaunchKernelGGL(k_sb_panel<4>, dim3(nmat), dim3(kThreads), 0, st, tp);
   };
   for (int k = 0; k < K; ++k) {
