@@ -494,7 +494,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
   __shared__ double sT[4][2][16 * 17]; // per wave: the tile transposed, real and imaginary plane; at the end the reduction buffer
   const DenseParams& p = tp.d;
   const int n = p.Np, k = tp.j;
-  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
+  // grid (matrices, column blocks): the blocks with the tallest strips (column block 0 of every matrix) are dispatched
+  // first, the launch ends on the shortest ones
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  const int bx = blockIdx.y;
   double2* A = p.A + (int64_t)mat * n * n;
   const double2* Vold = sb_V(tp, mat, k + 1);
   const double2* Vnew = sb_V(tp, mat, k);
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
   const int org = (kSbB * (k + 1)) & ~15;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const int cb0 = org + 64 * blockIdx.x;     // first column of the block (< n by the grid)
+  const int cb0 = org + 64 * bx;     // first column of the block (< n by the grid)
   const int ntile = min(4, (n - cb0) / 16);  // its column tiles
   for (int idx = threadIdx.x; idx < 64 * kSbB; idx += kThreads) {
     const int col = idx >> 3, q = idx & 7;
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
   const int vq = lr & 7;
   double* const tre = &sT[wave][0][0];
   double* const tim = &sT[wave][1][0];
-  double* const Zp = sb_Zp(tp, mat) + (int64_t)blockIdx.x * n * 16;
+  double* const Zp = sb_Zp(tp, mat) + (int64_t)bx * n * 16;
   v4d zc[4], mp = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) zc[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     }
     __syncthreads();
   }
-  double* Mw = sb_Mp(tp, mat) + (int64_t)(4 * blockIdx.x + wave) * 256;
+  double* Mw = sb_Mp(tp, mat) + (int64_t)(4 * bx + wave) * 256;
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) Mw[(lk + 4 * reg) * 16 + lr] = mp[reg];
 }

@@ -109,7 +109,7 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
     tp.j = k;
     panel();
     const int org = (kSbB * (k + 1)) & ~15;
-    if (tp.sb_lower) hipLaunchKernelGGL(k_sb_sweep_lo, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
+    if (tp.sb_lower) hipLaunchKernelGGL(k_sb_sweep_lo, dim3(nmat, (n - org + 63) / 64), dim3(kThreads), 0, st, tp);
     else hipLaunchKernelGGL(k_sb_sweep, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
   }
   tp.j = K;
