@@ -396,7 +396,7 @@ def main_dense(args, cpu):
     ctx = Context.get()
     cfg = wl.CONFIGS[args.config]
     kind = args.maker
-    for opt in ("ml_reduce", "gram_stage"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
+    for opt in ("ml_reduce", "gram_stage", "wiener_overlap"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
         if os.environ.get("DMM_" + opt.upper()):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt.encode(), int(os.environ["DMM_" + opt.upper()])))
     tiles = args.tiles or "screen"
@@ -456,7 +456,7 @@ def main_dense(args, cpu):
     elapsed = time.perf_counter() - t0
     mem1 = torch.cuda.memory_stats()
     prof = {k: {"ms": counter(f"prof_{k}_us".encode()) / 1e3 / args.steps, "spans": counter(f"prof_{k}_n".encode()) // max(args.steps, 1)}
-            for k in ("gram", "chol", "tridiag", "band", "chase", "ql", "backproj")}
+            for k in ("gram", "chol", "tridiag", "band", "chase", "ql", "backproj", "solve")}
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
     c1 = {k: counter(k) for k in c0}
     assert eng.fills == fills_before or args.warmup == 0, "B was generated inside the timed region"
@@ -497,6 +497,19 @@ def main_dense(args, cpu):
                               "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_day": ms,
                               "note": "bytes = n^3/6 * 20 B per decomposed tile (a fraction is only meaningful when every tile went this way)"})
+    gram_note = "useful flops (one Hermitian half-product of the smaller side per tile: 8 k^2 K / 2) / HIP-event time of every Gram launch of the timed day on its launch stream ('profile' option of the library); tiles whose certificate is rejected form their Gram matrix twice, so the fraction is a lower bound then"
+    roofline = {"kernel": "k_nt<GRAM/GRAMX> (Hermitian products D B B^H D / B^H N B on v_mfma_f64_16x16x4_f64)",
+                "bound": "mfma", "achieved": gram_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": gram_tf / 78.6 if gram_tf else None, "traffic": None,
+                "flops_per_day": gram_fl * nfreq_cfg, "ms_per_day_timed": prof["gram"]["ms"], "note": gram_note}
+    if kind == "wiener" and prof["solve"]["ms"] > 0:
+        # dmm_wiener_run keeps two batches in flight on two streams (one's factorisation beside the other's Gram products):
+        # the class sums overlap in time, the span of the whole pass is the time the matrix cores were asked for
+        tf = (gram_fl + chol_fl) * nfreq / (prof["solve"]["ms"] * 1e-3) / 1e12
+        secondary.append(dict(roofline, note=gram_note + "; HERE the Gram launches of one stream share the chip with the other stream's factorisation, so this busy-time figure is not the kernel alone (alone: profiles/r03_gram_stage_ab.txt, 0.78)"))
+        roofline = {"kernel": "dmm_wiener_run: Gram products + blocked Cholesky, all of it k_nt on v_mfma_f64_16x16x4_f64 (two batches in flight on two streams)",
+                    "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
+                    "flops_per_day": (gram_fl + chol_fl) * nfreq_cfg, "ms_per_day_timed": prof["solve"]["ms"],
+                    "note": "useful flops (Hermitian half of the smaller Gram matrix 8 k^2 K / 2 + factorisation (8/3) k^3 per tile) / HIP-event span of every dmm_wiener_run of the timed day on the caller's stream"}
     out = {
         "metric": f"m-modes/sec through MModeTransform+{cls.__name__} (128-feed, 256-freq)",
         "value": value, "unit": "m-modes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -511,13 +524,7 @@ def main_dense(args, cpu):
             "ms_per_solve": day_s * 1e3 / ((lmax + 1) * nfreq),
             "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "ql_failed": c1[b"ml_tiles_ql_failed"] - c0[b"ml_tiles_ql_failed"]} if kind == "ml" else None,
         },
-        "roofline": {
-            "kernel": "k_nt<GRAM/GRAMX> (Hermitian products D B B^H D / B^H N B on v_mfma_f64_16x16x4_f64)",
-            "bound": "mfma", "achieved": gram_tf, "peak": 78.6, "unit": "TFLOP/s",
-            "frac": gram_tf / 78.6 if gram_tf else None, "traffic": None,
-            "flops_per_day": gram_fl * nfreq_cfg, "ms_per_day_timed": prof["gram"]["ms"],
-            "note": "useful flops (one Hermitian half-product of the smaller side per tile: 8 k^2 K / 2) / HIP-event time of every Gram launch of the timed day on its launch stream ('profile' option of the library); tiles whose certificate is rejected form their Gram matrix twice, so the fraction is a lower bound then",
-        },
+        "roofline": roofline,
         "roofline_secondary": secondary,
         "kernel_classes_ms_per_day_timed": prof,
         "allocator": {"num_alloc_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),

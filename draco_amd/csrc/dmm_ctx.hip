@@ -14,7 +14,7 @@ int dmm_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-static const char* const kProfNames[DMM_PROF_NSLOT] = {"gram", "chol", "tridiag", "ql", "backproj", "band", "chase"};
+static const char* const kProfNames[DMM_PROF_NSLOT] = {"gram", "chol", "tridiag", "ql", "backproj", "band", "chase", "solve"};
 
 // read every finished span into the per-class sums (waits for spans still running)
 static void prof_collect(dmm_ctx* c) {
@@ -132,6 +132,7 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ringmap_variant")) c->opt_ringmap_variant = (int)value;
   else if (!strcmp(name, "ml_reduce")) c->opt_ml_reduce = (int)value;
   else if (!strcmp(name, "gram_stage")) c->opt_gram_stage = (int)value;
+  else if (!strcmp(name, "wiener_overlap")) c->opt_wiener_overlap = (int)value;
   else if (!strcmp(name, "ml_workspace_mib")) c->opt_ml_ws_mib = value > 0 ? value : 0;
   else if (!strcmp(name, "wiener_workspace_mib")) c->opt_wiener_ws_mib = value > 0 ? value : 0;
   else if (!strcmp(name, "profile")) {  // (re)start the per-class kernel timing: sums cleared

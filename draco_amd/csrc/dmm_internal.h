@@ -18,7 +18,7 @@ struct dmm_fft_tables {          // per transform length, built on first use
 
 // Kernel classes of the dense solvers that bench.py times live (HIP events on the stream a class is launched on;
 // "profile" option of dmm_ctx_set_option, read back through dmm_ctx_get_counter("prof_<class>_us" / "prof_<class>_n")).
-enum dmm_prof_slot { DMM_PROF_GRAM = 0, DMM_PROF_CHOL, DMM_PROF_TRIDIAG, DMM_PROF_QL, DMM_PROF_BACKPROJ, DMM_PROF_BAND, DMM_PROF_CHASE, DMM_PROF_NSLOT };
+enum dmm_prof_slot { DMM_PROF_GRAM = 0, DMM_PROF_CHOL, DMM_PROF_TRIDIAG, DMM_PROF_QL, DMM_PROF_BACKPROJ, DMM_PROF_BAND, DMM_PROF_CHASE, DMM_PROF_SOLVE, DMM_PROF_NSLOT };
 struct dmm_prof_span {
   hipEvent_t a, b;
   int slot;
@@ -50,12 +50,13 @@ struct dmm_ctx {
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
   int64_t ml_tiles_ql_failed = 0;          // ... of the latter: QL gave up, the tile was redone by the Jacobi solver
   int opt_ringmap_variant = 0;             // 1: always the three-kernel form of the ring-map maker (A/B, tests)
+  int opt_wiener_overlap = 1;              // 1: the batches of dmm_wiener_run alternate between two streams (half the workspace each); 0: one stream
   int opt_gram_stage = 0;                  // operand staging of the beam Gram kernel: 0 = through registers (k_nt), 1 = LDS-DMA (k_gram_dma, complex128 packed tiles)
   int opt_ml_reduce = 0;                   // tridiagonal reduction of the ML eigen path: 0 = two-stage (dense -> band -> tridiagonal) where the band fits the LDS, 1 = one-stage Householder
   int opt_profile = 0;                     // 1: dmm_prof_scope records event pairs (bench.py's live kernel timing)
   std::vector<dmm_prof_span> prof_open;    // spans whose events have not been read yet
-  double prof_us[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0, 0};
-  int64_t prof_n[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0, 0};
+  double prof_us[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t prof_n[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t ml_early_chunks = 0;             // reject chunks decomposed on the end-of-workspace slots under the direct batches
   unsigned long long* ticket = nullptr;    // ring of task counters for the dirty kernel's dynamic hand-out
   unsigned ticket_seq = 0;

@@ -530,11 +530,43 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   const size_t diag_lds = (size_t)TB * (TB + 1) * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
 
-  std::vector<dmm_tile> tiles_c;
-  std::vector<int32_t> work_c;
+  // The batches go down TWO streams in turn, half the workspace each: the factorisation of one batch -- its diagonal
+  // blocks and the triangular solves are latency bound, one block per matrix -- runs beside the Gram products of the
+  // next.  ("wiener_overlap" = 0: one stream, whole workspace, the A/B.)
+  size_t ntiles = tel_list.size();
+  for (auto& kv : sky_lists) ntiles += kv.second.size();
+  const bool two = ctx->opt_wiener_overlap && cap >= 2 && ntiles > (size_t)cap / 2;
+  const int caph = two ? cap / 2 : cap;
+  dmm_aux_scope aux_guard(ctx);  // the second stream is drained on every return path
+  struct StreamRestore {
+    dmm_ctx* c;
+    hipStream_t s;
+    ~StreamRestore() { c->stream = s; }
+  } stream_guard{ctx, ctx->stream};
+  hipStream_t st[2] = {ctx->stream, ctx->stream};
+  dmm_prof_scope prof_all(ctx, DMM_PROF_SOLVE, st[0]);  // the whole pass on the caller's stream (both halves are joined before it ends)
+  if (two) {
+    if (!ctx->aux_stream) DMM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux_ev[0]) DMM_HIP(hipEventCreateWithFlags(&ctx->aux_ev[0], hipEventDisableTiming));
+    st[1] = ctx->aux_stream;
+    DMM_HIP(hipEventRecord(ctx->aux_ev[0], st[0]));  // the prior tables and the sky-side right-hand sides are ready
+    DMM_HIP(hipStreamWaitEvent(st[1], ctx->aux_ev[0], 0));
+  }
+  std::vector<dmm_tile> tiles_c[2];
+  std::vector<int32_t> work_c[2];
+  int batch_no = 0;
   auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky) -> int {
+    const int h = two ? (batch_no++ & 1) : 0;
+    hipStream_t S = st[h];
+    const size_t off = (size_t)h * caph;
+    // the half's previous batch is done: its host vectors and device lists are free again
+    DMM_HIP(hipStreamSynchronize(S));
     DenseParams p = base;
-    p.tiles = tiles_d;
+    dmm_tile* const tiles_h = tiles_d + off;
+    int32_t* const work_h = work_d + off + h;  // (nmat + 1 entries per half: disjoint ranges)
+    p.A = base.A + off * L.Np * L.Np;
+    p.wbuf = base.wbuf + off * L.N;
+    p.tiles = tiles_h;
     p.tile0 = 0;
     p.nmat = nmat;
     p.sky = sky ? 1 : 0;
@@ -542,61 +574,67 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
     p.Np = (p.N + TB - 1) / TB * TB;
     p.T = p.Np / TB;
     p.alm = (double2*)alm;
-    p.Linv = Linvbuf;
-    tiles_c.resize(nmat);
-    work_c.assign(nmat + 1, 0);
+    p.Linv = Linvbuf + off * (L.Np / 64) * TB * TB;
+    double2* const Xh = Xbuf + off * L.Np * L.Np;
+    std::vector<dmm_tile>& tc = tiles_c[h];
+    std::vector<int32_t>& wc = work_c[h];
+    tc.resize(nmat);
+    wc.assign(nmat + 1, 0);
     for (int i = 0; i < nmat; ++i) {
-      tiles_c[i] = pl->tiles_h[list[i0 + i]];
-      const int ncol = pl->npol * (pl->lmax + 1 - tiles_c[i].m);
-      work_c[i + 1] = work_c[i] + (ncol + pl->cols_per_block - 1) / pl->cols_per_block;
+      tc[i] = pl->tiles_h[list[i0 + i]];
+      const int ncol = pl->npol * (pl->lmax + 1 - tc[i].m);
+      wc[i + 1] = wc[i] + (ncol + pl->cols_per_block - 1) / pl->cols_per_block;
     }
-    DMM_HIP(hipMemcpyAsync(tiles_d, tiles_c.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, ctx->stream));
-    DMM_HIP(hipMemcpyAsync(work_d, work_c.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    DMM_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors are reused by the next batch
+    DMM_HIP(hipMemcpyAsync(tiles_h, tc.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, S));
+    DMM_HIP(hipMemcpyAsync(work_h, wc.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, S));
     const int T = p.T;
     if (sky) {
-      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, ctx->stream);
+      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, S);
       p.ldx = ntel;
-      p.X = Xbuf;
-      hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Xbuf);
-      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
-      hipLaunchKernelGGL(k_add_prior_diag, dim3((p.Np + 255) / 256, nmat), dim3(256), 0, ctx->stream, p, (const double*)Sl);
+      p.X = Xh;
+      hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, S, p, Xh);
+      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S, p);
+      hipLaunchKernelGGL(k_add_prior_diag, dim3((p.Np + 255) / 256, nmat), dim3(256), 0, S, p, (const double*)Sl);
     } else {
-      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, ctx->stream);
+      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, S);
       p.Sl = Sl;
       p.Sk = Sk;
       p.sk_pitch = L.sk_pitch;
       p.add_identity = 1;
-      launch_gram(p, nmat, ctx->stream);
+      launch_gram(p, nmat, S);
     }
     {
-      dmm_prof_scope prof(ctx, DMM_PROF_CHOL, ctx->stream);
+      dmm_prof_scope prof(ctx, DMM_PROF_CHOL, S);
       for (int J = 0; J < T; ++J) {
         p.J = J;
-        if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(T - J, nmat), dim3(kThreads), 0, ctx->stream, p);
-        hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, ctx->stream, p);
-        if (J < T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(T - J - 1, nmat), dim3(kThreads), 0, ctx->stream, p);
+        if (J > 0) hipLaunchKernelGGL(k_nt<MODE_UPDATE>, dim3(T - J, nmat), dim3(kThreads), 0, S, p);
+        hipLaunchKernelGGL(k_chol_diag, dim3(nmat), dim3(kThreads), diag_lds, S, p);
+        if (J < T - 1) hipLaunchKernelGGL(k_nt<MODE_PANEL>, dim3(T - J - 1, nmat), dim3(kThreads), 0, S, p);
       }
-      hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, ctx->stream, p);  // sky: a_lm in place
+      hipLaunchKernelGGL(k_chol_solve, dim3(nmat), dim3(kThreads), solve_lds, S, p);  // sky: a_lm in place
     }
     DMM_HIP(hipGetLastError());
     if (!sky) {
-      dmm_prof_scope prof(ctx, DMM_PROF_BACKPROJ, ctx->stream);
-      int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, Sl, tiles_d, work_d, nmat, work_c[nmat], alm);
+      dmm_prof_scope prof(ctx, DMM_PROF_BACKPROJ, S);
+      ctx->stream = S;
+      const int rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, Sl, tiles_h, work_h, nmat, wc[nmat], alm);
+      ctx->stream = st[0];
       if (rc) return rc;
     }
-    DMM_HIP(hipStreamSynchronize(ctx->stream));  // tiles_d / work_d are rewritten by the next batch
     return DMM_OK;
   };
-  for (size_t i0 = 0; i0 < tel_list.size(); i0 += cap) {
-    int rc = run_batch(tel_list, i0, (int)std::min<size_t>(cap, tel_list.size() - i0), false, 0);
+  for (size_t i0 = 0; i0 < tel_list.size(); i0 += caph) {
+    int rc = run_batch(tel_list, i0, (int)std::min<size_t>(caph, tel_list.size() - i0), false, 0);
     if (rc) return rc;
   }
   for (auto& kv : sky_lists)
-    for (size_t i0 = 0; i0 < kv.second.size(); i0 += cap) {
-      int rc = run_batch(kv.second, i0, (int)std::min<size_t>(cap, kv.second.size() - i0), true, kv.first);
+    for (size_t i0 = 0; i0 < kv.second.size(); i0 += caph) {
+      int rc = run_batch(kv.second, i0, (int)std::min<size_t>(caph, kv.second.size() - i0), true, kv.first);
       if (rc) return rc;
     }
+  // the caller's stream continues behind both halves (the host vectors die with this frame: wait for their copies)
+  if (two) DMM_HIP(hipStreamSynchronize(st[1]));
+  DMM_HIP(hipStreamSynchronize(st[0]));
   return DMM_OK;
 }
 

@@ -92,7 +92,8 @@ int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
  * "prof_<class>_us" / "prof_<class>_n" = summed HIP-event time (microseconds) and number of spans of a kernel class,
  * class = gram (Hermitian products B B^H / B^H N B), chol (factorisations + triangular solves), tridiag (Householder
  * reduction), band (two-stage reduction, stage 1: dense -> band), chase (stage 2: band -> tridiagonal), ql
- * (tridiagonal eigen-solve + replay), backproj (a = B^H w).  Reading a counter waits for the spans still running. */
+ * (tridiagonal eigen-solve + replay), backproj (a = B^H w), solve (dmm_wiener_run from its first launch to its last: the
+ * batches of that call alternate between two streams, so its class sums overlap in time and this span is the wall).  Reading a counter waits for the spans still running. */
 int dmm_ctx_get_counter(dmm_ctx* ctx, const char* name, int64_t* value);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
 int dmm_timer_start(dmm_ctx* ctx);
