@@ -81,6 +81,8 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * Householder otherwise; 1 = one-stage always; 2 = two-stage with sweeps over both triangles, the first form),
  * "gram_stage" (operand staging of the beam Gram kernel of the Wiener / ML solves: 0 = through registers, 1 = LDS-DMA
  * `global_load_lds_dwordx4` into a source-swizzled image, complex128 packed tiles only: the A/B of DESIGN 5.3),
+ * "wiener_overlap" (1, default: the batches of dmm_wiener_run alternate between the caller's stream and a second one,
+ * half the workspace each -- one batch's factorisation beside the other's Gram products; 0: one stream),
  * "ml_workspace_mib" / "wiener_workspace_mib" (size dmm_ml_workspace_bytes / dmm_wiener_workspace_bytes report,
  * i.e. the matrices solved per sub-batch; 0 = 20 GiB / 6 GiB), "profile" (1: time the kernel classes of the dense
  * solvers with HIP events on their launch streams, sums cleared; 0: off) */
