@@ -228,3 +228,31 @@ def test_sidereal_mmode_resample(nra_in, nra_out, window):
     ref_v, ref_w = otr.mmode_inverse_transform(mv, mw, bool(nra_in % 2), nra=nra_out, apply_integration_window=window)
     assert np.abs(out.vis[:] - ref_v).max() < 3e-6 * np.abs(ref_v).max()
     assert np.abs(out.weight[:] - ref_w).max() < 3e-6 * np.abs(ref_w).max()
+
+
+@pytest.mark.parametrize("nrow,nra,mmax,window", [(64, 1024, 512, False), (65, 1024, 100, False), (7, 1022, 300, True), (130, 1001, 500, False), (1, 4, 2, True), (33, 8, 3, False)])
+def test_weight_reduction_all_load_store_forms(nrow, nra, mmax, window):
+    """`k_mmode_weight`: rows read four weights per load when ``nra % 4 == 0`` and one at a time otherwise; the (m, +/-)
+    broadcast stored two rows per lane when ``nrow`` is even, one otherwise.  Each combination against
+    transform.py:599-602,627,638-639 in float64: ``nra^2 / sum(1 / w)`` with zeros skipped, zero for an all-zero row."""
+    import torch
+
+    from draco_amd.analysis.transform import mmode_forward
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    rng = np.random.default_rng(nrow * 131 + nra)
+    w = rng.uniform(0.5, 40.0, (nrow, nra)).astype(np.float32)
+    w[rng.uniform(size=w.shape) < 0.05] = 0.0
+    w[nrow // 2] = 0.0  # one row without any valid sample
+    vis = (rng.standard_normal((nrow, nra)) + 1j * rng.standard_normal((nrow, nra))).astype(np.complex64)
+    _, mw = mmode_forward(ctx, torch.from_numpy(vis).to(ctx.device), torch.from_numpy(w).to(ctx.device), mmax, remove_integration_window=window)
+    inv = np.where(w != 0, 1.0 / np.where(w != 0, w, 1.0).astype(np.float64), 0.0).sum(axis=1)
+    ws = np.where(inv != 0, float(nra) ** 2 / np.where(inv != 0, inv, 1.0), 0.0)
+    ref = np.broadcast_to(ws, (mmax + 1, 2, nrow)).copy()
+    if window:
+        ref *= (np.sinc(np.arange(mmax + 1) / nra) ** 2)[:, None, None]
+    out = mw.cpu().numpy()
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out, ref, rtol=1e-13, atol=0)
+    assert np.all(out[:, :, nrow // 2] == 0)
