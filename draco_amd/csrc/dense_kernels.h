@@ -152,21 +152,29 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
                                       : TB;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // quadrant of this wave, rotated from block to block: see `dead` -- the idle wave must not always sit on the same SIMD
+  // quadrant of this wave, rotated from block to block (on a diagonal tile the waves' shares differ)
   const int quad = (wave + blockIdx.x + blockIdx.y) & 3;
-  const int wr = quad >> 1, wc = quad & 1;
+  int wr = quad >> 1, wc = quad & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  // a diagonal tile is Hermitian: nobody reads its upper-right quadrant (the Cholesky kernels read the lower triangle,
-  // k_mirror rebuilds the upper one), so that wave only helps with the staging and leaves the pipe to the other blocks
-  const bool dead = bi == bj && wc > wr;
-  v4d cre[2][2], cim[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) cre[a][b] = cim[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // A diagonal tile is Hermitian: nobody reads above its diagonal 16 x 16 tiles (the Cholesky kernels read the lower
+  // triangle, k_mirror rebuilds the upper one, the band reduction wants the diagonal 16 x 16 tiles in full).  Of its
+  // sixteen 16 x 16 tiles ten are needed; the four waves take 3 + 2 + 2 + 3 of them -- the two diagonal quadrants without
+  // their upper-right tile, the lower-left quadrant one tile row each -- where a quadrant per wave would make the block
+  // wait for four.  tmask: bit 2 ti + tj = tile (ti, tj) of the wave's quadrant is computed.
+  unsigned tmask = 0xF;
+  if ((MODE == MODE_GRAM || MODE == MODE_GRAMX) && bi == bj) {
+    if (quad == 0 || quad == 3) tmask = 0xD;     // (0,0), (1,0), (1,1)
+    else if (quad == 2) tmask = 0x3;             // lower-left quadrant, its first tile row
+    else wr = 1, wc = 0, tmask = 0xC;            // ... its second tile row (the wave of the unread upper-right quadrant)
+  }
+  const bool dead = false;
+  // accumulators of the wave's four tiles (named, not an array: with the per-tile branch below an array captured by the
+  // chunk lambda ends up in scratch)
+  const v4d vz = (v4d){0.0, 0.0, 0.0, 0.0};
+  v4d c0r = vz, c0i = vz, c1r = vz, c1i = vz, c2r = vz, c2i = vz, c3r = vz, c3i = vz;
 
   double2 xr[CPT], yr[CPT];
-  auto mfma_chunk = [&]() {
+  auto mfma_chunk = [&]() __attribute__((always_inline)) {
     if (dead) return;
     const int sgn = (lk & 1) ? 0 : (int)0x80000000u;
 #pragma unroll
@@ -179,13 +187,22 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
         const double o = ys[(32 * wc + 16 * t + lr) * LP + kk + (lk ^ 1)];
         b2[t] = __hiloint2double(__double2hiint(o) ^ sgn, __double2loint(o));  // (lk odd) ? o : -o
       }
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-          cre[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], cre[ti][tj], 0, 0, 0);
-          cim[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b2[tj], cim[ti][tj], 0, 0, 0);
-        }
+      if (tmask & 1u) {  // (wave-uniform)
+        c0r = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], c0r, 0, 0, 0);
+        c0i = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b2[0], c0i, 0, 0, 0);
+      }
+      if (tmask & 2u) {
+        c1r = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[1], c1r, 0, 0, 0);
+        c1i = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b2[1], c1i, 0, 0, 0);
+      }
+      if (tmask & 4u) {
+        c2r = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[0], c2r, 0, 0, 0);
+        c2i = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b2[0], c2i, 0, 0, 0);
+      }
+      if (tmask & 8u) {
+        c3r = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], c3r, 0, 0, 0);
+        c3i = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b2[1], c3i, 0, 0, 0);
+      }
     }
   };
   // fetch(k0): issue the loads of this thread's 4 columns of both operands for the chunk at k0; finish(): whatever has
@@ -299,6 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
   if (dead) return;
 
   // epilogue: lane holds rows (lk + 4*reg), column lr of each 16x16 tile
+  const v4d cre[2][2] = {{c0r, c1r}, {c2r, c3r}}, cim[2][2] = {{c0i, c1i}, {c2i, c3i}};
   const int nx = MODE == MODE_GRAMX ? order_of(p, tile) : 0;
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
@@ -306,6 +324,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
+        if (!(tmask & (1u << (2 * ti + tj)))) continue;
         const int i = I0 + 32 * wr + 16 * ti + lk + 4 * reg;
         const int j = J0 + 32 * wc + 16 * tj + lr;
         double2* dst = p.A + ((int64_t)mat * p.Np + i) * p.Np + j;
