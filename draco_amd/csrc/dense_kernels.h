@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
   // their upper-right tile, the lower-left quadrant one tile row each -- where a quadrant per wave would make the block
   // wait for four.  tmask: bit 2 ti + tj = tile (ti, tj) of the wave's quadrant is computed.
   unsigned tmask = 0xF;
-  if ((MODE == MODE_GRAM || MODE == MODE_GRAMX) && bi == bj) {
+  if (MODE != MODE_PANEL && bi == bj) {  // (the Cholesky update of a diagonal block too: k_chol_diag reads its lower triangle)
     if (quad == 0 || quad == 3) tmask = 0xD;     // (0,0), (1,0), (1,1)
     else if (quad == 2) tmask = 0x3;             // lower-left quadrant, its first tile row
     else wr = 1, wc = 0, tmask = 0xC;            // ... its second tile row (the wave of the unread upper-right quadrant)
