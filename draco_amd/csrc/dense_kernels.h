@@ -168,6 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
     else wr = 1, wc = 0, tmask = 0xC;            // ... its second tile row (the wave of the unread upper-right quadrant)
   }
   const bool dead = false;
+  const unsigned emask = tmask;  // the tiles this wave writes (the panel product narrows tmask chunk by chunk)
   // accumulators of the wave's four tiles (named, not an array: with the per-tile branch below an array captured by the
   // chunk lambda ends up in scratch)
   const v4d vz = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -217,6 +218,12 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
       commit(ys, yr);
       __syncthreads();
       if (k0 + KC < K) fetch(k0 + KC);
+      if (MODE == MODE_PANEL) {
+        // Y = the inverse of a LOWER triangular factor: row j has nothing beyond column j, so the chunk of columns
+        // [k0, k0 + 16) only matters to the output tile columns 16 tj' >= k0 (10 of the 16 tile-chunks)
+        const int c = k0 / KC;
+        tmask = (c <= 2 * wc ? 0x5u : 0u) | (c <= 2 * wc + 1 ? 0xAu : 0u);
+      }
       mfma_chunk();
     }
   };
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        if (!(tmask & (1u << (2 * ti + tj)))) continue;
+        if (!(emask & (1u << (2 * ti + tj)))) continue;
         const int i = I0 + 32 * wr + 16 * ti + lk + 4 * reg;
         const int j = J0 + 32 * wc + 16 * tj + lr;
         double2* dst = p.A + ((int64_t)mat * p.Np + i) * p.Np + j;
