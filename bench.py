@@ -16,12 +16,14 @@ cannot be resident on one GPU, so the job runs under SURVEY 8d's *hbm-pool* poli
 DISTINCT tiles (default 32 -> 205 GB, >> 256 MiB Infinity Cache) stay resident across slabs and across days: every
 byte of B is read from HBM exactly once per solve, tile contents repeat every pool_freqs frequencies.
 
-Multi-GPU (torchrun, one rank per GPU; frequency is the path's shard axis, no collective inside the timed region):
-``--scaling weak`` (default): every rank owns its own 256 frequencies of a 256*N-frequency job,
-value = N * (mmax+1) / T.  ``--scaling strong``: cfg 3's 256 frequencies are split over the ranks
-(``parallel.split_local``); at N = 8 every rank's 32 frequencies ARE the resident pool (no aliasing), value =
-(mmax+1) / T.  After the timed region the rank-local Maps are all-gathered (``parallel.allgather_map``, the north
-star's single RCCL collective) and its time is reported.
+Multi-GPU (one rank per GPU over RCCL; frequency is the path's shard axis, no collective inside the timed region).
+``python bench.py --gpus N`` with N > 1 starts the N ranks ITSELF (a child ``python -m torch.distributed.run
+--nproc-per-node N bench.py ...``; the parent never touches the GPU and relays rank 0's line); launched under torchrun
+(WORLD_SIZE set) it is a rank.  ``--scaling strong`` (default for N > 1): the metric's own job -- cfg 3's 256
+frequencies -- is split over the ranks (``parallel.split_local``, the rule of stream.py:73); at N = 8 every rank's 32
+frequencies ARE the resident pool (no aliasing), value = (mmax+1) / T_max.  ``--scaling weak``: every rank owns its own
+256 frequencies of a 256*N-frequency job, value = N * (mmax+1) / T_max.  After the timed region the rank-local Maps are
+all-gathered (``parallel.allgather_map``, the north star's single RCCL collective) and its time is reported.
 
 Prints ONE JSON line on rank 0.
 """
@@ -51,7 +53,7 @@ def parse():
     ap.add_argument("--maker", default="dirty", choices=["dirty", "ml", "wiener"], help="map-maker of the timed day (the headline metric is quoted on dirty; cfg 3 of BASELINE.json names ml)")
     ap.add_argument("--tiles", default=None, choices=["random", "screen"], help="B tile source: counter-hash tiles (SyntheticProvider) or physically structured ones (BeamScreenProvider); default: random for dirty, screen for ml / wiener")
     ap.add_argument("--freqs", type=int, default=0, help="ml / wiener: frequencies of the timed day (0 = all of the config's; fewer = a stated sample, scaled)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: 'strong' (default) splits the metric's 256 frequencies over the ranks -- the job BASELINE.json names; 'weak' gives every rank its own 256")
     ap.add_argument("--b-dtype", default="complex128", choices=["complex128", "complex64"])
     ap.add_argument("--pool-freqs", type=int, default=0, help="frequencies' worth of distinct B tiles resident (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -644,11 +646,62 @@ class Job:
         return {"T_fft": t_fft, "T_solve": t_solve, "T_sht": t_sht}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun around it: THIS process becomes the launcher.  It has not
+    touched the GPU (the CPU baseline below spawns CPU workers only; `torch.cuda.device_count()` does not initialise
+    HIP), starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process --
+    one rank per GPU over RCCL, the reference's `mpirun -np N` (.github/workflows/main.yaml:83-92) --, relays rank 0's
+    JSON line with its own `cpu_baseline` merged in, and exits with the child's code."""
+    import socket
+    import subprocess
+
+    import torch
+
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if ndev < n and not args.same_device:
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible (one rank per GPU over RCCL; --backend gloo --same-device rehearses the N > 1 code path on one GPU)")
+    cpu = None
+    if not args.no_cpu_baseline and args.maker == "dirty":
+        from draco_amd import workloads as _wl
+
+        cpu = cpu_baseline(_wl.CONFIGS[args.config], args.cpu_seconds)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), DMM_BENCH_LAUNCHER="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stdout.write(ln)
+    rc = proc.wait()
+    if line is None:
+        raise SystemExit(rc or f"bench.py: the {n}-rank child printed no result line")
+    out = json.loads(line)
+    out["cpu_baseline"] = cpu
+    out["launcher"] = {"command": " ".join(cmd[1:6]) + " ... bench.py", "ranks_started": n, "devices_visible": ndev}
+    print(json.dumps(out))
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}: the launcher's world size is what runs", file=sys.stderr)
+    if args.scaling is None:
+        # N > 1: the metric's own job -- (128-feed, 256-freq) -- split over the ranks; at N = 8 a rank's 32 frequencies
+        # are exactly the resident pool.  N = 1: both forms are the same job.
+        args.scaling = "strong" if world > 1 else "weak"
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from draco_amd import workloads as _wl  # (the oracle is imported inside cpu_baseline only)
@@ -680,6 +733,17 @@ def main():
         t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    ranks_rec = None
+    if world > 1:
+        # who is really there: every rank contributes (rank, local device index) through the SAME kind of collective the
+        # map gather uses (`all_gather_into_tensor`: RCCL under nccl), so the record says how many ranks RCCL saw
+        mine = torch.tensor([rank, torch.cuda.current_device()], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        seen = torch.empty(world * 2, dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(seen, mine)
+        seen = seen.view(world, 2).cpu().tolist()
+        ranks_rec = {"world_size": world, "ranks_seen_by_all_gather_into_tensor": len({r for r, _ in seen}), "devices": [d for _, d in seen],
+                     "distinct_devices": len({d for _, d in seen}), "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else " (rehearsal)")}
 
     from draco_amd import parallel
     from draco_amd import workloads as wl
@@ -853,6 +917,8 @@ def main():
         },
     }
     out["allocator"] = allocator
+    if ranks_rec is not None:
+        out["ranks"] = ranks_rec
     if gather is not None:
         out["allgather"] = gather
 

@@ -59,7 +59,34 @@ struct DenseParams {
   int* fail;               // [nmat] set when a Cholesky pivot is not positive (nullptr: not tracked)
   const int* msel;         // Jacobi kernels: matrix index of the k-th selected matrix (nullptr: identity)
   double* theta;           // [nmat] upper bound of the largest eigenvalue
+  double* diag;            // dmm_ctx_set_ml_diag: [nfreq][n_m][4] validation record of the rank decision, or nullptr
 };
+
+// Validation record of pinv_svd's rank decision for one tile (dmm_ctx_set_ml_diag): every thread of the 256-thread
+// block brings what it saw of the spectrum -- kept count, smallest kept sigma, largest cut sigma.
+__device__ __forceinline__ void ml_diag_write(const DenseParams& p, const dmm_tile& tile, double cnt, double mnk, double mxc, double smax) {
+  __shared__ double s_diag[3][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o);
+    mnk = fmin(mnk, __shfl_xor(mnk, o));
+    mxc = fmax(mxc, __shfl_xor(mxc, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_diag[0][threadIdx.x >> 6] = cnt;
+    s_diag[1][threadIdx.x >> 6] = mnk;
+    s_diag[2][threadIdx.x >> 6] = mxc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* d = p.diag + ((int64_t)tile.f * p.n_m + tile.m) * 4;
+    d[0] = s_diag[0][0] + s_diag[0][1] + s_diag[0][2] + s_diag[0][3];
+    d[1] = smax;
+    d[2] = fmin(fmin(s_diag[1][0], s_diag[1][1]), fmin(s_diag[1][2], s_diag[1][3]));
+    d[3] = fmax(fmax(s_diag[2][0], s_diag[2][1]), fmax(s_diag[2][2], s_diag[2][3]));
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ double2 load_bc(const void* B, int c128, int64_t off) {
   if (c128) return reinterpret_cast<const double2*>(B)[off];

@@ -167,6 +167,12 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   return DMM_OK;
 }
 
+int dmm_ctx_set_ml_diag(dmm_ctx* c, double* diag) {
+  DMM_REQUIRE(c != nullptr, "dmm_ctx_set_ml_diag: ctx is NULL");
+  c->ml_diag = diag;
+  return DMM_OK;
+}
+
 int dmm_ctx_sync(dmm_ctx* c) {
   DMM_REQUIRE(c != nullptr, "dmm_ctx_sync: ctx is NULL");
   DMM_HIP(hipStreamSynchronize(c->stream));

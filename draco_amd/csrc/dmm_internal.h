@@ -53,6 +53,7 @@ struct dmm_ctx {
   int opt_wiener_overlap = 1;              // 1: the batches of dmm_wiener_run alternate between two streams (half the workspace each); 0: one stream
   int opt_gram_stage = 0;                  // operand staging of the beam Gram kernel: 0 = through registers (k_nt), 1 = LDS-DMA (k_gram_dma, complex128 packed tiles)
   int opt_ml_reduce = 0;                   // tridiagonal reduction of the ML eigen path: 0 = two-stage (dense -> band -> tridiagonal) where the band fits the LDS, 1 = one-stage Householder
+  double* ml_diag = nullptr;               // dmm_ctx_set_ml_diag: [nfreq][n_m][4] rank / sigma record of the eigen-decomposed ML tiles (validation)
   int opt_profile = 0;                     // 1: dmm_prof_scope records event pairs (bench.py's live kernel timing)
   std::vector<dmm_prof_span> prof_open;    // spans whose events have not been read yet
   double prof_us[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -747,12 +747,18 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
     const double smax = sqrt(fmax(fmax(fmax(red[0], red[1]), fmax(red[2], red[3])), 0.0));
+    double cnt = 0.0, mnk = 1e300, mxc = 0.0;
     for (int i = threadIdx.x; i < n; i += kThreads) {
       const double lam = dl[i], sig = sqrt(fmax(lam, 0.0));
       double2 v = make_double2(0.0, 0.0);
-      if (sig > tp.rcond * smax && sig > tp.acond) v = make_double2(b[i].x / lam, b[i].y / lam);
+      const bool keep = sig > tp.rcond * smax && sig > tp.acond;
+      if (keep) v = make_double2(b[i].x / lam, b[i].y / lam);
       b[i] = v;
+      cnt += keep ? 1.0 : 0.0;
+      mnk = keep ? fmin(mnk, sig) : mnk;
+      mxc = keep ? mxc : fmax(mxc, sig);
     }
+    if (p.diag) ml_diag_write(p, tile, cnt, mnk, mxc, smax);
   }
   __syncthreads();
   // ---- y = S g: the chases in reverse order, ascending index pairs, same pipeline:

@@ -295,11 +295,16 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
   const double smax = sqrt(fmax(lam_max, 0.0));
   // c_k = (u_k^H b) / lambda_k for kept k.  Eigenvector k = column k of V.  Padded
   // coordinates (i >= N) never mix with the rest (their rows/cols are those of the identity).
+  double cnt = 0.0, mnk = 1e300, mxc = 0.0;
   for (int k = threadIdx.x; k < n; k += kThreads) {
     const double lam = A[(int64_t)k * n + k].x;
     const double sig = sqrt(fmax(lam, 0.0));
     double2 acc = make_double2(0.0, 0.0);
-    if (sig > jp.rcond * smax && sig > jp.acond) {  // pinv_svd's rank rule, mapmaker.py:296
+    const bool keep = sig > jp.rcond * smax && sig > jp.acond;
+    cnt += keep ? 1.0 : 0.0;
+    mnk = keep ? fmin(mnk, sig) : mnk;
+    mxc = keep ? mxc : fmax(mxc, sig);
+    if (keep) {  // pinv_svd's rank rule, mapmaker.py:296
       for (int i = 0; i < n; ++i) {
         const double2 u = V[(int64_t)i * n + k], x = b[i];
         acc.x += u.x * x.x + u.y * x.y;
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
     }
     c[k] = acc;
   }
+  if (p.diag) ml_diag_write(p, tile, cnt, mnk, mxc, smax);
   __syncthreads();
   for (int i = threadIdx.x; i < N; i += kThreads) {
     double2 acc = make_double2(0.0, 0.0);
@@ -437,6 +443,7 @@ DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, cons
   p.fail = nullptr;
   p.msel = nullptr;
   p.theta = nullptr;
+  p.diag = pl->ctx->ml_diag;
   return p;
 }
 

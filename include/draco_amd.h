@@ -97,6 +97,13 @@ int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
  * (tridiagonal eigen-solve + replay), backproj (a = B^H w), solve (dmm_wiener_run from its first launch to its last: the
  * batches of that call alternate between two streams, so its class sums overlap in time and this span is the wall).  Reading a counter waits for the spans still running. */
 int dmm_ctx_get_counter(dmm_ctx* ctx, const char* name, int64_t* value);
+/* Validation hook for pinv_svd's rank decision (mapmaker.py:296: keep sigma > rcond*sigma_max and sigma > acond).
+ * While `diag` [dev] is non-NULL every tile that dmm_ml_run eigen-decomposes writes four doubles at
+ * diag[(f * n_m + m) * 4]: the number of singular values it kept, sigma_max, the smallest kept sigma and the largest
+ * cut sigma (sigma = sqrt(lambda) of the smaller-side Gram matrix; exact zero modes -- padding, zero-weight rows,
+ * l < m -- count as cut with sigma 0).  Tiles solved by the certified full-rank shortcut write nothing (initialise
+ * the buffer to -1 to tell them apart).  f, m as in dmm_tile; n_m = the plan's.  NULL switches it off. */
+int dmm_ctx_set_ml_diag(dmm_ctx* ctx, double* diag);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
 int dmm_timer_start(dmm_ctx* ctx);
 int dmm_timer_stop(dmm_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */

@@ -1,5 +1,6 @@
-"""The N > 1 code path of bench.py rehearsed on ONE GPU: two ranks share cuda:0 over gloo (`--backend gloo
---same-device`), cfg 2, strong and weak scaling.  Functional check only -- process group, frequency slabs, barrier /
+"""The N > 1 code path of bench.py rehearsed on ONE GPU: `python bench.py --gpus 2` starts its two ranks ITSELF (no
+torchrun on the command line: the driver's command shape); they share cuda:0 over gloo (`--backend gloo
+--same-device`), cfg 2, strong (the default) and weak scaling.  Functional check only -- process group, frequency slabs, barrier /
 all-reduce MAX timing, the all-gather of the maps and its record -- not a measurement (RCCL needs one GPU per rank)."""
 
 import json
@@ -14,19 +15,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("scaling,port", [("strong", 29541), ("weak", 29542)])
-def test_bench_two_ranks_on_one_gpu(scaling, port):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "2",
-           "--backend", "gloo", "--same-device", "--scaling", scaling, "--pool-freqs", "16"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.parametrize("scaling", [None, "weak"])
+def test_bench_two_ranks_on_one_gpu(scaling):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "2",
+           "--backend", "gloo", "--same-device", "--pool-freqs", "16", "--no-cpu-baseline"] + (["--scaling", scaling] if scaling else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
+    scaling = scaling or "strong"  # the N > 1 default: the metric's own job split over the ranks
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 2 and d["value"] > 0
+    assert d["ranks"]["ranks_seen_by_all_gather_into_tensor"] == 2 and d["launcher"]["ranks_started"] == 2
     nfreq_job = 64 if scaling == "strong" else 128
     assert d["allgather"]["frequencies_gathered"] == nfreq_job  # every rank ends with the whole map
     assert d["allgather"]["gathered_GB"] == pytest.approx(2 * d["allgather"]["shard_GB"])
     assert d["roofline"]["launches"] >= 2 and 0 < d["roofline"]["frac"] < 1.0
-    assert d["cpu_baseline"] is None  # measured at N = 1 only
+    assert d["cpu_baseline"] is None  # (--no-cpu-baseline; otherwise the launcher times it before it starts the ranks)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`--gpus 8` on a one-GPU box must fail loudly, not run one rank and print n_gpus = 1."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-cpu-baseline"], cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}, capture_output=True, text=True, timeout=300)
+    import torch
+
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU box: the command is a real run here")
+    assert res.returncode != 0 and "GPU(s) visible" in res.stderr and not res.stdout.strip()
