@@ -28,6 +28,22 @@ def pinv_svd(M, acond=1e-4, rcond=1e-3):
     return np.transpose(np.conjugate(np.dot(u[:, :rank] * psigma_diag, vh[:rank])))
 
 
+def pinv_svd_spectrum(M, acond=1e-4, rcond=1e-3):
+    """What ``pinv_svd`` decides on: the singular values of ``M`` and the rank its rule keeps (``mapmaker.py:294-296``:
+    ``rank = sum(sig > rcond * sig.max() and sig > acond)``).  Returns ``(rank, sig)``, ``sig`` descending."""
+    sig = la.svd(M, compute_uv=False)
+    rank = int(np.sum(np.logical_and(sig > rcond * sig.max(), sig > acond)))
+    return rank, sig
+
+
+def ml_spectrum(bm, Ni):
+    """Rank and singular values of the matrix ``MaximumLikelihoodMapMaker._solve_m`` hands to ``pinv_svd``
+    (``N^-1/2 B``, ``mapmaker.py:188-196``)."""
+    ntel = bm.shape[0] * bm.shape[1]
+    B = bm.reshape(ntel, -1)
+    return pinv_svd_spectrum(B * (np.asarray(Ni).reshape(ntel) ** 0.5)[:, np.newaxis])
+
+
 def dirty_solve(bm, v, Ni):
     """``a = B^H (Ni * v)``, ``mapmaker.py:156-168`` -> ``[npol, lmax+1]``."""
     npol, nl = bm.shape[-2:]

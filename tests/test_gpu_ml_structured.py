@@ -1,0 +1,165 @@
+"""The dense map-makers at cfg-3 order on PHYSICALLY STRUCTURED tiles against the oracle (VERDICT r3 missing 2 / weak 2).
+
+cfg 3 is the ML configuration of BASELINE.json and ``bench.py --maker ml`` times it on ``BeamScreenProvider`` tiles
+(every tile eigen-decomposed, none certified) -- the regime where ``pinv_svd``'s cut (``mapmaker.py:287-300``:
+``rcond = 1e-3``, ``acond = 1e-4``) really truncates a continuous singular spectrum and where the Gram route of the
+GPU path (eigenvalues of ``D B B^H D`` / ``B^H N B``, rank decided on ``sqrt(lambda)``) squares the condition number.
+Here one cfg-3 frequency pair (379 baselines, lmax 512, the bench's screen parameters) goes through the BATCHED default
+pass of ``MaximumLikelihoodMapMaker`` and sampled (m, f) are compared with ``oracle.mapmaker.ml_solve`` (SVD of
+``N^-1/2 B``) on the tiles read back with ``bt.beam_m(m, fi=f)``: the kept rank must be the oracle's and the solution
+must agree.  The m whose spectrum comes closest to the cut is found from the library's own rank record
+(``dmm_ctx_set_ml_diag``) and is part of the sample; what happens there is written to the report, not hidden.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mapmaker as omm
+from oracle import synth as osyn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RCOND, ACOND = 1e-3, 1e-4  # pinv_svd's defaults, mapmaker.py:287
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _setup(nfreq=2, zero_frac=0.02, seed=11, **screen):
+    import torch
+
+    from draco_amd.core import containers
+    from draco_amd.core.products import BeamScreenProvider, TransitTelescope
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    c = osyn.CONFIGS[3]
+    tel = TransitTelescope(osyn.frequencies(c["nfreq"])[:nfreq], lmax=c["lmax"], ncyl=c["ncyl"], nfeed_cyl=c["nfeed_cyl"])
+    assert tel.npairs == 379 and tel.lmax == 512
+    bt = BeamScreenProvider(tel, seed=3003, **screen)  # bench.py --maker ml's tile source and seed
+    gen = torch.Generator(device=ctx.device).manual_seed(seed)
+    shape = (tel.lmax + 1, 2, nfreq, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    # the weights bench.py's day produces: w_m = nra^2 / sum_ra (1 / w), w ~ 20 U(0.5, 1.5) -> ~ 2e4; 2 % exact zeros
+    mw = (torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5) * 20.0 * 1024
+    mw[torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) < zero_frac] = 0.0
+    mm = containers.MModes(mmax=tel.lmax, freq=tel.frequencies, stack=tel.npairs, allocate=False)
+    mm.attach("vis", mv)
+    mm.attach("vis_weight", mw)
+    per_f = sum(2 * tel.npairs * 4 * (tel.lmax + 1 - m) for m in range(tel.lmax + 1)) * 16
+    return ctx, tel, bt, mm, mv, mw, per_f
+
+
+# (a) the bench's screen parameters: cylinders 22 m apart see the sky up to m ~ 300, so the truncating regime is the
+#     telescope-side one (order 758) and every tile beyond is below the absolute cut (rank 0, like the oracle);
+# (b) cylinders 44 m apart reach m ~ 500: the SKY-side systems (orders 4 (513 - m) < 758) are in the truncating regime
+@pytest.mark.parametrize("name,screen,sample", [
+    ("bench", {}, [(0, 0), (0, 40), (0, 120), (0, 180), (0, 240), (0, 280), (0, 300), (0, 324), (0, 505), (1, 7), (1, 200), (1, 262)]),
+    ("wide", {"cyl_sep": 44.0}, [(0, 10), (0, 250), (0, 322), (0, 330), (0, 380), (0, 430), (0, 470), (1, 325), (1, 400), (1, 455)]),
+])
+def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, screen, sample):
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.device import ptr
+
+    nfreq = 2
+    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, **screen)
+    lmax, n_m = tel.lmax, tel.lmax + 1
+    task = MaximumLikelihoodMapMaker(nside=64, pool_bytes=nfreq * per_f + (1 << 20))
+    task.setup(bt)
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    diag = torch.full((nfreq, n_m, 4), -1.0, dtype=torch.float64, device=ctx.device)
+    e0, d0 = counter(b"ml_tiles_eigen"), counter(b"ml_tiles_direct")
+    _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, ptr(diag)))
+    try:
+        alm = task.make_alm(mm)  # the batched default pass (certificate probe, deferred eigen pass, two-stage reduction)
+        ctx.sync()
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, None))
+    n_eig, n_dir = counter(b"ml_tiles_eigen") - e0, counter(b"ml_tiles_direct") - d0
+    assert n_eig + n_dir == nfreq * n_m
+    alm = alm.cpu().numpy()
+    diag = diag.cpu().numpy()
+    assert np.all(np.isfinite(alm))
+    dec = diag[..., 0] >= 0  # tiles the eigen path decomposed (the certified ones leave -1)
+    assert dec.sum() == n_eig
+    # these tiles are ill-conditioned the way real products are: (almost) nothing passes the full-rank certificate
+    assert n_eig > 0.9 * nfreq * n_m, (n_eig, n_dir)
+
+    # distance of every decomposed tile's spectrum from the cut, from the library's own record
+    smax, kept_min, cut_max = diag[..., 1], diag[..., 2], diag[..., 3]
+    cut = np.maximum(RCOND * smax, ACOND)
+    gap = np.where(dec, np.minimum(np.where(kept_min < 1e299, kept_min / cut - 1.0, np.inf), 1.0 - cut_max / cut), np.inf)
+    truncated = dec & (cut_max > 1e-2 * cut)  # a real mode is cut, not the rounding dust of zero modes (~1e-5 of the cut)
+    assert truncated.sum() > 0.5 * dec.sum()  # the cut removes modes on most tiles (random tiles: on none)
+    f_near, m_near = np.unravel_index(np.argmin(gap), gap.shape)
+    sample = sorted(set(sample) | {(int(f_near), int(m_near))})
+
+    mv_h, mw_h = mv.cpu().numpy(), mw.cpu().numpy()
+    rows, worst, rank_mismatch = [], 0.0, []
+    for f, m in sample:
+        bm = bt.beam_m(m, fi=f)
+        v, Ni = mv_h[m, :, f], mw_h[m, :, f]
+        ref = omm.ml_solve(bm, v, Ni)
+        rank_o, sig = omm.ml_spectrum(bm, Ni)
+        cut_o = max(RCOND * sig[0], ACOND)
+        gap_o = float(min(sig[rank_o - 1] / cut_o - 1.0 if rank_o > 0 else np.inf, 1.0 - (sig[rank_o] / cut_o if rank_o < len(sig) else 0.0)))
+        err = _rel(alm[f, :, m, :], ref)
+        rank_g = int(diag[f, m, 0]) if dec[f, m] else None
+        rows.append({"f": f, "m": m, "order": int(min(2 * tel.npairs, 4 * (n_m - m))), "side": "telescope" if 4 * (n_m - m) >= 2 * tel.npairs else "sky",
+                     "rank_oracle": rank_o, "rank_gpu": rank_g, "sigma_max_oracle": float(sig[0]), "sigma_max_gpu": float(diag[f, m, 1]),
+                     "zero_weights": int((Ni == 0).sum()), "gap_to_cut_oracle": gap_o, "gap_to_cut_gpu": float(gap[f, m]), "rel_err": err,
+                     "nearest_to_cut_of_all_tiles": bool((f, m) == (f_near, m_near))})
+        if rank_g is not None and rank_g != rank_o:
+            rank_mismatch.append(rows[-1])
+        else:
+            worst = max(worst, err)
+        # l < m stays exactly zero, like the reference's output for a provider that zeroes those columns
+        assert not np.any(alm[f, :, m, :m])
+    report = {"screen": name, "screen_parameters": bt.model() and {k: v for k, v in bt.model().items() if np.isscalar(v)}, "cyl_sep": bt.cyl_sep, "tiles": nfreq * n_m, "eigen_decomposed": n_eig, "certified": n_dir, "tiles_the_cut_truncates": int(truncated.sum()),
+              "smallest_gap_to_cut_over_all_tiles": float(gap.min()), "worst_rel_err_where_ranks_agree": worst, "rows": rows}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"r04_ml_structured_vs_oracle_{name}.json"), "w") as fh:
+        json.dump(report, fh, indent=1)
+    print(json.dumps(report))
+    # the sample really is in the truncating regime and carries zero weights
+    assert sum(0 < r["rank_oracle"] < r["order"] for r in rows) >= len(rows) // 2
+    assert any(r["side"] == "sky" and 0 < r["rank_oracle"] < r["order"] for r in rows) or name == "bench"
+    assert min(abs(r["gap_to_cut_oracle"]) for r in rows) < 1e-2  # a singular value within 1 % of the cut is in the sample
+    assert all(r["zero_weights"] >= 5 for r in rows)
+    # rank: the Gram route resolves sigma to ~ eps sigma_max^2 / (2 sigma) -> 1e-10 relative at the cut; a tie closer
+    # than 1e-8 of the cut may fall either way (and is then a different, equally valid, truncation): anything else must agree
+    for r in rank_mismatch:
+        assert abs(r["gap_to_cut_oracle"]) < 1e-8, r
+    # solution: 1e-7 of its scale
+    assert worst < 1e-7, report
+
+
+def test_cfg3_wiener_batched_pass_on_structured_tiles_against_the_oracle():
+    from draco_amd.analysis.mapmaker import WienerMapMaker
+
+    nfreq = 2
+    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, seed=12)
+    task = WienerMapMaker(nside=64, pool_bytes=nfreq * per_f + (1 << 20))
+    task.setup(bt)
+    alm = task.make_alm(mm).cpu().numpy()
+    mv_h, mw_h = mv.cpu().numpy(), mw.cpu().numpy()
+    worst = 0.0
+    for f, m in ((0, 0), (0, 150), (0, 323), (0, 324), (0, 500), (1, 60), (1, 322), (1, 400)):
+        ref = omm.wiener_solve(bt.beam_m(m, fi=f), m, mv_h[m, :, f], mw_h[m, :, f], task.prior_amp, task.prior_tilt)
+        worst = max(worst, _rel(alm[f, :, m, :], ref))
+    assert worst < 1e-9, worst

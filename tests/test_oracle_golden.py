@@ -105,6 +105,8 @@ def test_pinv_svd(golden_dir):
         p = omm.pinv_svd(g[f"c{i}_M"])
         np.testing.assert_allclose(p, g[f"c{i}_pinv"], rtol=0, atol=1e-12 * np.abs(g[f"c{i}_pinv"]).max())
         ranks.append(np.linalg.matrix_rank(p, tol=1e-9 * np.abs(p).max()))
+        # the rank the spectrum helper reports is the rank of the reference's own pseudo-inverse
+        assert omm.pinv_svd_spectrum(g[f"c{i}_M"])[0] == np.linalg.matrix_rank(g[f"c{i}_pinv"], tol=1e-9 * np.abs(g[f"c{i}_pinv"]).max())
     assert ranks[0] == 7 and ranks[1] == 7 and ranks[2] == 8  # rcond and acond cuts bite
 
 
