@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("DRACO_AMD_LIBRARY") or os.path.join(_HERE, "libdraco_
 
 DMM_C64, DMM_C128 = 0, 1
 DMM_B_FULL, DMM_B_PACKED = 0, 1
-DMM_E_ARG, DMM_E_UNSUPPORTED, DMM_E_NOMEM, DMM_E_STATE = -1, -2, -3, -4
+DMM_E_ARG, DMM_E_UNSUPPORTED, DMM_E_NOMEM, DMM_E_STATE, DMM_E_COMM = -1, -2, -3, -4, -5
 DMM_MAX_NRA = 8192
 
 

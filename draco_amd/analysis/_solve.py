@@ -151,6 +151,8 @@ class SolveEngine:
     Plans are kept for the engine's lifetime (``dmm_plan_destroy`` frees device memory, which synchronises).
     """
 
+    _MAX_PLAN_KEYS = 4
+
     def __init__(self, provider, ctx=None, b_dtype=_lib.DMM_C128, b_layout=_lib.DMM_B_PACKED, pool_bytes=None, cache=True):
         self.provider = provider
         self.ctx = ctx or Context.get()
@@ -161,6 +163,7 @@ class SolveEngine:
         self._cached_key = None
         self._cached_slabs = None
         self._plans: dict = {}
+        self._plan_keys: list = []  # keys of `_plans` entries, least recently used first
         self.last_b_bytes = 0
         self.fills = 0  # slabs actually filled (the others were resident)
         self.launch_events = None  # set to a list to collect (start, stop, b_bytes, ntile) per Dirty launch
@@ -171,6 +174,7 @@ class SolveEngine:
         for s in self._plans.values():
             s.close()
         self._plans.clear()
+        self._plan_keys.clear()
 
     def __del__(self):
         try:
@@ -247,9 +251,19 @@ class SolveEngine:
         ranges = self._slab_ranges(ms, mmax + 1)
         # plans are keyed by slab range; the ranges follow the HBM budget, which may drift between passes (free memory):
         # plans of a carving that is not this pass's are dropped instead of piling up with their device tables
+        # -- only plans of THIS key: another frequency selection or mmax used alternately through the same engine keeps
+        # its plans (dropping them costs a device-synchronising hipFree each and a rebuild every pass); at most
+        # `_MAX_PLAN_KEYS` keys are kept, the least recently used one goes first
         live = {(key, a, b) for a, b in ranges}
-        for stale in [k for k in self._plans if k not in live]:
+        for stale in [k for k in self._plans if k[0] == key and k not in live]:
             self._plans.pop(stale).close()
+        if key in self._plan_keys:
+            self._plan_keys.remove(key)
+        self._plan_keys.append(key)
+        while len(self._plan_keys) > self._MAX_PLAN_KEYS:
+            old = self._plan_keys.pop(0)
+            for stale in [k for k in self._plans if k[0] == old]:
+                self._plans.pop(stale).close()
         es = _ELEM[self.b_dtype]
         bufs = _buffers(ctx, self.nbuf, max(self._pool_elems, 1) * es)
         main = torch.cuda.current_stream(ctx.device)

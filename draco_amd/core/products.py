@@ -598,11 +598,16 @@ class PackedStoreProvider(BeamTransferProvider):
         (``mapmaker.py:160-162``): streamed tile by tile they are host-bound (14 GB/s through the staging ring, one
         interpreter packing under the GIL); packed once, every later day streams at the rate of a plain memory copy.
         The packing itself runs in ``processes`` worker PROCESSES (default: the host's share, at most 16), each
-        writing its (frequency, m-range) chunks straight into the memory-mapped file.  Workers are forked, so they
-        inherit ``provider`` as it is (they never touch the GPU); where forking is not an option pass ``factory``, a
-        picklable callable that builds the provider inside a spawned worker.
+        writing its (frequency, m-range) chunks straight into the memory-mapped file.  How the workers get the
+        provider: ``factory`` (a picklable callable that builds it inside a SPAWNED worker) if given; otherwise a
+        pickled copy of ``provider`` handed to spawned workers when this process has already initialised the GPU (a
+        forked child of a process that holds a HIP context and runtime threads is undefined: it can hang or crash);
+        plain ``fork`` (workers inherit ``provider`` as it is) only while the GPU is untouched.  A provider that
+        makes its tiles ON the GPU (``fill_mode == "device"``) cannot be packed by worker processes at all: that is
+        refused unless ``processes == 1`` (packed by this process).
         """
         import multiprocessing as mp
+        import pickle
 
         tel = provider.telescope
         npdt = np.dtype(dtype)
@@ -630,6 +635,19 @@ class PackedStoreProvider(BeamTransferProvider):
             for j in jobs:
                 _pack_job(j)
         else:
+            if factory is None:
+                if getattr(provider, "fill_mode", "host") == "device":
+                    raise ValueError(f"PackedStoreProvider.pack: {type(provider).__name__} generates its tiles on the GPU (fill_mode 'device'); "
+                                     "worker processes must not touch the GPU -- pack with processes=1, or pass a host-side factory")
+                import torch
+
+                if torch.cuda.is_initialized():
+                    try:
+                        factory = _Unpickle(pickle.dumps(provider, protocol=pickle.HIGHEST_PROTOCOL))
+                    except Exception as exc:  # noqa: BLE001
+                        raise RuntimeError("PackedStoreProvider.pack: this process has initialised the GPU, so its workers are spawned, not "
+                                           f"forked, and need a picklable provider ({type(provider).__name__} is not: {exc!r}); pass factory=, "
+                                           "or pack before the first GPU call") from exc
             ctx = mp.get_context("fork" if factory is None else "spawn")
             global _PACK_STATE
             _PACK_STATE = (provider, path) if factory is None else None  # forked workers inherit it
@@ -640,6 +658,18 @@ class PackedStoreProvider(BeamTransferProvider):
             finally:
                 _PACK_STATE = None
         return cls.open(tel, path)
+
+
+class _Unpickle:
+    """Picklable factory: the provider rebuilt from its pickle inside a spawned worker."""
+
+    def __init__(self, blob):
+        self.blob = blob
+
+    def __call__(self):
+        import pickle
+
+        return pickle.loads(self.blob)
 
 
 _PACK_STATE = None  # (provider, path) of the packing run in this process / inherited by its forked workers

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(kThreads) void k_redundancy(const float* __restrict
     const int t = (int)(idx - p * nra);
     const int s = stack[p];
     if (s < 0 || s >= nstack) continue;
-    const float v = all_good ? 1.f : flags[(int64_t)pa[p] * nra + t] * flags[(int64_t)pb[p] * nra + t];
+    const int a = pa[p], b = pb[p];
+    if (!all_good && ((unsigned)a >= (unsigned)ninput || (unsigned)b >= (unsigned)ninput)) continue;  // an input the flag table does not have
+    const float v = all_good ? 1.f : flags[(int64_t)a * nra + t] * flags[(int64_t)b * nra + t];
     // (the summands are 0 / 1 products of flags: float sums of them are exact and order independent)
     if (v != 0.f) atomicAdd(red + (int64_t)s * nra + t, v);
   }

@@ -6,7 +6,10 @@
 // its only link-time dependency, and a single-GPU user never loads RCCL at all.  The Python layer of this package
 // gathers through torch.distributed instead (draco_amd/parallel.py; backend "nccl" is the same RCCL).
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "dmm_internal.h"
 
@@ -32,32 +35,48 @@ struct Rccl {
   fn_error_string error_string = nullptr;
 };
 
+// One load per process, whoever calls first (std::call_once: two threads entering dmm_comm_* together do not race on
+// the table); a library that lacks a symbol is closed again and the failure is remembered.
 int rccl_load(Rccl** out) {
   static Rccl r;
-  if (!r.so) {
+  static std::once_flag once;
+  static int status = DMM_OK;
+  static char why[256] = "";
+  std::call_once(once, [] {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* so = nullptr;
     for (const char* nm : names) {
-      r.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-      if (r.so) break;
+      so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+      if (so) break;
     }
-    if (!r.so) return dmm_set_error(DMM_E_STATE, "dmm_comm: librccl.so could not be loaded (%s)", dlerror());
-    r.get_unique_id = (fn_get_unique_id)dlsym(r.so, "ncclGetUniqueId");
-    r.comm_init_rank = (fn_comm_init_rank)dlsym(r.so, "ncclCommInitRank");
-    r.comm_destroy = (fn_comm_destroy)dlsym(r.so, "ncclCommDestroy");
-    r.all_gather = (fn_all_gather)dlsym(r.so, "ncclAllGather");
-    r.error_string = (fn_error_string)dlsym(r.so, "ncclGetErrorString");
+    if (!so) {
+      const char* e = dlerror();
+      snprintf(why, sizeof(why), "dmm_comm: librccl.so could not be loaded (%s)", e ? e : "?");
+      status = DMM_E_STATE;
+      return;
+    }
+    r.get_unique_id = (fn_get_unique_id)dlsym(so, "ncclGetUniqueId");
+    r.comm_init_rank = (fn_comm_init_rank)dlsym(so, "ncclCommInitRank");
+    r.comm_destroy = (fn_comm_destroy)dlsym(so, "ncclCommDestroy");
+    r.all_gather = (fn_all_gather)dlsym(so, "ncclAllGather");
+    r.error_string = (fn_error_string)dlsym(so, "ncclGetErrorString");
     if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) {
-      r.so = nullptr;
-      return dmm_set_error(DMM_E_STATE, "dmm_comm: librccl.so lacks an expected symbol");
+      dlclose(so);
+      snprintf(why, sizeof(why), "dmm_comm: librccl.so lacks an expected symbol");
+      status = DMM_E_STATE;
+      return;
     }
-  }
+    r.so = so;
+  });
+  if (status != DMM_OK) return dmm_set_error(status, "%s", why);
   *out = &r;
   return DMM_OK;
 }
 
+// RCCL's result codes are small positive integers that would collide with hipError_t's number space (the meaning of
+// a positive dmm status): a failing collective is reported as DMM_E_COMM, the RCCL code and its text in the message.
 int rccl_fail(const Rccl* r, const char* what, int rc) {
-  // RCCL's codes are small positive integers like hipError_t's; the message says which library spoke
-  return dmm_set_error(rc > 0 ? rc : DMM_E_STATE, "%s failed: RCCL error %d (%s)", what, rc, r->error_string ? r->error_string(rc) : "?");
+  return dmm_set_error(DMM_E_COMM, "%s failed: RCCL error %d (%s)", what, rc, r->error_string ? r->error_string(rc) : "?");
 }
 
 constexpr int kNcclFloat64 = 8;  // ncclDouble in rccl.h's ncclDataType_t

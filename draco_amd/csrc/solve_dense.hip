@@ -544,6 +544,10 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   for (auto& kv : sky_lists) ntiles += kv.second.size();
   const bool two = ctx->opt_wiener_overlap && cap >= 2 && ntiles > (size_t)cap / 2;
   const int caph = two ? cap / 2 : cap;
+  // host-side sources of the batches' asynchronous list uploads: declared FIRST so that they outlive every guard
+  // below (destructors run in reverse order) -- on an early error return both streams are drained before they die
+  std::vector<dmm_tile> tiles_c[2];
+  std::vector<int32_t> work_c[2];
   dmm_aux_scope aux_guard(ctx);  // the second stream is drained on every return path
   struct StreamRestore {
     dmm_ctx* c;
@@ -551,6 +555,10 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
     ~StreamRestore() { c->stream = s; }
   } stream_guard{ctx, ctx->stream};
   hipStream_t st[2] = {ctx->stream, ctx->stream};
+  struct DrainCaller {  // the caller's stream too: copies out of tiles_c / work_c may still be queued on it
+    hipStream_t s;
+    ~DrainCaller() { (void)hipStreamSynchronize(s); }
+  } drain_guard{st[0]};
   dmm_prof_scope prof_all(ctx, DMM_PROF_SOLVE, st[0]);  // the whole pass on the caller's stream (both halves are joined before it ends)
   if (two) {
     if (!ctx->aux_stream) DMM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -559,8 +567,6 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
     DMM_HIP(hipEventRecord(ctx->aux_ev[0], st[0]));  // the prior tables and the sky-side right-hand sides are ready
     DMM_HIP(hipStreamWaitEvent(st[1], ctx->aux_ev[0], 0));
   }
-  std::vector<dmm_tile> tiles_c[2];
-  std::vector<int32_t> work_c[2];
   int batch_no = 0;
   auto run_batch = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky) -> int {
     const int h = two ? (batch_no++ & 1) : 0;

@@ -42,7 +42,8 @@ enum {
   DMM_E_ARG = -1,      /* invalid argument (null pointer, bad size, bad enum) */
   DMM_E_UNSUPPORTED = -2, /* valid request this build cannot serve (e.g. nra too long) */
   DMM_E_NOMEM = -3,
-  DMM_E_STATE = -4
+  DMM_E_STATE = -4,
+  DMM_E_COMM = -5      /* an RCCL call failed (dmm_comm_*, dmm_allgather_map); RCCL's own code is in dmm_last_error() */
 };
 
 /* element types of the beam-transfer pool and of m-mode outputs */

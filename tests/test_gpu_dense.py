@@ -126,11 +126,12 @@ def test_gram_operands_by_lds_dma_vs_oracle(kind, tol):
     assert _rel(alm, ref) < tol
 
 
-def test_wiener_two_batches_in_flight_is_the_same_solve():
+def test_wiener_two_batches_in_flight_is_the_same_solve(monkeypatch):
     """`dmm_wiener_run` alternates its batches between two streams, half the workspace each (`wiener_overlap`, default
     on).  A small workspace forces several batches per side; every tile's arithmetic is independent of its batch, so
     the one-stream pass must give the same bits -- and both agree with the oracle."""
     from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
     from draco_amd.analysis.mapmaker import WienerMapMaker
     from draco_amd.core import containers
     from draco_amd.core.products import SyntheticProvider
@@ -146,17 +147,24 @@ def test_wiener_two_batches_in_flight_is_the_same_solve():
     mm.vis[:] = mv
     mm.weight[:] = mw
     ctx = Context.get()
-    out = {}
+    out, batches = {}, {}
+    # the engine offers the solver half of the free HBM (one batch would take every tile): pin 24 MiB instead
+    monkeypatch.setattr(SolveEngine, "_offer_workspace", lambda self, option, cap_mib: _lib.check(_lib.lib.dmm_ctx_set_option(self.ctx.handle, option, 24)))
     try:
-        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"wiener_workspace_mib", 24))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
         for ov in (1, 0):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"wiener_overlap", ov))
             task = WienerMapMaker(prior_amp=1.5, prior_tilt=0.75)
             task.setup(bt)
+            n0 = _counter(ctx, b"prof_gram_n")
             out[ov] = task.alm_square(task.make_alm(mm))
+            batches[ov] = _counter(ctx, b"prof_gram_n") - n0  # one Gram span per batch
     finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"wiener_overlap", 1))
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"wiener_workspace_mib", 0))
+    # batches alternate between the two streams: more than two per stream = a half's device lists were reused
+    assert batches[1] >= 6 and batches[0] >= 3, batches
     assert np.array_equal(out[1], out[0])
     beam = lambda m, f: osyn.beam_tile(541, m, f, tel.npairs, 4, lmax)  # noqa: E731
     ref = omm.solve_alm("wiener", beam, mv, mw, lmax, tel.mmax, list(range(nfreq)), prior_amp=1.5, prior_tilt=0.75)

@@ -323,3 +323,39 @@ def test_bench_gpus_flag_starts_ranks_or_refuses():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "GPU(s) visible" in res.stderr and not res.stdout.strip()
+
+
+class _PicklableTiles:
+    """A per-tile provider body that survives pickling (module level, no closure)."""
+
+    def __init__(self, npairs, lmax):
+        self.npairs, self.lmax = npairs, lmax
+
+    def __call__(self, m, f):
+        from draco_amd.core.products import synth_beam_tile
+
+        return synth_beam_tile(11, m, f, self.npairs, 4, self.lmax)
+
+
+def test_pack_never_forks_a_process_that_holds_the_gpu(tmp_path, monkeypatch):
+    """`PackedStoreProvider.pack` forked its workers whatever the parent's state.  A provider that
+    fills on the device is refused (workers must not touch the GPU); once this process has initialised the GPU the
+    workers are SPAWNED from a pickled provider (or a factory), and an unpicklable provider is a clear error."""
+    import torch
+
+    from draco_amd.core.products import ArrayProvider, PackedStoreProvider, TransitTelescope
+
+    lmax = 7
+    tel = TransitTelescope(np.linspace(400.0, 500.0, 2), lmax=lmax, ncyl=1, nfeed_cyl=3)
+    host = ArrayProvider(tel, _PicklableTiles(tel.npairs, lmax))
+    dev = ArrayProvider(tel, _PicklableTiles(tel.npairs, lmax))
+    dev.fill_mode = "device"
+    with pytest.raises(ValueError, match="generates its tiles on the GPU"):
+        PackedStoreProvider.pack(dev, str(tmp_path / "d.npy"), processes=2, chunk_bytes=2048)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    st = PackedStoreProvider.pack(host, str(tmp_path / "s.npy"), processes=2, chunk_bytes=2048)  # spawned workers, pickled provider
+    for m in (0, 3, lmax):
+        assert np.array_equal(st.beam_m(m, fi=1), host.beam_m(m, fi=1))
+    closure = ArrayProvider(tel, lambda m, f: host.beam_m(m, fi=f))
+    with pytest.raises(RuntimeError, match="need a picklable provider"):
+        PackedStoreProvider.pack(closure, str(tmp_path / "c.npy"), processes=2, chunk_bytes=2048)

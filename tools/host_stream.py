@@ -20,6 +20,20 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+class PerTileFromStore:
+    """Picklable factory for `PackedStoreProvider.pack`'s spawned workers: a provider that only has per-tile `beam_m`
+    (what a driftscan BeamTransfer offers), served from a memory-mapped store."""
+
+    def __init__(self, tel, path):
+        self.tel, self.path = tel, path
+
+    def __call__(self):
+        from draco_amd.core.products import ArrayProvider, PackedStoreProvider
+
+        st = PackedStoreProvider.open(self.tel, self.path)
+        return ArrayProvider(self.tel, lambda m, f: st.beam_m(m, fi=f))
+
+
 def main():
     import torch
 
@@ -88,8 +102,12 @@ def main():
             tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else None
             with tempfile.TemporaryDirectory(dir=tmpdir) as d:
                 path = os.path.join(d, "b_packed.npy")
+                # this process has run GPU passes: pack() spawns its workers (never forks a process that holds a HIP
+                # context), so they get a picklable factory -- the per-tile provider over a memory-mapped copy
+                src = os.path.join(d, "b_source.npy")
+                np.save(src, pageable.store)
                 t0 = time.perf_counter()
-                packed = PackedStoreProvider.pack(per_tile, path)
+                packed = PackedStoreProvider.pack(per_tile, path, factory=PerTileFromStore(tel, src))
                 t_pack = time.perf_counter() - t0
                 nb = packed.store.size * packed.store.itemsize
                 out["arms"]["per-tile provider: one-time pack"] = {"seconds": t_pack, "b_GB": nb / 1e9, "GBs": nb / t_pack / 1e9, "where": d}
