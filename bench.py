@@ -381,6 +381,13 @@ def dense_flops(cfg, npairs):
 def main_dense(args, cpu):
     """`--maker ml|wiener`: one cfg-3 day through MModeTransform.process + {MaximumLikelihood,Wiener}MapMaker.process
     (single GPU), B tiles resident under the hbm-pool policy, physically structured by default."""
+    out = dense_day(args, args.maker)
+    out["cpu_baseline"] = cpu
+    print(json.dumps(out))
+
+
+def dense_day(args, kind):
+    """The record of `--maker ml|wiener` (also the `extra.ml_day` / `extra.wiener_day` entries of the headline line)."""
     import ctypes as C
 
     import torch
@@ -397,7 +404,6 @@ def main_dense(args, cpu):
     torch.cuda.set_device(0)
     ctx = Context.get()
     cfg = wl.CONFIGS[args.config]
-    kind = args.maker
     for opt in ("ml_reduce", "gram_stage", "wiener_overlap"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
         if os.environ.get("DMM_" + opt.upper()):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt.encode(), int(os.environ["DMM_" + opt.upper()])))
@@ -531,9 +537,9 @@ def main_dense(args, cpu):
         "kernel_classes_ms_per_day_timed": prof,
         "allocator": {"num_alloc_retries": int(mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0)),
                       "reserved_peak_GB": mem1.get("reserved_bytes.all.peak", 0) / 1e9},
-        "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    del task, eng, mt, ss, vis, weight, out_map
+    return out
 
 
 class Job:
@@ -1024,52 +1030,25 @@ def extras(args, cfg, job):
             extra["ml_eigen_ms_per_solve"] = (time.perf_counter() - t0) * 1e3 / (nf_w * (lmax + 1))
         finally:
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
-        # (3b) the same two makers on PHYSICALLY STRUCTURED tiles (BeamScreenProvider: none of them passes the ML certificate,
-        # every tile is eigen-decomposed through the two-stage reduction), 8 frequencies through the task classes;
-        # `python bench.py --maker ml|wiener` is the full-day form of this with rooflines and CPU baselines
-        try:
-            import ctypes as C
-
-            from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker, WienerMapMaker
-            from draco_amd.core.products import BeamScreenProvider
-
-            nf_s = min(8, nfreq)
-            tel_s = TransitTelescope(wl.frequencies(nfreq)[:nf_s], lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
-            bs = BeamScreenProvider(tel_s, seed=3003)
-            per_f = sum(2 * tel_s.npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * 16
-            mm_s = containers.MModes(mmax=lmax, freq=tel_s.frequencies, stack=tel_s.npairs, allocate=False)
-            mm_s.attach("vis", mv1[:, :, :nf_s].contiguous())
-            mm_s.attach("vis_weight", (mw1[:, :, :nf_s] * 20.0).contiguous())
-
-            def counter(name):
-                v = C.c_int64()
-                _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
-                return int(v.value)
-
-            st = {}
-            for kind, cls in (("wiener", WienerMapMaker), ("ml", MaximumLikelihoodMapMaker)):
-                task = cls(nside=64, pool_bytes=nf_s * per_f + (1 << 20))
-                task.setup(bs)
-                task.make_alm(mm_s)  # (generates the tiles: B resident afterwards)
-                ctx.sync()
-                e0, d0 = counter(b"ml_tiles_eigen"), counter(b"ml_tiles_direct")
-                t0 = time.perf_counter()
-                task.make_alm(mm_s)
-                ctx.sync()
-                dt = time.perf_counter() - t0
-                st[kind + "_ms_per_solve"] = dt * 1e3 / (nf_s * (lmax + 1))
-                if kind == "ml":
-                    st["ml_tiles_eigen_decomposed"] = counter(b"ml_tiles_eigen") - e0
-                    st["ml_tiles_certified"] = counter(b"ml_tiles_direct") - d0
-                del task
-            st["sample"] = f"all {lmax + 1} m of {nf_s} frequencies, BeamScreenProvider tiles, B resident"
-            extra["structured_tiles"] = st
-            del bs, mm_s
-        except Exception as e:  # noqa: BLE001
-            extra["structured_tiles"] = {"error": repr(e)[:300]}
         extra["dense_sample"] = f"all {lmax + 1} m of {nf_w} frequencies, B resident"
         del eng2, mv1, mw1, vis1, w1
         _solve.release_pools()
+        # (3b) the same two makers on PHYSICALLY STRUCTURED tiles through the task classes, as `bench.py --maker wiener|ml
+        # --freqs 32` reports them: a 32-frequency sample of the cfg-3 day (scaled to the day, frequencies are
+        # independent) with the SAME roofline objects -- Wiener: Gram + Cholesky over the span of the pass against the
+        # FP64 MFMA peak; ML: the Gram kernel's MFMA fraction, stage 1 of the reduction against the HBM peak, the tile
+        # counters (none of these tiles passes the full-rank certificate: every one is eigen-decomposed)
+        import copy
+
+        for kind in ("wiener", "ml"):
+            try:
+                a2 = copy.copy(args)
+                a2.maker, a2.tiles, a2.freqs, a2.pool_freqs, a2.steps, a2.warmup, a2.b_dtype = kind, "screen", min(32, nfreq), 16, 1, 1, "complex128"
+                rec = dense_day(a2, kind)
+                extra[kind + "_day"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "roofline_secondary", "kernel_classes_ms_per_day_timed", "allocator")}
+            except Exception as e:  # noqa: BLE001
+                extra[kind + "_day"] = {"error": repr(e)[:300]}
+            _solve.release_pools()
         # (4) B = host-stream (SURVEY 8d's second residency policy) THROUGH DirtyMapMaker.process: the tiles of a few
         # frequencies live in pinned host memory in the pool's wire format, nothing is resident on the GPU beforehand;
         # uploads of slab k+1 run under the solves of slab k (two buffers)
