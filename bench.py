@@ -90,11 +90,24 @@ def _cpu_worker(args):
     omm.dirty_solve(tiles[0], v, Ni)
     n = 0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.85 * budget:
+    while time.perf_counter() - t0 < 0.7 * budget:
         for bm in tiles:
             omm.dirty_solve(bm, v, Ni)
             n += 1
-    return n, time.perf_counter() - t0, t_fft
+    t_solve = time.perf_counter() - t0
+    # the same tiles against 16 days at once (one complex128 matrix product per tile: the CPU's way of sharing the read
+    # of B between days, next to the GPU's process_many)
+    D = 16
+    vs = rng.standard_normal((D, 2, npairs)) + 1j * rng.standard_normal((D, 2, npairs))
+    Nis = rng.uniform(0.5, 1.5, (D, 2, npairs))
+    omm.dirty_solve_many(tiles[0], vs, Nis)
+    nm = 0
+    t0 = time.perf_counter()
+    while nm < 1 or time.perf_counter() - t0 < 0.15 * budget:
+        for bm in tiles:
+            omm.dirty_solve_many(bm, vs, Nis)
+            nm += 1
+    return n, t_solve, t_fft, nm * D, time.perf_counter() - t0
 
 
 def _process_arm(nproc, npairs, nra, lmax, ms, budget):
@@ -108,9 +121,10 @@ def _process_arm(nproc, npairs, nra, lmax, ms, budget):
     try:
         with mp.get_context("spawn").Pool(nproc) as pool:
             res = pool.map(_cpu_worker, [(100 + i, npairs, nra, lmax, ms[i % len(ms) :: 3][:6], budget) for i in range(nproc)], chunksize=1)
-        solve_rate = sum(n / t for n, t, _ in res)  # solves per second, all processes together
-        fft_rate = sum(1.0 / tf for _, _, tf in res)  # frequencies per second, all processes together
-        return 1.0 / solve_rate, 1.0 / fft_rate, sum(n for n, _, _ in res)
+        solve_rate = sum(r[0] / r[1] for r in res)  # solves per second, all processes together
+        fft_rate = sum(1.0 / r[2] for r in res)  # frequencies per second, all processes together
+        many_rate = sum(r[3] / r[4] for r in res)  # day-solves per second with 16 days per tile read
+        return 1.0 / solve_rate, 1.0 / fft_rate, sum(r[0] for r in res), 1.0 / many_rate
     finally:
         for k, v_ in saved.items():
             if v_ is None:
@@ -244,13 +258,17 @@ def cpu_baseline(cfg, seconds):
         if nproc <= 1:
             continue
         try:
-            tp, tf, npr = _process_arm(nproc, npairs, nra, lmax, ms, budget)
-            arms[f"{nproc}_processes"] = {"cores": nproc, "ms_per_solve": tp * 1e3, "fft_ms_per_freq": tf * 1e3, "solves": npr}
+            tp, tf, npr, tmany = _process_arm(nproc, npairs, nra, lmax, ms, budget)
+            arms[f"{nproc}_processes"] = {"cores": nproc, "ms_per_solve": tp * 1e3, "fft_ms_per_freq": tf * 1e3, "solves": npr,
+                                          "ms_per_day_solve_16_days_per_tile_read": tmany * 1e3}
         except Exception as e:  # the baseline must never break the bench line
             print(f"cpu_baseline: {nproc}-process arm failed: {e!r}", file=sys.stderr)
     for a in arms.values():
         a["job_seconds"] = a["fft_ms_per_freq"] * 1e-3 * nfreq + a["ms_per_solve"] * 1e-3 * (lmax + 1) * nfreq
         a["m_modes_per_s"] = (lmax + 1) / a["job_seconds"]
+    for a in arms.values():
+        if "ms_per_day_solve_16_days_per_tile_read" in a:  # 16 days per read of B (one zgemm per tile): per day-equivalent
+            a["m_modes_per_s_16_days"] = (lmax + 1) / (a["fft_ms_per_freq"] * 1e-3 * nfreq + a["ms_per_day_solve_16_days_per_tile_read"] * 1e-3 * (lmax + 1) * nfreq)
     best_name = min(arms, key=lambda k: arms[k]["job_seconds"])
     best = arms[best_name]
     return {
@@ -258,6 +276,8 @@ def cpu_baseline(cfg, seconds):
         "unit": "m-modes/s",
         "cores": int(best["cores"]),
         "kind": "port",
+        "many_days": {"value": max((a.get("m_modes_per_s_16_days", 0.0) for a in arms.values()), default=0.0) or None, "unit": "m-modes/s per day-equivalent",
+                      "note": "the process arms again with 16 days per tile read (oracle.dirty_solve_many: one complex128 matrix product B^H [N_d v_d] per tile), the CPU counterpart of extra.many_days / b_host_stream D=16"},
         "sample": f"arm '{best_name}' (fastest of {list(arms)}): {best['solves']} Dirty solves (np.dot c128, full {2*npairs}x{4*(lmax+1)} tiles from RAM pools) + the FFT+pack of whole frequencies, {seconds:.0f}s of wall time over all arms, extrapolated linearly to {(lmax+1)*nfreq} solves + {nfreq} frequencies; alm2map not charged to the CPU time (the GPU step includes it)",
         "host_cores_visible": ncpu,
         "cpu_share": _cpu_share(),
@@ -453,7 +473,7 @@ def dense_day(args, kind):
     eng = task._get_engine()
     fills_before = eng.fills
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
-    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed")}
+    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed", b"ml_tiles_null", b"ml_gram_flops", b"ml_band_bytes")}
     mem0 = torch.cuda.memory_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -464,7 +484,7 @@ def dense_day(args, kind):
     elapsed = time.perf_counter() - t0
     mem1 = torch.cuda.memory_stats()
     prof = {k: {"ms": counter(f"prof_{k}_us".encode()) / 1e3 / args.steps, "spans": counter(f"prof_{k}_n".encode()) // max(args.steps, 1)}
-            for k in ("gram", "chol", "tridiag", "band", "chase", "ql", "backproj", "solve")}
+            for k in ("gram", "chol", "tridiag", "band", "chase", "ql", "backproj", "solve", "null")}
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
     c1 = {k: counter(k) for k in c0}
     assert eng.fills == fills_before or args.warmup == 0, "B was generated inside the timed region"
@@ -474,6 +494,10 @@ def dense_day(args, kind):
     value = (lmax + 1) / (day_s * scale)
     gram_fl, chol_fl = dense_flops(cfg, npairs)
     gram_tf = gram_fl * nfreq / (prof["gram"]["ms"] * 1e-3) / 1e12 if prof["gram"]["ms"] > 0 else None
+    if kind == "ml":  # the library's own count of what it formed (tiles answered by the null certificate never get a Gram matrix)
+        gram_done = (c1[b"ml_gram_flops"] - c0[b"ml_gram_flops"]) / max(args.steps, 1)
+        band_bytes = (c1[b"ml_band_bytes"] - c0[b"ml_band_bytes"]) / max(args.steps, 1)
+        gram_tf = gram_done / (prof["gram"]["ms"] * 1e-3) / 1e12 if prof["gram"]["ms"] > 0 else None
     n_direct = (c1[b"ml_tiles_direct"] - c0[b"ml_tiles_direct"]) // max(args.steps, 1)
     n_eigen = (c1[b"ml_tiles_eigen"] - c0[b"ml_tiles_eigen"]) // max(args.steps, 1)
     secondary = []
@@ -483,13 +507,7 @@ def dense_day(args, kind):
         if prof["band"]["ms"] > 0:
             # stage 1 of the two-stage reduction (k_sb_panel + k_sb_sweep_lo): per panel of 8 columns every 16 x 16 tile of
             # the trailing matrix's lower triangle is read and written once (8 KB) and leaves 0.5 KB of row partials
-            by = 0.0
-            for m in range(lmax + 1):
-                n = -(-min(ntel, 4 * (lmax + 1 - m)) // 64) * 64
-                for k in range(n // 8 - 1):
-                    t = (n - ((8 * (k + 1)) & ~15)) // 16
-                    by += t * (t + 1) / 2 * 8.5 * 1024
-            by *= nfreq * frac_eig
+            by = band_bytes  # (counted by the library per reduced matrix: sum over panels of t (t + 1) / 2 tiles x 8.5 KB)
             ms = prof["band"]["ms"]
             secondary.append({"kernel": "two-stage reduction, stage 1: dense -> band (k_sb_sweep_lo + k_sb_panel)",
                               "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -505,10 +523,10 @@ def dense_day(args, kind):
                               "bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_day": ms,
                               "note": "bytes = n^3/6 * 20 B per decomposed tile (a fraction is only meaningful when every tile went this way)"})
-    gram_note = "useful flops (one Hermitian half-product of the smaller side per tile: 8 k^2 K / 2) / HIP-event time of every Gram launch of the timed day on its launch stream ('profile' option of the library); tiles whose certificate is rejected form their Gram matrix twice, so the fraction is a lower bound then"
+    gram_note = "useful flops (one Hermitian half-product of the smaller side per tile: 8 k^2 K / 2) / HIP-event time of every Gram launch of the timed day on its launch stream ('profile' option of the library); ML: the flops are the library's own count of the Gram matrices it formed (counter ml_gram_flops: a tile whose certificate is rejected counts twice, a tile answered by the null certificate not at all)"
     roofline = {"kernel": "k_nt<GRAM/GRAMX> (Hermitian products D B B^H D / B^H N B on v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma", "achieved": gram_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": gram_tf / 78.6 if gram_tf else None, "traffic": None,
-                "flops_per_day": gram_fl * nfreq_cfg, "ms_per_day_timed": prof["gram"]["ms"], "note": gram_note}
+                "flops_per_day": (gram_done * scale if kind == "ml" else gram_fl * nfreq_cfg), "ms_per_day_timed": prof["gram"]["ms"], "note": gram_note}
     if kind == "wiener" and prof["solve"]["ms"] > 0:
         # dmm_wiener_run keeps two batches in flight on two streams (one's factorisation beside the other's Gram products):
         # the class sums overlap in time, the span of the whole pass is the time the matrix cores were asked for
@@ -530,7 +548,8 @@ def dense_day(args, kind):
             "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}; generated on the GPU in {t_fill:.1f} s before the clock starts",
             "solves_per_s": (lmax + 1) * nfreq / day_s,
             "ms_per_solve": day_s * 1e3 / ((lmax + 1) * nfreq),
-            "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "ql_failed": c1[b"ml_tiles_ql_failed"] - c0[b"ml_tiles_ql_failed"]} if kind == "ml" else None,
+            "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "null_certificate": (c1[b"ml_tiles_null"] - c0[b"ml_tiles_null"]) // max(args.steps, 1),
+                         "ql_failed": c1[b"ml_tiles_ql_failed"] - c0[b"ml_tiles_ql_failed"]} if kind == "ml" else None,
         },
         "roofline": roofline,
         "roofline_secondary": secondary,
@@ -1058,6 +1077,12 @@ def extras(args, cfg, job):
         mm_h = containers.MModes(mmax=lmax, freq=tel_h.frequencies, stack=tel_h.npairs, allocate=False)
         mm_h.attach("vis", torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen))
         mm_h.attach("vis_weight", torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5)
+        mm_more = []
+        for _ in range(15):
+            mm_d = containers.MModes(mmax=lmax, freq=tel_h.frequencies, stack=tel_h.npairs, allocate=False)
+            mm_d.attach("vis", torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen))
+            mm_d.attach("vis_weight", torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5)
+            mm_more.append(mm_d)
         hs = {}
         for b_dtype, npdt in (("complex128", np.complex128), ("complex64", np.complex64)):
             store = PackedStoreProvider.from_provider(SyntheticProvider(tel_h, seed=9), ctx, npdt, pin=True)
@@ -1075,10 +1100,53 @@ def extras(args, cfg, job):
                 best = dt if best is None else min(best, dt)
             nb = t_._get_engine().last_b_bytes
             hs[b_dtype] = {"value": (lmax + 1) / (best * nfreq / nf_h), "unit": "m-modes/s", "h2d_GBs": nb / best / 1e9, "seconds": best, "b_GB": nb / 1e9}
+            # D days per PCIe crossing of B (BaseMapMaker.process_many): per day-equivalent
+            for D in (4, 16):
+                days = [mm_h] + [mm_more[d] for d in range(D - 1)]
+                _solve.release_pools()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                mps = t_.process_many(days)
+                mps[-1].map._dev
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                hs[b_dtype][f"process_many_D{D}"] = {"value": (lmax + 1) * D / (dt * nfreq / nf_h), "unit": "m-modes/s per day-equivalent", "seconds": dt,
+                                                      "h2d_GBs": t_._get_engine().last_b_bytes / dt / 1e9}
+                del mps, days
             del store, t_
-        hs["note"] = f"DirtyMapMaker.process with a PackedStoreProvider over pinned host memory ({nf_h} frequencies' cfg-3 tiles, every byte crosses PCIe, double-buffered under the solves), scaled to the {nfreq}-frequency day"
+        hs["note"] = f"DirtyMapMaker.process with a PackedStoreProvider over pinned host memory ({nf_h} frequencies' cfg-3 tiles, every byte crosses PCIe, double-buffered under the solves), scaled to the {nfreq}-frequency day; process_many_D*: D days share one crossing (each day's a_lm bit-identical to its own pass, tests/test_gpu_process_many.py)"
         extra["b_host_stream"] = hs
+        del mm_more, mm_h
         HostStager.release()
+        _solve.release_pools()
+        # (5) B resident, D days per READ of B: MModeTransform.process per day + DirtyMapMaker.process_many (the Dirty
+        # kernel keeps 8 accumulators per column: 8 days per pass over a slab), 16 frequencies' tiles resident
+        torch.cuda.empty_cache()
+        md = {}
+        pf = 16
+        dmm_ = DirtyMapMaker(nside=nside, pool_bytes=pf * job.per_freq + (1 << 20))
+        bt16 = PoolCycledProvider(SyntheticProvider(job.tel, seed=3003), pf)
+        dmm_.setup(bt16)
+        streams = [job.ss]
+        for d in range(7):
+            s_ = containers.SiderealStream(freq=job.tel.frequencies, ra=nra, stack=job.npairs, allocate=False)
+            s_.attach("vis", torch.randn((nfreq, job.npairs, nra), dtype=torch.complex64, device=ctx.device, generator=gen))
+            s_.attach("vis_weight", torch.rand((nfreq, job.npairs, nra), dtype=torch.float32, device=ctx.device, generator=gen) + 0.5)
+            streams.append(s_)
+        for D in (1, 8):
+            dmm_.process_many([job.mt.process(s_) for s_ in streams[:D]])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                mps = dmm_.process_many([job.mt.process(s_) for s_ in streams[:D]])
+            mps[-1].map._dev
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            md[f"D{D}"] = {"value": (lmax + 1) * D / dt, "unit": "m-modes/s per day-equivalent", "seconds_per_group": dt}
+            del mps
+        md["note"] = f"B resident ({pf} frequencies' distinct tiles), {nfreq}-frequency days: MModeTransform.process per day + DirtyMapMaker.process_many (dmm_dirty_run_multi: D days per read of every tile; alm2map of every day included)"
+        extra["many_days"] = md
+        del streams, dmm_
         _solve.release_pools()
     except Exception as e:  # secondary numbers must never break the headline line
         import traceback

@@ -78,6 +78,7 @@ _SIGS = {
     "dmm_plan_destroy": (_i, [_vp]),
     "dmm_plan_b_bytes": (_i64, [_vp]),
     "dmm_dirty_run": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "dmm_dirty_run_multi": (_i, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i]),
     "dmm_wiener_workspace_bytes": (_i64, [_vp]),
     "dmm_wiener_run": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
     "dmm_ml_workspace_bytes": (_i64, [_vp]),

@@ -356,6 +356,69 @@ class SolveEngine:
         self._ws = None
         return alm
 
+    def solve_many(self, kind, mvis_l, mweight_l, freq_ind, mmax, on_freqs_done=None, **params):
+        """D sidereal days against ONE pass over B: a list of ``alm`` as :meth:`solve` returns them, one per day.
+
+        Every slab of B is made resident once (one PCIe crossing for providers whose tiles live on the host) and
+        serves all D days before the next slab replaces it.  ``"dirty"``: ``dmm_dirty_run_multi`` -- up to eight days
+        share every tile READ too (the kernel keeps eight accumulators per column), each day bit-identical to its
+        own :meth:`solve`.  ``"wiener"`` / ``"ml"``: the Gram matrices depend on the day's noise weights, so the days
+        run one after the other inside the slab.  ``on_freqs_done(d, alm_d, f0, f1)`` as in :meth:`solve`, per day.
+        """
+        tel = self.provider.telescope
+        D = len(mvis_l)
+        if D == 0:
+            return []
+        if len(mweight_l) != D:
+            raise ValueError("solve_many: one weight array per day")
+        shape = tuple(mvis_l[0].shape)
+        for v, w in zip(mvis_l, mweight_l):
+            if tuple(v.shape) != shape or tuple(w.shape) != shape:
+                raise ValueError("solve_many: every day must have the same [m, msign, freq, stack] shape")
+        n_m_data, _, nfreq, npairs = shape
+        if npairs != tel.npairs:
+            raise ValueError(f"m-modes have {npairs} baselines, the beam transfers {tel.npairs}")
+        n_m = mmax + 1
+        alms = [torch.empty((nfreq, tel.num_pol_sky, n_m, tel.lmax + 1), dtype=torch.complex128, device=self.ctx.device) for _ in range(D)]
+        self.last_b_bytes = 0
+        self._ws_offer = {}
+        self._ws = None
+        lib = _lib.lib
+        PA = C.c_void_p * D
+        pv, pw, pa = PA(*[ptr(x) for x in mvis_l]), PA(*[ptr(x) for x in mweight_l]), PA(*[ptr(x) for x in alms])
+        issued, f_done = 0, 0
+        for slab in self.slabs(freq_ind, mmax, nfreq, n_m):
+            self.last_b_bytes += slab.b_bytes
+            if kind == "dirty":
+                if self.launch_events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _lib.check(lib.dmm_dirty_run_multi(slab.plan, ptr(slab.pool), pv, pw, pa, D))
+                if self.launch_events is not None:
+                    e1.record()
+                    self.launch_events.append((e0, e1, slab.b_bytes, slab.ntile))
+            elif kind == "wiener":
+                self._offer_workspace(b"wiener_workspace_mib", 24 << 10)
+                ws = self._workspace(int(lib.dmm_wiener_workspace_bytes(slab.plan)))
+                for d in range(D):
+                    _lib.check(lib.dmm_wiener_run(slab.plan, ptr(slab.pool), ptr(mvis_l[d]), ptr(mweight_l[d]), float(params["prior_amp"]),
+                                                  float(params["prior_tilt"]), ptr(ws), ptr(alms[d])))
+            elif kind == "ml":
+                self._offer_workspace(b"ml_workspace_mib", 64 << 10)
+                ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
+                for d in range(D):
+                    _lib.check(lib.dmm_ml_run(slab.plan, ptr(slab.pool), ptr(mvis_l[d]), ptr(mweight_l[d]), float(params.get("acond", 1e-4)),
+                                              float(params.get("rcond", 1e-3)), ptr(ws), ptr(alms[d])))
+            else:
+                raise ValueError(kind)
+            issued += slab.ntile
+            if on_freqs_done is not None and issued // n_m > f_done:
+                for d in range(D):
+                    on_freqs_done(d, alms[d], f_done, issued // n_m)
+                f_done = issued // n_m
+        self._ws = None
+        return alms
+
     def _workspace(self, nbytes):
         """The pass's workspace: one allocation, reused by every slab it is large enough for (the library drains its
         own streams before a run returns, and the caller's stream orders the slabs)."""

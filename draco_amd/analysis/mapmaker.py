@@ -177,6 +177,82 @@ class BaseMapMaker(ContainerTask):
         m.attach("map", maps, pending=pending)
         return m
 
+    def process_many(self, mmodes_list):
+        """Maps of D sidereal days from ONE pass over the beam transfers: ``[process(mm) for mm in mmodes_list]``, with
+        every slab of B brought in once for all of them.  Not a reference method: the reference's pipeline calls
+        ``process`` once per item (``doc/tutorial.rst:110-120``, the loop at ``mapmaker.py:79-94``) and reads every
+        ``beam_m`` again each time; real processing applies one set of beam transfers to many days.
+
+        With B streamed from the host the PCIe crossing (56 GB/s: 28 s per cfg-3 day) is shared by the D days; with B
+        resident ``DirtyMapMaker`` also shares every tile READ between up to eight days (``dmm_dirty_run_multi``).
+        All days must have the same frequencies and m range.  Each day's a_lm equals its single-day ``process`` bit for
+        bit.  HBM: every day in the group holds its own a_lm and maps (10.7 GB at cfg 3).
+        """
+        mmodes_list = list(mmodes_list)
+        if not mmodes_list:
+            return []
+        bt = self.beamtransfer
+        if type(self)._solve_m not in _BUILTIN_SOLVERS or bt.telescope.num_pol_sky != 4:
+            return [self.process(mm) for mm in mmodes_list]
+        first = mmodes_list[0]
+        for mm in mmodes_list[1:]:
+            if len(mm.index_map["m"]) != len(first.index_map["m"]) or not np.array_equal(mm.index_map["freq"]["centre"], first.index_map["freq"]["centre"]):
+                raise ValueError("process_many: every day must cover the same frequencies and m range")
+        lmax = bt.telescope.lmax
+        ctx = Context.get()
+        nside = int(self.nside)
+        npix = 12 * nside**2
+        # run-ahead in DAYS, not calls: a group of D days holds D sets of a_lm and maps, so at most
+        # days_in_flight // D earlier groups (none for D > days_in_flight / 2) may still be running when this one is queued
+        _bound_run_ahead(ctx, max(int(self.days_in_flight) // len(mmodes_list), 1))
+        overlap = (str(self.b_dtype) != "complex64") if self.overlap_sht is None else bool(self.overlap_sht)
+        side = Context.side(ctx.device_index) if overlap else ctx
+        main = torch.cuda.current_stream(ctx.device)
+        maps = {}
+
+        def sht_of(d, alm, f0, f1):
+            nfreq, _, n_m, _ = alm.shape
+            if d not in maps:
+                maps[d] = ctx.empty((nfreq, 4, npix), np.float64)
+            if overlap:
+                if d == 0:
+                    side.wait_for(main)
+                side.uses(alm, maps[d])
+            _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(maps[d][f0:f1])))
+
+        alms = self.make_alm_many(mmodes_list, on_freqs_done=sht_of)
+        pending = None
+        if overlap and maps:
+            pending = StreamDone(side.stream, ctx.device)
+            side.release_held()
+        _IN_FLIGHT.setdefault(ctx.device_index, collections.deque()).append(
+            pending if pending is not None else StreamDone(torch.cuda.current_stream(ctx.device), ctx.device))
+        out = []
+        for d, mm in enumerate(mmodes_list):
+            mp = maps.get(d)
+            if mp is None:  # no frequencies on this rank
+                mp = ctx.empty((alms[d].shape[0], 4, npix), np.float64)
+            m = containers.Map(nside=self.nside, axes_from=mm, comm=mm.comm, allocate=False)
+            m.attach("map", mp, pending=pending)
+            out.append(m)
+        return out
+
+    def make_alm_many(self, mmodes_list, on_freqs_done=None):
+        """The a_lm of D days from one pass over B (see :meth:`process_many`): a list of device arrays as
+        :meth:`make_alm` returns them."""
+        bt = self.beamtransfer
+        first = mmodes_list[0]
+        mmax = min(bt.telescope.mmax, len(first.index_map["m"]) - 1)
+        freq_ind = tools.find_keys(bt.telescope.frequencies, first.index_map["freq"]["centre"], require_match=True)
+        eng = self._get_engine()
+        ctx = eng.ctx
+        mv, mw = [], []
+        for mm in mmodes_list:
+            mm.redistribute("freq")
+            mv.append(_dev_dataset(mm.vis, ctx, np.complex128))
+            mw.append(_dev_dataset(mm.weight, ctx, np.float64))
+        return eng.solve_many(self._kind, mv, mw, freq_ind, mmax, on_freqs_done=on_freqs_done, **self._solve_params())
+
     def _host_loop(self, mmodes):
         """A subclass overrode ``_solve_m``: honour the hook with the reference's loop (:79-94)."""
         bt = self.beamtransfer

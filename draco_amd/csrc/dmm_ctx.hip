@@ -14,7 +14,7 @@ int dmm_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-static const char* const kProfNames[DMM_PROF_NSLOT] = {"gram", "chol", "tridiag", "ql", "backproj", "band", "chase", "solve"};
+static const char* const kProfNames[DMM_PROF_NSLOT] = {"gram", "chol", "tridiag", "ql", "backproj", "band", "chase", "solve", "null"};
 
 // read every finished span into the per-class sums (waits for spans still running)
 static void prof_collect(dmm_ctx* c) {
@@ -128,6 +128,7 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_outer_sweeps")) c->opt_ml_outer_sweeps = (int)value;
   else if (!strcmp(name, "sht_variant")) c->opt_sht_variant = (int)value;
   else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
+  else if (!strcmp(name, "ml_null")) c->opt_ml_null = (int)value;
   else if (!strcmp(name, "ml_eigen")) c->opt_ml_eigen = (int)value;
   else if (!strcmp(name, "ringmap_variant")) c->opt_ringmap_variant = (int)value;
   else if (!strcmp(name, "ml_reduce")) c->opt_ml_reduce = (int)value;
@@ -148,6 +149,9 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   DMM_REQUIRE(c != nullptr && name != nullptr && value != nullptr, "dmm_ctx_get_counter: NULL argument");
   if (!strcmp(name, "ml_tiles_direct")) *value = c->ml_tiles_direct;
   else if (!strcmp(name, "ml_tiles_eigen")) *value = c->ml_tiles_eigen;
+  else if (!strcmp(name, "ml_tiles_null")) *value = c->ml_tiles_null;
+  else if (!strcmp(name, "ml_gram_flops")) *value = c->ml_gram_flops;
+  else if (!strcmp(name, "ml_band_bytes")) *value = c->ml_band_bytes;
   else if (!strcmp(name, "ml_tiles_ql_failed")) *value = c->ml_tiles_ql_failed;
   else if (!strcmp(name, "ml_early_chunks")) *value = c->ml_early_chunks;
   else if (!strncmp(name, "prof_", 5)) {

@@ -18,7 +18,7 @@ struct dmm_fft_tables {          // per transform length, built on first use
 
 // Kernel classes of the dense solvers that bench.py times live (HIP events on the stream a class is launched on;
 // "profile" option of dmm_ctx_set_option, read back through dmm_ctx_get_counter("prof_<class>_us" / "prof_<class>_n")).
-enum dmm_prof_slot { DMM_PROF_GRAM = 0, DMM_PROF_CHOL, DMM_PROF_TRIDIAG, DMM_PROF_QL, DMM_PROF_BACKPROJ, DMM_PROF_BAND, DMM_PROF_CHASE, DMM_PROF_SOLVE, DMM_PROF_NSLOT };
+enum dmm_prof_slot { DMM_PROF_GRAM = 0, DMM_PROF_CHOL, DMM_PROF_TRIDIAG, DMM_PROF_QL, DMM_PROF_BACKPROJ, DMM_PROF_BAND, DMM_PROF_CHASE, DMM_PROF_SOLVE, DMM_PROF_NULL, DMM_PROF_NSLOT };
 struct dmm_prof_span {
   hipEvent_t a, b;
   int slot;
@@ -47,6 +47,9 @@ struct dmm_ctx {
   int opt_ml_eigen = 0;                    // 0: by batch size (tridiagonalisation + QL for large batches, blocked Jacobi for a few matrices); 1: Jacobi; 4: tridiagonal; 2: tridiagonal with full-matrix trailing updates; 3: tridiagonal with QL made to give up (Jacobi fallback)
   int64_t opt_ml_ws_mib = 0, opt_wiener_ws_mib = 0;  // workspace the ML / Wiener solves size themselves for (0: 20 / 6 GiB)
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
+  int opt_ml_null = 0;                     // 1: no null certificate (tiles whose Frobenius norm puts every singular value below acond are decomposed like any other)
+  int64_t ml_gram_flops = 0, ml_band_bytes = 0;  // counters: useful flops of the ML Gram launches (4 k^2 K per tile), algorithmic bytes of stage 1 of the two-stage reduction (8.5 KB per lower-triangle tile and panel)
+  int64_t ml_tiles_null = 0;               // counter: tiles the null certificate answered with zero
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
   int64_t ml_tiles_ql_failed = 0;          // ... of the latter: QL gave up, the tile was redone by the Jacobi solver
   int opt_ringmap_variant = 0;             // 1: always the three-kernel form of the ring-map maker (A/B, tests)
@@ -56,8 +59,8 @@ struct dmm_ctx {
   double* ml_diag = nullptr;               // dmm_ctx_set_ml_diag: [nfreq][n_m][4] rank / sigma record of the eigen-decomposed ML tiles (validation)
   int opt_profile = 0;                     // 1: dmm_prof_scope records event pairs (bench.py's live kernel timing)
   std::vector<dmm_prof_span> prof_open;    // spans whose events have not been read yet
-  double prof_us[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int64_t prof_n[DMM_PROF_NSLOT] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double prof_us[DMM_PROF_NSLOT] = {};
+  int64_t prof_n[DMM_PROF_NSLOT] = {};
   int64_t ml_early_chunks = 0;             // reject chunks decomposed on the end-of-workspace slots under the direct batches
   unsigned long long* ticket = nullptr;    // ring of task counters for the dirty kernel's dynamic hand-out
   unsigned ticket_seq = 0;

@@ -335,6 +335,56 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
   }
 }
 
+// ---- ML, null certificate.  pinv_svd keeps sigma > acond (mapmaker.py:296): a tile whose LARGEST singular value is at
+// most acond keeps nothing and its solution is exactly zero.  sigma_max^2 <= trace(G) = sum_i Ni_i sum_j |B_ij|^2 (the
+// squared Frobenius norm of D B), and that costs one pass over the tile -- no Gram matrix, no decomposition.  Beam
+// transfers beyond the m a telescope's east-west extent can see are numerically empty; on the structured tiles of
+// bench.py --maker ml that is every tile above m ~ 300, two fifths of the day's tiles.
+// grid (ntile, kTraceSplit): a block sums the rows of its split, lanes along the contiguous packed row.
+constexpr int kTraceSplit = 4;
+__global__ __launch_bounds__(kThreads) void k_ml_trace(const dmm_tile* __restrict__ tiles, DenseParams p, double* __restrict__ trace) {
+  const dmm_tile tile = tiles[blockIdx.x];
+  const int L = p.lmax + 1 - tile.m;
+  const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+  const int col0 = p.full_layout ? tile.m : 0;
+  const int64_t row_stride = (int64_t)p.npol * pol_stride;
+  const int ntel = 2 * p.npairs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = (int)((int64_t)ntel * blockIdx.y / kTraceSplit), r1 = (int)((int64_t)ntel * (blockIdx.y + 1) / kTraceSplit);
+  double acc = 0.0;
+  for (int i = r0 + wave; i < r1; i += kThreads / 64) {
+    const int s = i >= p.npairs, pp = i - s * p.npairs;
+    const double ni = p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp];
+    if (ni == 0.0) continue;  // (wave-uniform)
+    double rs = 0.0;
+    for (int pol = 0; pol < p.npol; ++pol) {
+      const int64_t base = tile.b_off + (int64_t)i * row_stride + (int64_t)pol * pol_stride + col0;
+#pragma unroll 4
+      for (int l = lane; l < L; l += 64) {
+        const double2 b = load_bc(p.B, p.b_c128, base + l);
+        rs = fma(b.x, b.x, fma(b.y, b.y, rs));
+      }
+    }
+    acc = fma(ni, rs, acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ double part[kThreads / 64];
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(trace + blockIdx.x, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// a_lm of the tiles in `list` := 0 (l >= m columns; the caller's array may hold anything)
+__global__ __launch_bounds__(kThreads) void k_zero_alm_tiles(const dmm_tile* __restrict__ tiles, const int32_t* __restrict__ list, DenseParams p, double2* __restrict__ alm) {
+  const dmm_tile tile = tiles[list[blockIdx.x]];
+  const int nl = p.lmax + 1;
+  for (int idx = threadIdx.x; idx < p.npol * nl; idx += kThreads) {
+    const int pol = idx / nl, l = idx - pol * nl;
+    alm[(((int64_t)tile.f * p.npol + pol) * p.n_m + tile.m) * nl + l] = make_double2(0.0, 0.0);
+  }
+}
+
 __global__ void k_prior(double* Sl, int lmax, double amp, double tilt) {
   for (int l = blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
     const double dl = l == 0 ? 1.0 : (double)l;  // mapmaker.py:261: l[0] = 1
@@ -698,14 +748,64 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   int* const any_rot_d = (int*)q;
 
   const int ntel = 2 * pl->npairs;
+  // bookkeeping for bench.py's rooflines: useful flops of a Gram launch, algorithmic bytes of a stage-1 reduction
+  auto count_gram = [&](const dmm_tile* tl, int nmat) {
+    for (int i = 0; i < nmat; ++i) {
+      const double nsky = (double)pl->npol * (pl->lmax + 1 - tl[i].m);
+      const double k = std::min<double>(ntel, nsky), K = std::max<double>(ntel, nsky);
+      ctx->ml_gram_flops += (int64_t)(4.0 * k * k * K);
+    }
+  };
+  auto count_band = [&](int n, int nmat) {
+    double by = 0.0;
+    for (int k = 0; k < n / 8 - 1; ++k) {
+      const double t = (n - ((8 * (k + 1)) & ~15)) / 16;
+      by += t * (t + 1) / 2 * 8.5 * 1024;
+    }
+    ctx->ml_band_bytes += (int64_t)(by * nmat);
+  };
   const bool shortcut = ctx->opt_ml_shortcut != 2;  // 2: always take the eigen path (tests, timing)
   const int max_sweeps = ctx->opt_ml_outer_sweeps > 0 ? ctx->opt_ml_outer_sweeps : 60;
   const int inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;  // tools/ml_tune.py
 
+  // Null certificate (k_ml_trace): tiles whose Frobenius norm says that EVERY singular value is at or below acond keep
+  // nothing under pinv_svd's rule -- their a_lm is zero and they never see a Gram matrix.  One pass over B; the scratch
+  // is the workspace header (the prior tables of the Wiener solve: unused here).  "ml_null" = 1 switches it off.
+  std::vector<char> is_null(pl->ntile, 0);
+  if (ctx->opt_ml_null == 0 && acond > 0.0 && (size_t)pl->ntile * (sizeof(double) + sizeof(int32_t)) <= L.header) {
+    double* const trace_d = (double*)ws;
+    int32_t* const null_d = (int32_t*)(trace_d + pl->ntile);
+    DMM_HIP(hipMemsetAsync(trace_d, 0, pl->ntile * sizeof(double), ctx->stream));
+    {
+      dmm_prof_scope prof(ctx, DMM_PROF_NULL, ctx->stream);
+      hipLaunchKernelGGL(k_ml_trace, dim3((unsigned)pl->ntile, kTraceSplit), dim3(kThreads), 0, ctx->stream, pl->tiles_d, base, trace_d);
+    }
+    DMM_HIP(hipGetLastError());
+    std::vector<double> trace_h(pl->ntile);
+    DMM_HIP(hipMemcpyAsync(trace_h.data(), trace_d, pl->ntile * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DMM_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> null_h;
+    // (the sum is exact to a few ulp; the margin keeps a tile AT the threshold on the decomposing side, where the cut
+    // is decided on the eigenvalues themselves)
+    const double lim = acond * acond * (1.0 - 1e-9);
+    for (int64_t t = 0; t < pl->ntile; ++t)
+      if (trace_h[t] <= lim) {
+        is_null[t] = 1;
+        null_h.push_back((int32_t)t);
+      }
+    if (!null_h.empty()) {
+      DMM_HIP(hipMemcpyAsync(null_d, null_h.data(), null_h.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_zero_alm_tiles, dim3((unsigned)null_h.size()), dim3(kThreads), 0, ctx->stream, pl->tiles_d, null_d, base, (double2*)alm);
+      DMM_HIP(hipGetLastError());
+      DMM_HIP(hipStreamSynchronize(ctx->stream));  // null_h dies with this block
+      ctx->ml_tiles_null += (int64_t)null_h.size();
+    }
+  }
   // the smaller Gram matrix of each tile: telescope side (any m) or sky side (tiles of one m share an order)
   std::vector<int64_t> tel_list;
   std::map<int, std::vector<int64_t>> sky_lists;
   for (int64_t t = 0; t < pl->ntile; ++t) {
+    if (is_null[t]) continue;
     const int m = pl->tiles_h[t].m;
     const int nsky = pl->npol * (pl->lmax + 1 - m);
     if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);  // 3: telescope side only
@@ -790,6 +890,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const bool lower_only = cert_only && rs_lds <= 40 * 1024;
     auto form_gram = [&](bool mirror = true) {
       dmm_prof_scope prof(ctx, DMM_PROF_GRAM, ctx->stream);
+      count_gram(tiles_c.data(), nmat);
       if (sky) {
         hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, ctx->stream, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, ctx->stream, p);
@@ -872,6 +973,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         if (tp.two_stage) {
           {
             dmm_prof_scope prof(ctx, DMM_PROF_BAND, ctx->stream);
+            count_band(n, nsel);
             sb_reduce(tp, nsel, ctx->stream);
           }
           dmm_prof_scope prof(ctx, DMM_PROF_CHASE, ctx->stream);
@@ -1043,6 +1145,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const int T = p.T, n = p.Np;
     {
       dmm_prof_scope prof(ctx, DMM_PROF_GRAM, S1);
+      count_gram(H.tiles.data(), nmat);
       if (sky) {
         p.ldx = ntel;
         p.X = Vb;
@@ -1074,6 +1177,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
     if (tp.two_stage) {
       dmm_prof_scope prof(ctx, DMM_PROF_BAND, S1);
+      count_band(n, nmat);
       sb_reduce(tp, nmat, S1);
     } else {
       dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, S1);

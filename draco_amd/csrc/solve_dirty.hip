@@ -233,6 +233,144 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
   }
 }
 
+// ND sidereal days against ONE read of B: a_d = B^H (Ni_d o v_d), d < ND (BaseMapMaker.process_many; the reference
+// calls mapmaker.py:79-94 once per pipeline item against the same beam transfers).  Same decomposition as k_dirty -- a
+// block = one tile x 256*CPL adjacent columns, every wave-load one contiguous 1 KiB piece of a B row -- with ND complex
+// accumulators per column and w = Ni o v of the ND days side by side in LDS ([ntel][ND], wave-uniform broadcasts).
+// Per 16 bytes of B: 4 ND f64 FMAs instead of 4, so the kernel leaves the HBM roofline for the FP64 one near ND = 16;
+// the row loop is the pipelined one (the next group's loads fly under this group's 32 ND FMAs).  Every day's column
+// is accumulated over the rows in the same order by the same FMA chain as k_dirty: the results are bit-identical to
+// ND single-day launches.
+template <int ND>
+struct MultiPtrs {
+  const double2* mvis[ND];
+  const double* mweight[ND];
+  double2* alm[ND];
+};
+
+template <typename BT, int CPL, int ND, bool NT, int kUnroll>
+__global__ __launch_bounds__(kThreads) void k_dirty_multi(SolveParams p, const BT* __restrict__ B, MultiPtrs<ND> q) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double2* w = reinterpret_cast<double2*>(smem);  // [ntel][ND]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntel = p.ntel, npairs = p.npairs;
+
+  __shared__ unsigned long long s_next;
+  for (int64_t work0 = blockIdx.x;; work0 += gridDim.x) {
+    if (p.ticket) {
+      if (threadIdx.x == 0) s_next = atomicAdd(p.ticket, 1ull);
+      __syncthreads();
+      work0 = (int64_t)s_next;
+    }
+    if (work0 >= p.nwork) break;
+    const int64_t t = find_tile(p.work_start, p.ntile, work0);
+    const dmm_tile tile = p.tiles[t];
+    const int cb = (int)(work0 - p.work_start[t]);
+    const int m = tile.m, f = tile.f;
+    const int L = p.lmax + 1 - m;
+    const int ncol = p.npol * L;
+    const int pol_stride = p.full_layout ? p.lmax + 1 : L;
+    const int col0 = p.full_layout ? m : 0;
+    const int64_t row_stride = (int64_t)p.npol * pol_stride;
+
+    __syncthreads();  // previous task's readers of w are done
+    // (all ND days of a baseline by one thread, their 2 ND loads in flight together: ntel / 256 rounds of memory
+    // latency per task whatever ND -- one day after the other it was ND times that, a third of the task's time at ND = 8)
+    for (int i = threadIdx.x; i < ntel; i += kThreads) {
+      const int s = i >= npairs, pp = i - s * npairs;
+      const int64_t o = (((int64_t)m * 2 + s) * p.nfreq + f) * npairs + pp;
+      double2 v[ND];
+      double ni[ND];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) {
+        v[d] = q.mvis[d][o];
+        ni[d] = q.mweight[d][o];
+      }
+#pragma unroll
+      for (int d = 0; d < ND; ++d) w[i * ND + d] = make_double2(ni[d] * v[d].x, ni[d] * v[d].y);
+    }
+    __syncthreads();
+
+    if (cb == 0)
+      for (int idx = threadIdx.x; idx < p.npol * m; idx += kThreads) {
+        const int pol = idx / m, l = idx - pol * m;
+        const int64_t o = (((int64_t)f * p.npol + pol) * p.n_m + m) * (p.lmax + 1) + l;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) q.alm[d][o] = make_double2(0.0, 0.0);
+      }
+
+    const int jbase = (cb * kWaves + wave) * 64 * CPL + lane * CPL;
+    if (jbase >= ncol) continue;
+
+    int64_t off[CPL];
+    bool ok[CPL];
+    int opol[CPL], ol[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int j = jbase + c;
+      ok[c] = j < ncol;
+      const int jj = ok[c] ? j : ncol - 1;
+      opol[c] = jj / L;
+      const int lrel = jj - opol[c] * L;
+      ol[c] = m + lrel;
+      off[c] = tile.b_off + (int64_t)opol[c] * pol_stride + col0 + lrel;
+    }
+    double are[ND][CPL], aim[ND][CPL];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) are[d][c] = aim[d][c] = 0.0;
+
+    typedef typename RawOf<BT, CPL>::type Raw;
+    auto consume = [&](const Raw& r, int row) __attribute__((always_inline)) {
+      const double2* wr = w + row * ND;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) accumulate<BT, CPL>(r, wr[d], are[d], aim[d]);
+    };
+    int i = 0;
+    if (ntel >= kUnroll) {
+      Raw ra[kUnroll], rb[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) ra[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)u * row_stride);
+      for (; i + 3 * kUnroll <= ntel; i += 2 * kUnroll) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) rb[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + kUnroll + u) * row_stride);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) consume(ra[u], i + u);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) ra[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + 2 * kUnroll + u) * row_stride);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) consume(rb[u], i + kUnroll + u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i + 2 * kUnroll <= ntel) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) rb[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + kUnroll + u) * row_stride);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) consume(ra[u], i + u);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) consume(rb[u], i + kUnroll + u);
+        i += 2 * kUnroll;
+      } else {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) consume(ra[u], i + u);
+        i += kUnroll;
+      }
+    }
+    for (; i < ntel; ++i) consume(load_raw<BT, CPL, NT>(B, off, (int64_t)i * row_stride), i);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+      if (ok[c]) {
+        const int64_t o = (((int64_t)f * p.npol + opol[c]) * p.n_m + m) * (p.lmax + 1) + ol[c];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) q.alm[d][o] = make_double2(are[d][c], aim[d][c]);
+      }
+  }
+}
+
 // v[i] = sum_{pol,l} B[i, pol, l] * a[pol, l]: one wave per row, lanes across the
 // contiguous row (coalesced), shuffle reduction; a (<= 64 KB) staged in LDS per block.
 template <typename BT, bool NT = false, int UNR = 4>
@@ -469,6 +607,37 @@ int launch_dirty(dmm_plan* pl, const SolveParams& p_in, const void* B, const dou
   return DMM_OK;
 }
 
+template <int ND>
+int launch_dirty_multi(dmm_plan* pl, const void* B, const void* const* mvis, const double* const* mweight, void* const* alm) {
+  dmm_ctx* ctx = pl->ctx;
+  SolveParams p = base_params(pl);
+  const size_t lds = (size_t)p.ntel * ND * sizeof(double2);
+  int64_t grid = (int64_t)ctx->num_cu * (ctx->opt_grid_mult > 0 ? ctx->opt_grid_mult : 1);
+  if (grid > p.nwork) grid = p.nwork;
+  if (grid <= 0) return DMM_OK;
+  if (ctx->opt_dirty_static == 0) {
+    DMM_HIP(dmm_ticket(ctx, &p.ticket));
+    DMM_HIP(hipMemsetAsync(p.ticket, 0, sizeof(unsigned long long), ctx->stream));
+  }
+  MultiPtrs<ND> q;
+  for (int d = 0; d < ND; ++d) {
+    q.mvis[d] = (const double2*)mvis[d];
+    q.mweight[d] = mweight[d];
+    q.alm[d] = (double2*)alm[d];
+  }
+#define DMM_LAUNCH_DIRTY_MULTI(KERN, BTYPE)                                                                     \
+  do {                                                                                                          \
+    auto k = KERN;                                                                                              \
+    DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const BTYPE*)B, q);       \
+  } while (0)
+  if (pl->b_dtype == DMM_C128) DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<double2, 1, ND, true, 8>), double2);
+  else if (pl->pair_ok) DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<float2, 2, ND, true, 8>), float2);
+  else DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<float2, 1, ND, true, 8>), float2);
+  DMM_HIP(hipGetLastError());
+  return DMM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -555,6 +724,34 @@ int dmm_dirty_run(dmm_plan* pl, const void* B, const void* mvis, const double* m
   DMM_HIP(hipSetDevice(ctx->device));
   SolveParams p = base_params(pl);
   return launch_dirty<false>(pl, p, B, (const double2*)mvis, mweight, (double2*)alm);
+}
+
+int dmm_dirty_run_multi(dmm_plan* pl, const void* B, const void* const* mvis, const double* const* mweight, void* const* alm, int nday) {
+  DMM_REQUIRE(pl && B && mvis && mweight && alm, "dmm_dirty_run_multi: NULL argument");
+  DMM_REQUIRE(nday >= 1, "dmm_dirty_run_multi: nday = %d", nday);
+  DMM_REQUIRE(((uintptr_t)B & 15) == 0, "dmm_dirty_run_multi: B must be 16-byte aligned");
+  for (int d = 0; d < nday; ++d) {
+    DMM_REQUIRE(mvis[d] && mweight[d] && alm[d], "dmm_dirty_run_multi: NULL array of day %d", d);
+    DMM_REQUIRE(((uintptr_t)mvis[d] & 15) == 0 && ((uintptr_t)alm[d] & 15) == 0, "dmm_dirty_run_multi: mvis and alm of day %d must be 16-byte aligned", d);
+    for (int e = 0; e < d; ++e) DMM_REQUIRE(alm[e] != alm[d], "dmm_dirty_run_multi: days %d and %d share their alm", e, d);
+  }
+  if (pl->ntile == 0) return DMM_OK;
+  dmm_ctx* ctx = pl->ctx;
+  DMM_HIP(hipSetDevice(ctx->device));
+  // groups of 8, 4, 2 days per read of B (8 days' w = Ni o v take 8 x 12 KB of LDS at cfg 3); a last single day goes
+  // through the one-day kernel
+  const int nd_max = (size_t)2 * pl->npairs * 8 * sizeof(double2) <= 128 * 1024 ? 8 : ((size_t)2 * pl->npairs * 4 * sizeof(double2) <= 128 * 1024 ? 4 : 2);
+  int d = 0;
+  while (d < nday) {
+    const int left = nday - d;
+    int rc;
+    if (left >= 8 && nd_max >= 8) { rc = launch_dirty_multi<8>(pl, B, mvis + d, mweight + d, alm + d); d += 8; }
+    else if (left >= 4 && nd_max >= 4) { rc = launch_dirty_multi<4>(pl, B, mvis + d, mweight + d, alm + d); d += 4; }
+    else if (left >= 2) { rc = launch_dirty_multi<2>(pl, B, mvis + d, mweight + d, alm + d); d += 2; }
+    else { SolveParams p = base_params(pl); rc = launch_dirty<false>(pl, p, B, (const double2*)mvis[d], mweight[d], (double2*)alm[d]); d += 1; }
+    if (rc) return rc;
+  }
+  return DMM_OK;
 }
 
 int dmm_project_run(dmm_plan* pl, const void* B, const void* alm_in, void* vis_out) {

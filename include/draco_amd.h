@@ -76,6 +76,9 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * "ml_eigen" (eigen path of the ML solve: 0 = chosen by batch size; 4 = Householder tridiagonalisation + QL kept
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give
  * up on every other matrix, which exercises the Jacobi fallback),
+ * "ml_null" (0, default: a tile whose weighted Frobenius norm puts EVERY singular value at or below acond is answered
+ * with zero -- what pinv_svd's rule gives -- without a Gram matrix or a decomposition; 1: such tiles are decomposed
+ * like any other, with the same result),
  * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies),
  * "ml_reduce" (tridiagonal reduction of the eigen path: 0 = two-stage, dense -> band of half-width 8 on the matrix
  * cores over the lower triangle -> tridiagonal by bulge chasing in LDS, for orders whose band fits the LDS, one-stage
@@ -89,13 +92,16 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * solvers with HIP events on their launch streams, sums cleared; 0: off) */
 int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
 /* diagnostics counters, cumulative per context: "ml_tiles_direct" (tiles whose pseudo-inverse was
- * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed), "ml_tiles_ql_failed"
+ * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed), "ml_tiles_null" (tiles answered with zero by the null certificate: every
+ * singular value at or below acond), "ml_gram_flops" / "ml_band_bytes" (useful flops 4 k^2 K of the
+ * Gram matrices dmm_ml_run formed, algorithmic bytes of stage 1 of its two-stage reductions: the numerators of
+ * bench.py's rooflines), "ml_tiles_ql_failed"
  * (of those: tridiagonal QL did not converge, the tile was redone by the blocked Jacobi solver), "ml_early_chunks"
  * (chunks of early-known rejects decomposed beside the remaining certificate batches); with the "profile" option on,
  * "prof_<class>_us" / "prof_<class>_n" = summed HIP-event time (microseconds) and number of spans of a kernel class,
  * class = gram (Hermitian products B B^H / B^H N B), chol (factorisations + triangular solves), tridiag (Householder
  * reduction), band (two-stage reduction, stage 1: dense -> band), chase (stage 2: band -> tridiagonal), ql
- * (tridiagonal eigen-solve + replay), backproj (a = B^H w), solve (dmm_wiener_run from its first launch to its last: the
+ * (tridiagonal eigen-solve + replay), backproj (a = B^H w), null (the null certificate's pass over B), solve (dmm_wiener_run from its first launch to its last: the
  * batches of that call alternate between two streams, so its class sums overlap in time and this span is the wall).  Reading a counter waits for the spans still running. */
 int dmm_ctx_get_counter(dmm_ctx* ctx, const char* name, int64_t* value);
 /* Validation hook for pinv_svd's rank decision (mapmaker.py:296: keep sigma > rcond*sigma_max and sigma > acond).
@@ -192,6 +198,14 @@ int64_t dmm_plan_b_bytes(const dmm_plan* plan);
 /* DirtyMapMaker._solve_m (mapmaker.py:156-168): a = B^H (Ni o v) for every tile */
 int dmm_dirty_run(dmm_plan* plan, const void* B, const void* mvis, const double* mweight,
                   void* alm);
+
+/* The same for `nday` sidereal days against ONE read of B: alm[d] = B^H (Ni_d o v_d).  The reference's loop
+ * (mapmaker.py:79-94) is run once per pipeline item (doc/tutorial.rst:110-120) against the same beam transfers; here
+ * up to 8 days share every tile read (4 ND f64 FMAs per 16 bytes of B instead of 4).  mvis / mweight / alm: [host]
+ * arrays of `nday` device pointers, each as in dmm_dirty_run; the alm arrays must be distinct.  Every day's result is
+ * bit-identical to dmm_dirty_run's on that day (same accumulation order). */
+int dmm_dirty_run_multi(dmm_plan* plan, const void* B, const void* const* mvis, const double* const* mweight,
+                        void* const* alm, int nday);
 
 /* WienerMapMaker._solve_m (mapmaker.py:235-284):
  *   a = (S^-1 + B~^H B~)^-1 B~^H v~,  B~ = sqrt(Ni) o B[:, l>=m],  S = amp^2 l^-tilt (l[0]:=1)

@@ -55,6 +55,17 @@ def dirty_solve(bm, v, Ni):
     return a.reshape(npol, nl)
 
 
+def dirty_solve_many(bm, vs, Nis):
+    """D days against one tile: column d is ``dirty_solve(bm, vs[d], Nis[d])`` (``mapmaker.py:156-168`` called once per
+    pipeline item with the same ``beam_m``) -- as ONE matrix product ``B^H [Ni_d * v_d]_d``, the form a CPU would use to
+    share the read of B between the days.  Returns ``[D, npol, lmax+1]``."""
+    npol, nl = bm.shape[-2:]
+    ntel = bm.shape[0] * bm.shape[1]
+    W = (np.asarray(Nis).reshape(-1, ntel) * np.asarray(vs).reshape(-1, ntel)).T  # [ntel, D]
+    a = np.dot(bm.reshape(ntel, npol * nl).T.conj(), W)
+    return a.T.reshape(-1, npol, nl)
+
+
 def ml_solve(bm, v, Ni):
     """``a = pinv(N^-1/2 B) N^-1/2 v``, ``mapmaker.py:184-201``."""
     npol, nl = bm.shape[-2:]

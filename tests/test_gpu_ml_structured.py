@@ -83,22 +83,34 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
         return int(v.value)
 
     diag = torch.full((nfreq, n_m, 4), -1.0, dtype=torch.float64, device=ctx.device)
-    e0, d0 = counter(b"ml_tiles_eigen"), counter(b"ml_tiles_direct")
+    e0, d0, z0 = counter(b"ml_tiles_eigen"), counter(b"ml_tiles_direct"), counter(b"ml_tiles_null")
     _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, ptr(diag)))
     try:
         alm = task.make_alm(mm)  # the batched default pass (certificate probe, deferred eigen pass, two-stage reduction)
         ctx.sync()
     finally:
         _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, None))
-    n_eig, n_dir = counter(b"ml_tiles_eigen") - e0, counter(b"ml_tiles_direct") - d0
-    assert n_eig + n_dir == nfreq * n_m
+    n_eig, n_dir, n_null = counter(b"ml_tiles_eigen") - e0, counter(b"ml_tiles_direct") - d0, counter(b"ml_tiles_null") - z0
+    assert n_eig + n_dir + n_null == nfreq * n_m
+    # the null certificate is a shortcut, never a different answer: switched off, the same tiles are decomposed to the same zeros
+    _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_null", 1))
+    try:
+        e1 = counter(b"ml_tiles_eigen")
+        alm_off = task.make_alm(mm)
+        ctx.sync()
+        assert counter(b"ml_tiles_eigen") - e1 == n_eig + n_null
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_null", 0))
+    assert torch.equal(alm, alm_off)
+    del alm_off
     alm = alm.cpu().numpy()
     diag = diag.cpu().numpy()
     assert np.all(np.isfinite(alm))
     dec = diag[..., 0] >= 0  # tiles the eigen path decomposed (the certified ones leave -1)
     assert dec.sum() == n_eig
-    # these tiles are ill-conditioned the way real products are: (almost) nothing passes the full-rank certificate
-    assert n_eig > 0.9 * nfreq * n_m, (n_eig, n_dir)
+    # these tiles are ill-conditioned the way real products are: (almost) nothing passes the full-rank certificate; what
+    # is not decomposed was answered by the NULL certificate (every singular value at or below acond -> a = 0)
+    assert n_dir < 0.1 * nfreq * n_m, (n_eig, n_dir, n_null)
 
     # distance of every decomposed tile's spectrum from the cut, from the library's own record
     smax, kept_min, cut_max = diag[..., 1], diag[..., 2], diag[..., 3]
@@ -120,6 +132,9 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
         gap_o = float(min(sig[rank_o - 1] / cut_o - 1.0 if rank_o > 0 else np.inf, 1.0 - (sig[rank_o] / cut_o if rank_o < len(sig) else 0.0)))
         err = _rel(alm[f, :, m, :], ref)
         rank_g = int(diag[f, m, 0]) if dec[f, m] else None
+        if rank_g is None and n_dir == 0:  # not decomposed, not certified full rank: the null certificate spoke
+            assert rank_o == 0 and sig[0] <= ACOND and not np.any(alm[f, :, m, :]), (f, m, rank_o, sig[0])
+            rank_g = 0
         rows.append({"f": f, "m": m, "order": int(min(2 * tel.npairs, 4 * (n_m - m))), "side": "telescope" if 4 * (n_m - m) >= 2 * tel.npairs else "sky",
                      "rank_oracle": rank_o, "rank_gpu": rank_g, "sigma_max_oracle": float(sig[0]), "sigma_max_gpu": float(diag[f, m, 1]),
                      "zero_weights": int((Ni == 0).sum()), "gap_to_cut_oracle": gap_o, "gap_to_cut_gpu": float(gap[f, m]), "rel_err": err,
@@ -130,7 +145,7 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
             worst = max(worst, err)
         # l < m stays exactly zero, like the reference's output for a provider that zeroes those columns
         assert not np.any(alm[f, :, m, :m])
-    report = {"screen": name, "screen_parameters": bt.model() and {k: v for k, v in bt.model().items() if np.isscalar(v)}, "cyl_sep": bt.cyl_sep, "tiles": nfreq * n_m, "eigen_decomposed": n_eig, "certified": n_dir, "tiles_the_cut_truncates": int(truncated.sum()),
+    report = {"screen": name, "screen_parameters": bt.model() and {k: v for k, v in bt.model().items() if np.isscalar(v)}, "cyl_sep": bt.cyl_sep, "tiles": nfreq * n_m, "eigen_decomposed": n_eig, "certified": n_dir, "null_certificate": n_null, "tiles_the_cut_truncates": int(truncated.sum()),
               "smallest_gap_to_cut_over_all_tiles": float(gap.min()), "worst_rel_err_where_ranks_agree": worst, "rows": rows}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"r04_ml_structured_vs_oracle_{name}.json"), "w") as fh:

@@ -383,3 +383,15 @@ def test_ringmap_chain_oracle_against_the_reference_classes(golden_dir):
         assert rmm.shape == ref.shape and np.abs(rmm - ref).max() <= 1e-6 * np.abs(ref).max(), i
         assert np.allclose(rmw, g[f"ew{i}_weight"], rtol=1e-6, atol=0), i
         assert np.allclose(rmr, g[f"ew{i}_rms"], rtol=1e-6, atol=0), i
+
+
+def test_dirty_solve_many_is_the_per_day_solve():
+    """The multi-day form of the Dirty solve (one matrix product per tile) column by column against the per-day
+    restatement that the reference's golden `_solve_m` outputs pin."""
+    rng = np.random.default_rng(5)
+    bm = rng.standard_normal((2, 7, 4, 9)) + 1j * rng.standard_normal((2, 7, 4, 9))
+    vs = rng.standard_normal((3, 2, 7)) + 1j * rng.standard_normal((3, 2, 7))
+    Nis = rng.uniform(0.0, 2.0, (3, 2, 7))
+    many = omm.dirty_solve_many(bm, vs, Nis)
+    for d in range(3):
+        np.testing.assert_allclose(many[d], omm.dirty_solve(bm, vs[d], Nis[d]), rtol=1e-13, atol=1e-13)
