@@ -101,10 +101,18 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
         assert counter(b"ml_tiles_eigen") - e1 == n_eig + n_null
     finally:
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_null", 0))
-    assert torch.equal(alm, alm_off)
-    del alm_off
+    # (not bit for bit everywhere: with fewer tiles the sky-side lists pair up differently and a tile may be reduced at
+    # another padded order; the tiles the certificate answered are exact zeros either way)
     alm = alm.cpu().numpy()
+    alm_off = alm_off.cpu().numpy()
     diag = diag.cpu().numpy()
+    assert np.abs(alm - alm_off).max() < 1e-9 * np.abs(alm).max()
+    answered = diag[..., 0] < 0
+    assert answered.sum() == n_null + n_dir
+    if n_dir == 0:
+        for f, m in zip(*np.nonzero(answered)):
+            assert not np.any(alm[f, :, m, :]) and not np.any(alm_off[f, :, m, :]), (f, m)
+    del alm_off
     assert np.all(np.isfinite(alm))
     dec = diag[..., 0] >= 0  # tiles the eigen path decomposed (the certified ones leave -1)
     assert dec.sum() == n_eig
