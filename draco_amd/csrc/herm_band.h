@@ -515,7 +515,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
       v = Vold[(int64_t)(cb0 + col) * kSbB + q];
       vn = Vnew[(int64_t)(cb0 + col) * kSbB + q];
     }
-    sJ[0][q][col] = x.x, sJ[1][q][col] = x.y, sJ[2][q][col] = v.x, sJ[3][q][col] = v.y;
+    // (column index XOR 2 q inside its aligned 16: the 8 lanes that share a column land on 8 different banks -- plain, this
+    // store was 8-way conflicted -- and a reader, whose q is uniform over its 16 lanes, still sees 16 contiguous columns)
+    const int cx = col ^ (2 * q);
+    sJ[0][q][cx] = x.x, sJ[1][q][cx] = x.y, sJ[2][q][cx] = v.x, sJ[3][q][cx] = v.y;
     sB[0][col][q] = vn.x, sB[0][col][8 + q] = vn.y;
     sB[1][col][q] = -vn.y, sB[1][col][8 + q] = vn.x;
   }
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
         // C -= V_I X_J^H + X_I V_J^H:  Re = Vr Xr + Vi Xi + Xr Vr + Xi Vi,  Im = Vi Xr - Vr Xi + Xi Vr - Xr Vi
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int q = lk + 4 * h, c = 16 * cb + lr;
+          const int q = lk + 4 * h, c = 16 * cb + (lr ^ (2 * q));
           const double jxr = sJ[0][q][c], jxi = sJ[1][q][c], jvr = sJ[2][q][c], jvi = sJ[3][q][c];
           cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvr[h], jxr, cre, 0, 0, 0);
           cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxr, cim, 0, 0, 0);

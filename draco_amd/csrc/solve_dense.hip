@@ -1293,14 +1293,19 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   // factorisations per tile (about a fifth of a decomposition): where almost nothing passes -- ill-conditioned beam
   // transfers -- the batches go to the eigen pass directly, and every eighth batch probes again.
   // (break-even: a certificate attempt costs ~0.10 ms per tile, a decomposition ~0.44: worth trying above ~0.25)
-  double pass_rate = 1.0;
-  int batch_no = 0;
+  // The pass rate is a property of the telescope's beam transfers, not of the day: it is remembered across calls (per
+  // context).  A call whose predecessor found (almost) nothing to certify starts with a 128-tile probe instead of a
+  // full batch, and while the probes keep failing they thin out: every 8th batch, then every 16th, ... (a full batch of
+  // rejects costs a Gram matrix and two factorisations per tile: 6 % of the structured-tile day went there).
+  double pass_rate = ctx->ml_pass_rate;
+  int batch_no = 0, probe_every = 8;
   auto certify = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky, int off) -> int {
-    if (pass_rate < 0.3 && (++batch_no & 7) != 0) {
+    if (pass_rate < 0.3 && batch_no > 0 && (++batch_no % probe_every) != 0) {
       std::vector<int64_t>& d = sky ? sky_deferred[np_sky] : tel_deferred;
       d.insert(d.end(), list.begin() + i0, list.begin() + i0 + nmat);
       return DMM_OK;
     }
+    if (batch_no == 0) batch_no = 1;
     // a probe (the rate was low last time) is a sample of the batch, not the batch: 128 tiles cost a hundredth of a
     // pass, a full batch of rejects a twentieth
     constexpr int kProbe = 128;
@@ -1309,6 +1314,8 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const int64_t before = ctx->ml_tiles_direct;
     int rc = run_batch(list, i0, first, sky, np_sky, false, off);
     pass_rate = (double)(ctx->ml_tiles_direct - before) / (double)first;
+    ctx->ml_pass_rate = pass_rate;
+    if (probe) probe_every = pass_rate < 0.3 ? std::min(probe_every * 2, 64) : 8;
     if (rc || first == nmat) return rc;
     if (pass_rate >= 0.3) return run_batch(list, i0 + first, nmat - first, sky, np_sky, false, off);
     std::vector<int64_t>& d = sky ? sky_deferred[np_sky] : tel_deferred;
