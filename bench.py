@@ -775,6 +775,14 @@ def main():
     from draco_amd.analysis import _solve
 
     cfg = wl.CONFIGS[args.config]
+    if os.environ.get("DMM_OPTS"):  # A/B switches of the library ("name=value,..."; include/draco_amd.h), e.g. DMM_OPTS=dirty_prio=1
+        from draco_amd import _lib
+        from draco_amd.device import Context
+
+        for kv in os.environ["DMM_OPTS"].split(","):
+            k_, v_ = kv.split("=")
+            for c_ in (Context.get(), Context.side(Context.get().device_index)):
+                _lib.check(_lib.lib.dmm_ctx_set_option(c_.handle, k_.strip().encode(), int(v_)))
     job = Job(cfg, rank, world, args.scaling, args.b_dtype, args.pool_freqs, overlap_sht=False if args.no_overlap else None)
 
     def barrier():

@@ -39,6 +39,7 @@ struct dmm_ctx {
   std::map<int64_t, void*> sht;            // SHT geometry caches keyed by (nside,lmax,mmax)
   int opt_dirty_variant = 0;               // tuning knobs, see dmm_ctx_set_option
   int opt_grid_mult = 0;
+  int opt_dirty_prio = 0;                  // 1: k_dirty's waves run at raised issue priority (A/B: beside the side stream's SHT)
   int opt_dirty_static = 0;                // 1: static striding of the dirty kernel's task list (default: dynamic hand-out)
   int opt_project_grid_mult = 0;
   int opt_project_variant = 0;

@@ -41,6 +41,7 @@ struct SolveParams {
   // dynamic task hand-out: a device counter (zeroed before the launch) from which blocks draw their next task, so a
   // CU slowed down by a neighbour on another stream simply takes fewer tasks; nullptr = static striding
   unsigned long long* ticket;
+  int prio;  // 1: the kernel's waves raise their issue priority (s_setprio 3) over whatever shares their SIMDs
 };
 
 __device__ __forceinline__ int64_t find_tile(const int32_t* __restrict__ ws, int64_t ntile, int64_t w) {
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(kThreads) void k_dirty(SolveParams p, const BT* __r
   double2* w = reinterpret_cast<double2*>(smem);  // [ntel]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntel = p.ntel, npairs = p.npairs;
+  if (p.prio) __builtin_amdgcn_s_setprio(3);
 
   __shared__ unsigned long long s_next;
   for (int64_t work0 = blockIdx.x;; work0 += gridDim.x) {
@@ -546,6 +548,7 @@ SolveParams base_params(const dmm_plan* pl) {
   p.tile0 = 0;
   p.work_base = 0;
   p.ticket = nullptr;
+  p.prio = pl->ctx->opt_dirty_prio;
   return p;
 }
 
