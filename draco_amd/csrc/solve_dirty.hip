@@ -329,6 +329,23 @@ __global__ __launch_bounds__(kThreads) void k_dirty_multi(SolveParams p, const B
 #pragma unroll
       for (int d = 0; d < ND; ++d) accumulate<BT, CPL>(r, wr[d], are[d], aim[d]);
     };
+    // a group of kUnroll rows: the ND broadcast reads of row u + 1 are issued before the 4 ND FMAs of row u, so that
+    // with one wave per SIMD the LDS latency hides under arithmetic instead of being paid once per row
+    auto consume_group = [&](const Raw (&r)[kUnroll], int row0) __attribute__((always_inline)) {
+      double2 wa[ND], wb[ND];
+      const double2* wr = w + row0 * ND;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) wa[d] = wr[d];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (u + 1 < kUnroll) {
+#pragma unroll
+          for (int d = 0; d < ND; ++d) (u & 1 ? wa : wb)[d] = wr[(u + 1) * ND + d];
+        }
+#pragma unroll
+        for (int d = 0; d < ND; ++d) accumulate<BT, CPL>(r[u], (u & 1 ? wb : wa)[d], are[d], aim[d]);
+      }
+    };
     int i = 0;
     if (ntel >= kUnroll) {
       Raw ra[kUnroll], rb[kUnroll];
@@ -338,14 +355,12 @@ __global__ __launch_bounds__(kThreads) void k_dirty_multi(SolveParams p, const B
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) rb[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + kUnroll + u) * row_stride);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) consume(ra[u], i + u);
+        consume_group(ra, i);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) ra[u] = load_raw<BT, CPL, NT>(B, off, (int64_t)(i + 2 * kUnroll + u) * row_stride);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) consume(rb[u], i + kUnroll + u);
+        consume_group(rb, i + kUnroll);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (i + 2 * kUnroll <= ntel) {
@@ -634,8 +649,15 @@ int launch_dirty_multi(dmm_plan* pl, const void* B, const void* const* mvis, con
     DMM_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));         \
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, p, (const BTYPE*)B, q);       \
   } while (0)
-  if (pl->b_dtype == DMM_C128) DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<double2, 1, ND, true, 8>), double2);
-  else if (pl->pair_ok) DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<float2, 2, ND, true, 8>), float2);
+  if (pl->b_dtype == DMM_C128) {
+    switch (ctx->opt_dirty_variant) {  // (tools/multi_tune.py)
+      case 1: DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<double2, 1, ND, true, 16>), double2); break;
+      case 2: DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<double2, 1, ND, true, 4>), double2); break;
+      case 3: DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<double2, 1, ND, false, 8>), double2); break;
+      case 4: DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<double2, 1, ND, true, 12>), double2); break;
+      default: DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<double2, 1, ND, true, 8>), double2); break;
+    }
+  } else if (pl->pair_ok) DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<float2, 2, ND, true, 8>), float2);
   else DMM_LAUNCH_DIRTY_MULTI((k_dirty_multi<float2, 1, ND, true, 8>), float2);
   DMM_HIP(hipGetLastError());
   return DMM_OK;
