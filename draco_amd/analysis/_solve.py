@@ -379,7 +379,10 @@ class SolveEngine:
         if npairs != tel.npairs:
             raise ValueError(f"m-modes have {npairs} baselines, the beam transfers {tel.npairs}")
         n_m = mmax + 1
-        alms = [torch.empty((nfreq, tel.num_pol_sky, n_m, tel.lmax + 1), dtype=torch.complex128, device=self.ctx.device) for _ in range(D)]
+        # (ONE allocation for the group: the caching allocator then recycles one block per group instead of juggling D of them
+        # against the side stream's events -- every fresh hipMalloc of a few GB stalls the device for tens of milliseconds)
+        alm_all = torch.empty((D, nfreq, tel.num_pol_sky, n_m, tel.lmax + 1), dtype=torch.complex128, device=self.ctx.device)
+        alms = [alm_all[d] for d in range(D)]
         self.last_b_bytes = 0
         self._ws_offer = {}
         self._ws = None

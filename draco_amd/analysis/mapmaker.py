@@ -210,10 +210,14 @@ class BaseMapMaker(ContainerTask):
         main = torch.cuda.current_stream(ctx.device)
         maps = {}
 
+        ndays = len(mmodes_list)
+
         def sht_of(d, alm, f0, f1):
             nfreq, _, n_m, _ = alm.shape
-            if d not in maps:
-                maps[d] = ctx.empty((nfreq, 4, npix), np.float64)
+            if not maps:  # one allocation for the whole group (see solve_many)
+                all_maps = ctx.empty((ndays, nfreq, 4, npix), np.float64)
+                for dd in range(ndays):
+                    maps[dd] = all_maps[dd]
             if overlap:
                 if d == 0:
                     side.wait_for(main)

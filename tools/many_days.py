@@ -65,16 +65,21 @@ def main():
             def group():
                 return dm.process_many([mt.process(s) for s in streams[:D]])
 
-            group()  # (fills the pool the first time)
+            for _ in range(3):  # (fills the pool the first time; lets the caching allocator reach its steady set of blocks --
+                group()         # a group's maps stay with the side stream until its events have passed)
             torch.cuda.synchronize()
             eng.launch_events = []
-            steps = 3
+            steps = 4
+            mem0 = torch.cuda.memory_stats()
             t0 = time.perf_counter()
             for _ in range(steps):
                 maps = group()
             maps[-1].map._dev
             torch.cuda.synchronize()
             el = (time.perf_counter() - t0) / steps
+            mem1 = torch.cuda.memory_stats()
+            alloc = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in ("num_alloc_retries", "num_device_alloc", "num_device_free")}
+            alloc["reserved_GB"] = mem1.get("reserved_bytes.all.current", 0) / 1e9
             ms = [a.elapsed_time(b) for a, b, _, _ in eng.launch_events]
             eng.launch_events = None
             launch_ms = float(np.mean(ms))
@@ -83,7 +88,7 @@ def main():
             res[f"D={D}"] = {"seconds_per_group": el, "value": (lmax + 1) * D / el, "ms_per_day_equivalent": el / D * 1e3,
                             "dirty_launch_ms": launch_ms, "launches_per_group": len(ms) // steps,
                             "hbm_GBs": by / launch_ms / 1e6, "hbm_frac": by / launch_ms / 1e6 / HBM_PEAK,
-                            "f64_TFLOPs": fl / launch_ms / 1e9, "f64_frac": fl / launch_ms / 1e9 / F64_PEAK}
+                            "f64_TFLOPs": fl / launch_ms / 1e9, "f64_frac": fl / launch_ms / 1e9 / F64_PEAK, "allocator": alloc}
             print(f"resident D={D}", json.dumps(res[f"D={D}"]), file=sys.stderr, flush=True)
             del maps
         # the days' a_lm only (no alm2map): what the solves alone do
