@@ -709,6 +709,9 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
   double* dd = reinterpret_cast<double*>(vbm + 5 * n);
   double* ee = dd + n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, c = lane & 7;
+  // (Tried: s_setprio(3) for this kernel's and the serial QL's waves -- beside the next chunk's Gram / sweep kernels a
+  // chase launch takes 2.4 x what it takes alone.  No change: 668 against 680 ms of chase per 32 frequencies.  What the
+  // chase waits for in the step is a CU whose LDS is EMPTY, not issue slots.)
 #define SB_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   for (int e = threadIdx.x; e < (kSbB + 1) * n; e += 64 * kSbCW) {
     const int d = e / n, col = e - d * n;
@@ -717,7 +720,13 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
   for (int e = threadIdx.x; e < (n / kSbB + 2) * 21; e += 64 * kSbCW) ab[bg0 + e] = SB_ZERO;
   if (threadIdx.x < kSbCW) s_prog[threadIdx.x] = 0;
   __syncthreads();
-  volatile int* prog = s_prog;
+  // The progress words are read and written with relaxed workgroup-scope atomics ON THE __shared__ ARRAY: ds_read_b32 /
+  // ds_write_b32.  Through a `volatile int*` (a generic pointer) they were FLAT loads / stores followed by
+  // `s_waitcnt vmcnt(0)`: every step of every wave then waited for the acknowledgement of the previous step's reflector
+  // log stores to GLOBAL memory -- a round trip to HBM on the dependency chain that is the kernel's whole run time.
+  // Ordering between the waves is what SB_FENCE provides (the LDS serves a CU's requests in issue order).
+#define SB_PROG_LOAD(w) __hip_atomic_load(&s_prog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define SB_PROG_STORE(w, v) __hip_atomic_store(&s_prog[w], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
   double2* const scr = &s_scr[wave][8 * g];  // the slot's 8 entries
   const int pred = (wave + kSbCW - 1) % kSbCW;
   const int ngroup = (n - 2) / 8 + 1;  // sweeps 0 .. n - 2
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
     for (int S = 0; S < nstep; ++S) {
       if (G > 0) {  // sweep 8 G at iteration S needs sweep 8 G - 1 (slot 7 of the group before) through iteration S + 2
         const int need = ((G - 1) << 12) + S + 8 * kSbLag;
-        while (prog[pred] < need) __builtin_amdgcn_s_sleep(1);
+        while (SB_PROG_LOAD(pred) < need) __builtin_amdgcn_s_sleep(1);
         SB_FENCE();
       }
       const int it = S - kSbLag * g;
@@ -873,10 +882,10 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
       }
       // step S is done: its LDS writes first, then the counter
       SB_FENCE();
-      if (lane == 0) prog[wave] = (G << 12) + S + 1;
+      if (lane == 0) SB_PROG_STORE(wave, (G << 12) + S + 1);
     }
     SB_FENCE();
-    if (lane == 0) prog[wave] = (G << 12) + 4095;  // the whole group
+    if (lane == 0) SB_PROG_STORE(wave, (G << 12) + 4095);  // the whole group
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -884,6 +893,8 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
     ee[n - 1] = 0.0;
   }
 #undef SB_FENCE
+#undef SB_PROG_LOAD
+#undef SB_PROG_STORE
 }
 #undef SB_ZERO
 
