@@ -302,7 +302,12 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   lp.alm = alm;
   lp.accumulate = accumulate;
   if (NPOL == 4 && !(ctx->opt_sht_variant & 8)) {  // bit 3: force the vector-ALU kernels
-    hipLaunchKernelGGL(k_leg_anal_mfma, dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(kAnThreads), 0, ctx->stream, lp);
+    // 4-wave blocks, two per CU, the ring pairs in passes of 256 (default since round 4: map2alm 0.116 -> 0.110 ms per
+    // frequency at cfg 3, -4.4 % with three iterations); bit 4 of sht_variant: the 8-wave block of rounds 1-3 (A/B)
+    if (ctx->opt_sht_variant & 16)
+      hipLaunchKernelGGL(k_leg_anal_mfma<kAnThreads>, dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(kAnThreads), 0, ctx->stream, lp);
+    else
+      hipLaunchKernelGGL(k_leg_anal_mfma<256>, dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(256), 0, ctx->stream, lp);
     DMM_HIP(hipGetLastError());
     return DMM_OK;
   }

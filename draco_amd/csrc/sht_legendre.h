@@ -499,9 +499,15 @@ __global__ __launch_bounds__(kThreads) void k_leg_anal(LegAnalParams p) {
 // F2 operand is the F1 operand with its four columns reversed and two signs flipped: one DPP move.
 // The 8 waves' tiles are parked in their (then free) slabs, summed in a fixed order once per chunk and
 // added to a_lm.  Slab pitch 65: the 16 rows (stride 2) x 2 rings of a half wave fall on disjoint banks.
-constexpr int kAnL = 32, kAnPitch = 65, kAnThreads = 512, kAnWaves = kAnThreads / 64;
+constexpr int kAnL = 32, kAnPitch = 65, kAnThreads = 512;
+// NT = 256 (default): 4 waves, 69 KB of slabs -- two independent blocks per CU, the ring pairs in passes of 256, every
+// later pass adding to the a_lm of the one before (fixed summation order within a pass and across passes).
+// NT = kAnThreads = 512 (sht_variant bit 4, the form of rounds 1-3): one block of 8 waves per CU (137 KB), every ring pair
+// of nside <= 256 in one pass; two barriers per 32-l chunk hold eight waves instead of four.
 
-__global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
+template <int NT>
+__global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p) {
+  constexpr int kAnWaves = NT / 64;
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ double slab[kAnWaves][(kAnL + 1) * kAnPitch];  // row 0: lambda of the step before the chunk
   __shared__ double ringtab[kAnWaves][2][64];                // x / sin^2, 1 / sin^2 of the wave's rings
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
   double* alm_d = reinterpret_cast<double*>(p.alm);
 
   // structural zeros l < m
-  for (int idx = threadIdx.x; idx < kLegF * 4 * m; idx += kAnThreads) {
+  for (int idx = threadIdx.x; idx < kLegF * 4 * m; idx += NT) {
     const int fp = idx / m, l = idx - fp * m;
     const int f = f0 + (fp >> 2);
     if (f < p.nf) p.alm[(((int64_t)f * 4 + (fp & 3)) * p.n_m + m) * (lmax + 1) + l] = make_double2(0.0, 0.0);
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
   const bool fok = f < p.nf;
   const double* bsrc = reinterpret_cast<const double*>(p.b);
 
-  for (int r0 = 0; r0 < npair; r0 += kAnThreads) {  // ring super-chunks of 512 pairs (one at nside <= 256)
+  for (int r0 = 0; r0 < npair; r0 += NT) {  // ring super-chunks of 512 pairs (one at nside <= 256)
     // generation state of this thread's ring pair
     const int r = r0 + threadIdx.x;
     double x = 0.0, inv_s2 = 0.0, xs2 = 0.0, lam = 0.0, lam_prev = 0.0;
@@ -660,10 +666,10 @@ __global__ __launch_bounds__(kAnThreads) void k_leg_anal_mfma(LegAnalParams p) {
         out[(1 * kAnL + 2 * i + 1) * 16 + li] = acc[3][reg];
       }
       __syncthreads();
-      // two values per thread: fixed-order sum over the waves, then into a_lm
+      // 1024 / NT values per thread: fixed-order sum over the waves, then into a_lm
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int idx = threadIdx.x + h * kAnThreads;  // [tile][row][col]
+      for (int h = 0; h < 1024 / NT; ++h) {
+        const int idx = threadIdx.x + h * NT;  // [tile][row][col]
         const int tile = idx >> 9, row = (idx >> 4) & 31, oc = idx & 15;
         double sum = 0.0;
 #pragma unroll
