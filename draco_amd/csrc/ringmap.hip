@@ -489,6 +489,171 @@ __global__ __launch_bounds__(kFuThreads) void k_rm_fused(RmParams p, RmFft q, in
   }
 }
 
+// The same with SIXTEEN elevations per block (round 4).  HBM serves 128-byte lines: read in 64-byte pieces at a 4 KB
+// stride -- what 8 elevations of complex64 are -- it delivers 3.0 TB/s, in 128-byte pieces 6.2 (tools/probe/piece_bw.hip),
+// and 3.0 TB/s is exactly what the load phase of k_rm_fused ran at.  The LDS holds the inverse-FFT image of 8 elevations, no
+// more; so the block reads 128-byte pieces (lane = (m, 16 elevations)), puts the modes of elevations 0-7 into the LDS
+// image as before and PARKS those of elevations 8-15 in a global scratch image (131 KB per block, 64-byte pieces in
+// natural order; it lives in L2 / the Infinity Cache until it is read back), transforms and stores the first eight, reads
+// the parked image in (bit reversal on the LDS side), transforms and stores the second eight.
+constexpr int kFuEl16 = 16;
+__global__ __launch_bounds__(kFuThreads) void k_rm_fused16(RmParams p, RmFft q, int ntile_el, double2* __restrict__ park) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_acc[3][kFuThreads / 64][kFuEl16];
+  __shared__ double s_nrm[kFuEl16], s_wv[kFuEl16];
+  C<double>* buf = reinterpret_cast<C<double>*>(smem);  // [4][P]
+  C<double>* twl = buf + (size_t)4 * q.P;
+  const int N = p.nra, M = q.M, P = q.P;
+  const int64_t tile_lin = blockIdx.x;  // (grid = tiles exactly)
+  C<double>* const pk = reinterpret_cast<C<double>*>(park) + (size_t)blockIdx.x * 4 * N;
+  const int pf = (int)(tile_lin / ntile_el), tile = (int)(tile_lin - (int64_t)pf * ntile_el);
+  const int pol = pf / p.nfreq, f = pf - pol * p.nfreq;
+  const int el0 = tile * kFuEl16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int eli = lane & 15, ms = lane >> 4;  // 16 elevations x 4 m per wave: 128-byte pieces of the input rows
+  const int el = el0 + eli;
+  const bool el_ok = el < p.nel;
+  const int elc = el_ok ? el : p.nel - 1;
+  for (int k = threadIdx.x; k < (M >> 1); k += kFuThreads) twl[k] = {q.tw[k].x, q.tw[k].y};
+  const int nterm = 2 * p.new_;
+  double acc_d = 0.0, acc_q = 0.0, acc_p = 0.0;
+  for (int mb = 0; mb < p.nm; mb += 4 * (kFuThreads / 64)) {
+    const int m = mb + wave * 4 + ms;
+    const bool m_ok = m < p.nm;
+    const int mc = m_ok ? m : p.nm - 1;
+    double sw = 0.0, mre = 0.0, mim = 0.0, sg = 0.0;
+    for (int t0 = 0; t0 < nterm; t0 += 8) {
+      // lane `eli` of the group works out the weights of term t0 + eli of its m; the group's lanes pick them up below
+      double w = 0.0, g = 0.0;
+      {
+        const int t = t0 + (eli & 7);  // (both 8-lane halves of an m work the weights out: each picks them up from its own)
+        if (t < nterm) {
+          const int s = t / p.new_, e = t - s * p.new_;
+          const int64_t wbase = ((((int64_t)mc * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_;
+          double iv = (double)p.hw[wbase + e];
+          if (p.mode == 0) {
+            w = iv > 0.0 ? p.wt[e] : 0.0;
+          } else {
+            iv *= p.wt[e];
+            if (p.mode == 1) {
+              double wsumv = 0.0;
+              for (int e2 = 0; e2 < p.new_; ++e2) wsumv += (double)p.hw[wbase + e2] * p.wt[e2];
+              w = iv * (wsumv != 0.0 ? 1.0 / wsumv : 0.0);
+            } else {
+              w = iv;
+            }
+            if (!(iv > 0.0)) w = 0.0;
+          }
+          g = w * w * (iv > 0.0 ? 1.0 / iv : 0.0);
+        }
+      }
+      float2 h[8], b[8];
+      double w2[8], g2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool live = t0 + k < nterm;
+        const int tg = live ? t0 + k : nterm - 1, s = tg / p.new_, e = tg - s * p.new_;
+        const double wk = __shfl(w, (lane & ~7) + k, 64), gk = __shfl(g, (lane & ~7) + k, 64);
+        w2[k] = live ? wk : 0.0;
+        g2[k] = live ? gk : 0.0;
+        const int64_t rbase = (((((int64_t)mc * 2 + s) * p.npol + pol) * p.nfreq + f) * p.new_ + e) * p.nel + elc;
+        h[k] = p.hv[rbase];
+        b[k] = p.bv[rbase];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double br = b[k].x, bi = b[k].y, hr = h[k].x, hi = h[k].y;
+        const double b2 = br * br + bi * bi;
+        sw = fma(w2[k], b2, sw);
+        mre = fma(w2[k], br * hr + bi * hi, mre);  // conj(b) * h
+        mim = fma(w2[k], br * hi - bi * hr, mim);
+        sg = fma(g2[k], b2, sg);
+      }
+    }
+    double ar = 0.0, ai = 0.0;
+    if (m_ok && el_ok) {
+      const double cinv = p.eps[(int64_t)f * p.nm + m] + sw;  // (skip_deconvolution takes the three-kernel path)
+      const double ic = cinv != 0.0 ? 1.0 / cinv : 0.0;
+      const double win = p.window ? (double)p.window[((int64_t)f * p.nm + m) * p.nel + el] : 1.0;
+      ar = win * mre * ic;
+      ai = win * mim * ic;
+      const double rd = win * sw * ic;
+      const double qv = sqrt(sg) * win * ic / (double)(p.mmax + 1);
+      acc_d += rd;
+      acc_q += qv * qv;
+      acc_p += ((m == 0 || 2 * m == N) ? 1.0 : 2.0) * rd * rd;
+    }
+    const bool edge = m == 0 || 2 * m == N;  // DC and Nyquist bins are real, and their own mirror
+    if (edge) ai = 0.0;
+    // rows 2j (A) and 2j + 1 (B) share a transform: z = X_A + i X_B, loaded conjugated at the bit-reversed position
+    const double orr = __shfl_xor(ar, 1, 64), oi = __shfl_xor(ai, 1, 64);
+    if (m_ok) {
+      const bool odd = eli & 1;
+      const double a_r = odd ? orr : ar, a_i = odd ? oi : ai, b_r = odd ? ar : orr, b_i = odd ? ai : oi;
+      const C<double> lo = {a_r - b_i, -(a_i + b_r)}, hi = {a_r + b_i, a_i - b_r};  // bins m and N - m (= conj(X[m]) of both rows)
+      if (eli < 8) {  // elevations 0-7: straight into the LDS image (bit-reversed positions)
+        C<double>* row = buf + (size_t)(eli >> 1) * P;
+        if (!odd) row[dmm_fft::bitrev(m, q.logM)] = lo;
+        else if (!edge) row[dmm_fft::bitrev(N - m, q.logM)] = hi;
+      } else {        // elevations 8-15: parked in natural order (64-byte pieces per image row), transformed second
+        C<double>* row = pk + (size_t)((eli - 8) >> 1) * N;
+        if (!odd) row[m] = lo;
+        else if (!edge) row[N - m] = hi;
+      }
+    }
+  }
+  // the block's per-row sums over m: the 4 m of a wave by a butterfly, the waves in a fixed order
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1) {
+    acc_d += __shfl_xor(acc_d, o, 64);
+    acc_q += __shfl_xor(acc_q, o, 64);
+    acc_p += __shfl_xor(acc_p, o, 64);
+  }
+  if (ms == 0) {
+    s_acc[0][wave][eli] = acc_d;
+    s_acc[1][wave][eli] = acc_q;
+    s_acc[2][wave][eli] = acc_p;
+  }
+  __syncthreads();
+  if (threadIdx.x < kFuEl16) {
+    double d = 0.0, q2 = 0.0, p2 = 0.0;
+    for (int w2 = 0; w2 < kFuThreads / 64; ++w2) {
+      d += s_acc[0][w2][threadIdx.x];
+      q2 += s_acc[1][w2][threadIdx.x];
+      p2 += s_acc[2][w2][threadIdx.x];
+    }
+    const double mean = d / (double)p.nm;
+    const double nrm = mean != 0.0 ? 1.0 / mean : 0.0;
+    const double sv = 0.5 * nrm * nrm * q2;
+    s_nrm[threadIdx.x] = nrm;
+    s_wv[threadIdx.x] = sv != 0.0 ? 1.0 / sv : 0.0;
+    if (el0 + (int)threadIdx.x < p.nel) p.dbp[(int64_t)pf * p.nel + el0 + threadIdx.x] = nrm * nrm * p2 / (double)N / (double)N;  // Parseval
+  }
+  __syncthreads();
+  for (int half = 0; half < 2; ++half) {
+    if (half == 1) {  // the parked image of elevations 8-15 comes in (coalesced reads, bit reversal on the LDS side)
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < 4 * N; idx += kFuThreads) {
+        const int j = idx / N, n = idx - j * N;
+        buf[(size_t)j * P + dmm_fft::bitrev(n, q.logM)] = pk[(size_t)j * N + n];
+      }
+      __syncthreads();
+    }
+    dmm_fft::fft_dit<double, false, kFuThreads>(buf, twl, 4, M, q.logM, P);
+    // y = conj(result) / N: even row = Re, odd row = -Im, each times its row's normalisation; 64-byte pieces of [ra][el]
+    const int e8 = threadIdx.x & 7;
+    const int ele = el0 + 8 * half + e8;
+    const double sc = s_nrm[8 * half + e8] / (double)N, wv = s_wv[8 * half + e8];
+    if (ele < p.nel)
+      for (int ra = threadIdx.x >> 3; ra < N; ra += kFuThreads / 8) {
+        const C<double> v = buf[(size_t)(e8 >> 1) * P + ra];
+        const int64_t o = ((int64_t)pf * p.nra + ra) * p.nel + ele;
+        p.map[o] = (e8 & 1) ? -v.y * sc : v.x * sc;
+        p.weight[o] = wv;
+      }
+  }
+}
+
 // [pf][el][ra] -> map[pf][ra][el] (+ dirty beam), weight[pf][ra][el] = wv[pf][el]; 32x32 tiles
 __global__ __launch_bounds__(kThreads) void k_rm_store(RmParams p) {
   __shared__ double ta[32][33], tb[32][33];
@@ -601,6 +766,18 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
   p.db = dirty_beam;
   // one pass over the m-modes where the whole inverse FFT of 8 elevations fits the LDS (power-of-two nra up to 2048)
   const size_t fused_lds = (size_t)4 * q.P * sizeof(double2) + tw_b;
+  if (!dirty_beam && !skip_deconvolution && !q.blue && nra >= 8 && fused_lds <= 150 * 1024 && ctx->opt_ringmap_variant != 1 && ctx->opt_ringmap_variant != 2) {
+    // sixteen elevations per block: 128-byte pieces of the input rows ("ringmap_variant" = 2: the 8-elevation form)
+    const int ntile_el = (nel + kFuEl16 - 1) / kFuEl16;
+    const int64_t ntile = (int64_t)ntile_el * npol * nfreq;
+    void* park = nullptr;
+    rc = dmm_get_scratch(ctx, (size_t)ntile * 4 * nra * sizeof(double2) + 256, &park);
+    if (rc) return rc;
+    DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fused16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+    hipLaunchKernelGGL(k_rm_fused16, dim3((unsigned)ntile), dim3(kFuThreads), fused_lds, ctx->stream, p, q, ntile_el, (double2*)park);
+    DMM_HIP(hipGetLastError());
+    return DMM_OK;
+  }
   if (!dirty_beam && !skip_deconvolution && !q.blue && nra >= 8 && fused_lds <= 150 * 1024 && ctx->opt_ringmap_variant != 1) {
     const int ntile_el = (nel + kFuEl - 1) / kFuEl;
     const int64_t ntile = (int64_t)ntile_el * npol * nfreq;

@@ -1,0 +1,78 @@
+// How fast can HBM be read in PIECES of W bytes at a 4 KB stride, the access pattern of the single-pass ring-map kernel
+// (a block owns W bytes of every 4 KB row of a (pol, freq) slab; the 4096 / W blocks of a slab run in lock step)?
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/piece_bw tools/probe/piece_bw.hip && /tmp/piece_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+template <int W, int LB>  // piece width in bytes, bytes per lane per load (8 or 16)
+__global__ __launch_bounds__(1024) void k_read(const char* __restrict__ buf, int64_t rows_per_slab, int nslab, double* sink) {
+  constexpr int LPP = W / LB;        // lanes per piece
+  constexpr int RPW = 64 / LPP;      // rows per wave-load
+  const int pieces = 4096 / W;
+  const int slab = blockIdx.x / pieces, piece = blockIdx.x % pieces;
+  if (slab >= nslab) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const char* base = buf + (int64_t)slab * rows_per_slab * 4096 + (int64_t)piece * W + (lane % LPP) * LB;
+  double acc = 0.0;
+  constexpr int U = 8;
+  for (int64_t r0 = (int64_t)wave * RPW; r0 + (U - 1) * nwave * RPW + RPW <= rows_per_slab; r0 += (int64_t)U * nwave * RPW) {
+    if constexpr (LB == 8) {
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const double*>(base + (r0 + (int64_t)u * nwave * RPW + lane / LPP) * 4096));
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += v[u];
+    } else {
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      v2d v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(base + (r0 + (int64_t)u * nwave * RPW + lane / LPP) * 4096));
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += v[u].x + v[u].y;
+    }
+  }
+  if (acc == 1.2345e300) sink[0] = acc;
+}
+
+template <int W, int LB>
+void run(const char* buf, int64_t rows_per_slab, int nslab, double* sink, int threads) {
+  const int grid = nslab * (4096 / W);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  float best = 1e9;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((k_read<W, LB>), dim3(grid), dim3(threads), 0, 0, buf, rows_per_slab, nslab, sink);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    if (rep) best = ms < best ? ms : best;
+  }
+  const double bytes = (double)nslab * rows_per_slab * 4096;
+  printf("piece %4d B, %2d B per lane, %4d threads/block, grid %5d: %.3f ms  %.2f TB/s\n", W, LB, threads, grid, best, bytes / best / 1e9);
+}
+
+int main() {
+  // the CHIME-like ring-map input: per (pol, freq) slab 1025 m x 2 signs x 4 EW rows x 2 arrays (hv, bv) = 16400 rows of 4 KB;
+  // 4 pol x 8 freq = 32 slabs = 2.15 GB
+  const int64_t rows = 16400;
+  const int nslab = 32;
+  char* buf;
+  double* sink;
+  hipMalloc(&buf, (size_t)nslab * rows * 4096);
+  hipMalloc(&sink, 8);
+  hipMemset(buf, 1, (size_t)nslab * rows * 4096);
+  for (int threads : {1024, 512}) {
+    run<64, 8>(buf, rows, nslab, sink, threads);
+    run<128, 8>(buf, rows, nslab, sink, threads);
+    run<128, 16>(buf, rows, nslab, sink, threads);
+    run<256, 16>(buf, rows, nslab, sink, threads);
+    run<512, 16>(buf, rows, nslab, sink, threads);
+    run<1024, 16>(buf, rows, nslab, sink, threads);
+    run<4096, 16>(buf, rows, nslab, sink, threads);
+  }
+  return 0;
+}
