@@ -35,6 +35,67 @@ __global__ __launch_bounds__(1024) void k_read(const char* __restrict__ buf, int
   if (acc == 1.2345e300) sink[0] = acc;
 }
 
+// The ring-map kernel's own order: two arrays [m][sign][pf][ew][4 KB]; a block = (pf, 128-byte piece) reads, per step of
+// 64 m, the 8 (sign, ew) rows of both arrays for 4 m per wave -- rows 1 MB apart between the m of one wave-load.
+template <int MPW>  // m per wave-load instruction (4: the kernel's; 1: a wave reads ONE m, its 4 lane groups take 4 of the 8 terms)
+__global__ __launch_bounds__(1024) void k_read_rm(const char* __restrict__ a0, const char* __restrict__ a1, int nm, int npf, double* sink) {
+  const int pf = blockIdx.x / 32, piece = blockIdx.x % 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane >> 4, l16 = lane & 15;
+  double acc = 0.0;
+  if (MPW == 4) {
+    for (int mb = 0; mb < nm; mb += 64) {
+      const int m = min(mb + wave * 4 + sub, nm - 1);
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t row = (((int64_t)m * 2 + (k >> 2)) * npf + pf) * 4 + (k & 3);
+        v[k] = *reinterpret_cast<const double*>(a0 + row * 4096 + piece * 128 + l16 * 8);
+        v[8 + k] = *reinterpret_cast<const double*>(a1 + row * 4096 + piece * 128 + l16 * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+  } else {
+    for (int mb = 0; mb < nm; mb += 64) {
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = min(mb + wave * 4 + j, nm - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = sub * 2 + h;  // this lane group's two terms
+          const int64_t row = (((int64_t)m * 2 + (k >> 2)) * npf + pf) * 4 + (k & 3);
+          v[j * 4 + h * 2] = *reinterpret_cast<const double*>(a0 + row * 4096 + piece * 128 + l16 * 8);
+          v[j * 4 + h * 2 + 1] = *reinterpret_cast<const double*>(a1 + row * 4096 + piece * 128 + l16 * 8);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+  }
+  if (acc == 1.2345e300) sink[0] = acc;
+}
+
+template <int MPW>
+void run_rm(const char* buf, int nm, int npf, double* sink) {
+  const size_t arr = (size_t)nm * 2 * npf * 4 * 4096;
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  float best = 1e9;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((k_read_rm<MPW>), dim3(npf * 32), dim3(1024), 0, 0, buf, buf + arr, nm, npf, sink);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    if (rep) best = ms < best ? ms : best;
+  }
+  printf("ring-map order, %d m per wave-load, 128-byte pieces: %.3f ms  %.2f TB/s\n", MPW, best, 2.0 * arr / best / 1e9);
+}
+
 template <int W, int LB>
 void run(const char* buf, int64_t rows_per_slab, int nslab, double* sink, int threads) {
   const int grid = nslab * (4096 / W);
@@ -65,7 +126,9 @@ int main() {
   hipMalloc(&buf, (size_t)nslab * rows * 4096);
   hipMalloc(&sink, 8);
   hipMemset(buf, 1, (size_t)nslab * rows * 4096);
-  for (int threads : {1024, 512}) {
+  run_rm<4>(buf, 1025, 32, sink);
+  run_rm<1>(buf, 1025, 32, sink);
+  for (int threads : {1024}) {
     run<64, 8>(buf, rows, nslab, sink, threads);
     run<128, 8>(buf, rows, nslab, sink, threads);
     run<128, 16>(buf, rows, nslab, sink, threads);

@@ -36,7 +36,7 @@ def main():
     def run():
         _lib.check(_lib.lib.dmm_ringmap_deconvolve(ctx.handle, nm, nm, npol, nfreq, new, nel, nra, 2, 0, 0, ptr(hv), ptr(hw), ptr(bv), ptr(table), ptr(eps), None, ptr(rmap), ptr(rwgt), ptr(rdbp), None))
 
-    variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 1: the three-kernel form even where the single pass applies
+    variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 1: the three-kernel form even where the single pass applies; 2: the single pass with 8 elevations per block (round 3)
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ringmap_variant", variant))
     run()
     ctx.sync()
@@ -48,7 +48,7 @@ def main():
     t = float(np.median(ts))
     b_in = hv.numel() * 8 * 2 + hw.numel() * 4
     b_out = (rmap.numel() + rwgt.numel()) * 8
-    print(json.dumps({"variant": "three kernels" if variant else "auto (single pass where it applies)", "mmax": mmax, "nra": nra, "nfreq": nfreq, "nel": nel, "ms": t, "ms_per_freq": t / nfreq,
+    print(json.dumps({"variant": {0: "single pass, 16 elevations per block (default where it applies)", 1: "three kernels", 2: "single pass, 8 elevations per block (round 3)"}.get(variant, str(variant)), "mmax": mmax, "nra": nra, "nfreq": nfreq, "nel": nel, "ms": t, "ms_per_freq": t / nfreq,
                       "algorithmic_GB": (b_in + b_out) / 1e9, "GBs": (b_in + b_out) / t / 1e6}))
 
 
