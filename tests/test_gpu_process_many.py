@@ -148,3 +148,30 @@ def test_abi_multi_day_launch_and_its_argument_errors(layout):
     nul = PA(*([ptr(mv[0])] + [C.c_void_p(0)] * (D - 1)))
     assert _lib.lib.dmm_dirty_run_multi(slab.plan, ptr(slab.pool), nul, pw, pa, D) == _lib.DMM_E_ARG
     slab.close()
+
+
+def test_many_baselines_take_smaller_day_groups_and_one_polarisation_falls_back():
+    """cfg-4 baseline count (763 -> 1526 telescope rows): eight days' weights no longer fit the LDS side by side, the library
+    groups the days by four; a telescope with ONE sky polarisation goes through the per-day path (the reference broadcasts
+    its single solve into four slots, mapmaker.py:94).  Both: every day equals its own pass."""
+    from draco_amd.analysis.mapmaker import DirtyMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider, TransitTelescope
+
+    for kw, D in (({"npairs": 763}, 9), ({"num_pol_sky": 1}, 3)):
+        lmax, nfreq = 24, 2
+        tel = TransitTelescope(osyn.frequencies(nfreq), lmax=lmax, ncyl=1, nfeed_cyl=3, **kw)
+        bt = SyntheticProvider(tel, seed=17)
+        shape = (lmax + 1, 2, nfreq, tel.npairs)
+        days = []
+        for d in range(D):
+            rng = np.random.default_rng(100 + d)
+            mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs)
+            mm.vis[:] = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+            mm.weight[:] = rng.uniform(0.5, 1.5, shape)
+            days.append(mm)
+        t = DirtyMapMaker(nside=8)
+        t.setup(bt)
+        many = t.process_many(days)
+        for d in range(D):
+            np.testing.assert_array_equal(many[d].map[:], t.process(days[d]).map[:])
