@@ -497,12 +497,15 @@ __global__ __launch_bounds__(kFuThreads) void k_rm_fused(RmParams p, RmFft q, in
 // natural order; it lives in L2 / the Infinity Cache until it is read back), transforms and stores the first eight, reads
 // the parked image in (bit reversal on the LDS side), transforms and stores the second eight.
 constexpr int kFuEl16 = 16;
+// PARK = false: the image of all sixteen elevations fits the LDS (nra <= 1024): no parking, one transform of eight
+// sequences, 128-byte pieces on the way out too.
+template <bool PARK>
 __global__ __launch_bounds__(kFuThreads) void k_rm_fused16(RmParams p, RmFft q, int ntile_el, double2* __restrict__ park) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double s_acc[3][kFuThreads / 64][kFuEl16];
   __shared__ double s_nrm[kFuEl16], s_wv[kFuEl16];
-  C<double>* buf = reinterpret_cast<C<double>*>(smem);  // [4][P]
-  C<double>* twl = buf + (size_t)4 * q.P;
+  C<double>* buf = reinterpret_cast<C<double>*>(smem);  // [4][P] (PARK) or [8][P]
+  C<double>* twl = buf + (size_t)(PARK ? 4 : 8) * q.P;
   const int N = p.nra, M = q.M, P = q.P;
   const int64_t tile_lin = blockIdx.x;  // (grid = tiles exactly)
   C<double>* const pk = reinterpret_cast<C<double>*>(park) + (size_t)blockIdx.x * 4 * N;
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(kFuThreads) void k_rm_fused16(RmParams p, RmFft q, 
       const bool odd = eli & 1;
       const double a_r = odd ? orr : ar, a_i = odd ? oi : ai, b_r = odd ? ar : orr, b_i = odd ? ai : oi;
       const C<double> lo = {a_r - b_i, -(a_i + b_r)}, hi = {a_r + b_i, a_i - b_r};  // bins m and N - m (= conj(X[m]) of both rows)
-      if (eli < 8) {  // elevations 0-7: straight into the LDS image (bit-reversed positions)
+      if (!PARK || eli < 8) {  // elevations 0-7 (all sixteen without parking): straight into the LDS image (bit-reversed positions)
         C<double>* row = buf + (size_t)(eli >> 1) * P;
         if (!odd) row[dmm_fft::bitrev(m, q.logM)] = lo;
         else if (!edge) row[dmm_fft::bitrev(N - m, q.logM)] = hi;
@@ -630,6 +633,20 @@ __global__ __launch_bounds__(kFuThreads) void k_rm_fused16(RmParams p, RmFft q, 
     if (el0 + (int)threadIdx.x < p.nel) p.dbp[(int64_t)pf * p.nel + el0 + threadIdx.x] = nrm * nrm * p2 / (double)N / (double)N;  // Parseval
   }
   __syncthreads();
+  if (!PARK) {
+    dmm_fft::fft_dit<double, false, kFuThreads>(buf, twl, 8, M, q.logM, P);
+    const int e16 = threadIdx.x & 15;
+    const int ele = el0 + e16;
+    const double sc = s_nrm[e16] / (double)N, wv = s_wv[e16];
+    if (ele < p.nel)
+      for (int ra = threadIdx.x >> 4; ra < N; ra += kFuThreads / 16) {
+        const C<double> v = buf[(size_t)(e16 >> 1) * P + ra];
+        const int64_t o = ((int64_t)pf * p.nra + ra) * p.nel + ele;
+        p.map[o] = (e16 & 1) ? -v.y * sc : v.x * sc;
+        p.weight[o] = wv;
+      }
+    return;
+  }
   for (int half = 0; half < 2; ++half) {
     if (half == 1) {  // the parked image of elevations 8-15 comes in (coalesced reads, bit reversal on the LDS side)
       __syncthreads();
@@ -770,11 +787,17 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
     // sixteen elevations per block: 128-byte pieces of the input rows ("ringmap_variant" = 2: the 8-elevation form)
     const int ntile_el = (nel + kFuEl16 - 1) / kFuEl16;
     const int64_t ntile = (int64_t)ntile_el * npol * nfreq;
-    void* park = nullptr;
-    rc = dmm_get_scratch(ctx, (size_t)ntile * 4 * nra * sizeof(double2) + 256, &park);
-    if (rc) return rc;
-    DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fused16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
-    hipLaunchKernelGGL(k_rm_fused16, dim3((unsigned)ntile), dim3(kFuThreads), fused_lds, ctx->stream, p, q, ntile_el, (double2*)park);
+    const size_t lds16 = (size_t)8 * q.P * sizeof(double2) + tw_b;  // all sixteen elevations' image in the LDS?
+    if (lds16 <= 150 * 1024) {
+      DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fused16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+      hipLaunchKernelGGL(k_rm_fused16<false>, dim3((unsigned)ntile), dim3(kFuThreads), lds16, ctx->stream, p, q, ntile_el, (double2*)nullptr);
+    } else {
+      void* park = nullptr;
+      rc = dmm_get_scratch(ctx, (size_t)ntile * 4 * nra * sizeof(double2) + 256, &park);
+      if (rc) return rc;
+      DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fused16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
+      hipLaunchKernelGGL(k_rm_fused16<true>, dim3((unsigned)ntile), dim3(kFuThreads), fused_lds, ctx->stream, p, q, ntile_el, (double2*)park);
+    }
     DMM_HIP(hipGetLastError());
     return DMM_OK;
   }

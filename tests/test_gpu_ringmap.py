@@ -220,7 +220,8 @@ def test_analytic_beam_vs_oracle(mmax, oddra, nel, nfreq):
         assert np.all(got[mmax, 1] == 0)
 
 
-def test_single_pass_kernel_against_the_three_kernel_form():
+@pytest.mark.parametrize("nm,nel", [(257, 77), (1025, 37)])  # nra 512: all sixteen elevations' image in the LDS; nra 2048: the second eight parked
+def test_single_pass_kernel_against_the_three_kernel_form(nm, nel):
     """The single-pass kernel (power-of-two nra, no RA-space dirty beam, own-row normalisation: reduce, inverse FFT and
     the [ra][el] store in one pass over the m-modes; 16 elevations per block, the second eight parked in a scratch image,
     and the 8-elevation form of round 3) against the three-kernel form on the same
@@ -231,7 +232,7 @@ def test_single_pass_kernel_against_the_three_kernel_form():
     from draco_amd.device import Context, ptr
 
     ctx = Context.get()
-    nm, npol, nfreq, new, nel = 257, 2, 3, 4, 77
+    npol, nfreq, new = 2, 3, 4
     nra = 2 * (nm - 1)
     gen = torch.Generator(device=ctx.device).manual_seed(3)
     shp = (nm, 2, npol, nfreq, new, nel)
