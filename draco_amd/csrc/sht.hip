@@ -231,6 +231,7 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   lp.n_m = n_m;
   lp.alm = alm;
   lp.b = b;
+  lp.m_identity = (ctx->opt_sht_variant & 32) ? 1 : 0;
   if (NPOL == 4 && !(ctx->opt_sht_variant & 8)) {  // bit 3: force the vector-ALU kernel
     const int npair = (g.nring + 1) / 2;
     hipLaunchKernelGGL(k_leg_synth_mfma, dim3(g.mmax + 1, (npair + kThreads - 1) / kThreads, (nf + kLegF - 1) / kLegF), dim3(kThreads), 0, ctx->stream, lp);
@@ -301,6 +302,7 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   lp.b = b;
   lp.alm = alm;
   lp.accumulate = accumulate;
+  lp.m_identity = (ctx->opt_sht_variant & 32) ? 1 : 0;
   if (NPOL == 4 && !(ctx->opt_sht_variant & 8)) {  // bit 3: force the vector-ALU kernels
     // 4-wave blocks, two per CU, the ring pairs in passes of 256 (default since round 4: map2alm 0.116 -> 0.110 ms per
     // frequency at cfg 3, -4.4 % with three iterations); bit 4 of sht_variant: the 8-wave block of rounds 1-3 (A/B)

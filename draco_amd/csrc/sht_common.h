@@ -47,6 +47,7 @@ struct LegParams {
   int n_m;                // m-stride of alm (= mmax+1 of the alm buffer)
   const double2* alm;     // [nf, npol, n_m, lmax+1]
   double2* b;             // [nf, npol, nring, mmax+1]
+  int m_identity;         // 1: block b takes m = b (sht_variant bit 5, the A/B of leg_m_of_block)
 };
 
 // LDS image of one (f, m): coefficient rows + npol a_lm columns

@@ -6,6 +6,18 @@
 namespace {
 
 // ---------------------------------------------------------------- synthesis, stage 1
+// block -> m.  Every Legendre kernel reads or writes ONE m of the ring-coefficient array [freq][pol][ring][m]: 16-byte
+// pieces 8 KB apart, eight consecutive m to a 128-byte line.  Workgroups go to the eight XCDs (each with its own L2) round
+// robin by linear id, so with m = blockIdx.x the eight blocks that share a line sat on eight different L2s: every line was
+// fetched (analysis) or partially written (synthesis) eight times over.  Here the blocks b, b + 8, ..., b + 56 of one XCD
+// take eight consecutive m (groups of 64; a last partial group keeps m = b).
+__device__ __forceinline__ int leg_m_of_block(int b, int n_m, int variant_identity) {
+  if (variant_identity) return b;
+  const int q = b >> 6, r = b & 63;
+  if (q * 64 + 64 > n_m) return b;
+  return q * 64 + (r & 7) * 8 + (r >> 3);
+}
+
 template <int NPOL, int NR, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void k_leg_synth(LegParams p) {
   const int m = blockIdx.x, f = blockIdx.y;
@@ -161,7 +173,7 @@ constexpr int kLegL = 8, kLegF = 4, kLegPitch = 72;
 __global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ double slab[kThreads / 64][3][kLegL][kLegPitch];
-  const int m = blockIdx.x, rc = blockIdx.y, f0 = blockIdx.z * kLegF;
+  const int m = leg_m_of_block(blockIdx.x, p.g.mmax + 1, p.m_identity), rc = blockIdx.y, f0 = blockIdx.z * kLegF;
   const int lmax = p.g.lmax, nl = lmax - m + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nring = p.g.nring, npair = (nring + 1) / 2;
@@ -310,6 +322,7 @@ struct LegAnalParams {
   const double2* b;   // [nf, npol, nring, mmax+1] ring coefficients g_m
   double2* alm;       // [nf, npol, n_m, lmax+1]
   int accumulate;     // 1: alm += result (Jacobi refinement)
+  int m_identity;     // 1: block b takes m = b (sht_variant bit 5)
 };
 
 // Sum NV per-lane values over the 64 lanes of a wave with a halving butterfly: at each of
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p)
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ double slab[kAnWaves][(kAnL + 1) * kAnPitch];  // row 0: lambda of the step before the chunk
   __shared__ double ringtab[kAnWaves][2][64];                // x / sin^2, 1 / sin^2 of the wave's rings
-  const int m = blockIdx.x, f0 = blockIdx.y * kLegF;
+  const int m = leg_m_of_block(blockIdx.x, p.g.mmax + 1, p.m_identity), f0 = blockIdx.y * kLegF;
   const int lmax = p.g.lmax, nl = lmax - m + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nring = p.g.nring, npair = (nring + 1) / 2;
