@@ -49,6 +49,7 @@ struct dmm_ctx {
   int64_t opt_ml_ws_mib = 0, opt_wiener_ws_mib = 0;  // workspace the ML / Wiener solves size themselves for (0: 20 / 6 GiB)
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
   double ml_pass_rate = 1.0;               // share of the last certificate batch / probe that passed (dmm_ml_run starts the next call from it)
+  int opt_ml_chase_grid = 0;               // > 0: the bulge-chase kernel's grid is capped at this many blocks (each loops over matrices)
   int opt_ml_null = 0;                     // 1: no null certificate (tiles whose Frobenius norm puts every singular value below acond are decomposed like any other)
   int64_t ml_gram_flops = 0, ml_band_bytes = 0;  // counters: useful flops of the ML Gram launches (4 k^2 K per tile), algorithmic bytes of stage 1 of the two-stage reduction (8.5 KB per lower-triangle tile and panel)
   int64_t ml_tiles_null = 0;               // counter: tiles the null certificate answered with zero

@@ -694,21 +694,23 @@ __device__ __forceinline__ double2 sb_shfl2(double2 v, int src) { return make_do
 constexpr int kSbCW = 4;
 constexpr int kSbLag = 2;  // iterations between consecutive sweeps (see the kernel's comment)
 __host__ __device__ constexpr int sb_pitch(int n) { return n + 2; }  // a column's 8 lanes (stride pitch - 1 or pitch) spread over the banks
-__global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
+__global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) {
   extern __shared__ __align__(16) unsigned char smem_sb[];
   __shared__ int s_prog[kSbCW];
   __shared__ __align__(16) double2 s_scr[kSbCW][64];
   const DenseParams& p = tp.d;
   const int n = p.Np, pitch = sb_pitch(n);
-  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
-  const double2* A = p.A + (int64_t)mat * n * n;
   double2* ab = reinterpret_cast<double2*>(smem_sb);
   const int bg0 = (kSbB + 1) * pitch;  // the bulge triangles follow the band
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, c = lane & 7;
+  // a block works through the matrices bi = blockIdx.x, blockIdx.x + gridDim.x, ... (grid < nmat: "ml_chase_grid")
+  for (int bi = blockIdx.x; bi < nmat; bi += gridDim.x) {
+  const int mat = p.msel ? p.msel[bi] : bi;
+  const double2* A = p.A + (int64_t)mat * n * n;
   double2* const rlog = sb_rlog(tp, mat);
   double2* vbm = tp.vec + (int64_t)mat * td_slots(n) * n;
   double* dd = reinterpret_cast<double*>(vbm + 5 * n);
   double* ee = dd + n;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, c = lane & 7;
   // (Tried: s_setprio(3) for this kernel's and the serial QL's waves -- beside the next chunk's Gram / sweep kernels a
   // chase launch takes 2.4 x what it takes alone.  No change: 668 against 680 ms of chase per 32 frequencies.  What the
   // chase waits for in the step is a CU whose LDS is EMPTY, not issue slots.)
@@ -891,6 +893,8 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp) {
   if (threadIdx.x == 0) {
     dd[n - 1] = ab[n - 1].x;
     ee[n - 1] = 0.0;
+  }
+  __syncthreads();  // (the next matrix's band overwrites the image)
   }
 #undef SB_FENCE
 #undef SB_PROG_LOAD

@@ -115,8 +115,11 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   tp.j = K;
   panel();
 }
-void sb_chase(const TdParams& tp, int nmat, hipStream_t st) {
-  hipLaunchKernelGGL(k_sb_chase, dim3(nmat), dim3(64 * kSbCW), sb_chase_lds(tp.d.Np), st, tp);
+void sb_chase(const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0) {
+  // grid_cap > 0 ("ml_chase_grid"): at most that many blocks, each working through several matrices -- the chase keeps a
+  // CU's whole LDS, so a capped grid confines it to that many CUs instead of letting it take every CU in turn
+  const int grid = grid_cap > 0 && grid_cap < nmat ? grid_cap : nmat;
+  hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), sb_chase_lds(tp.d.Np), st, tp, nmat);
 }
 
 // QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
@@ -977,7 +980,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
             sb_reduce(tp, nsel, ctx->stream);
           }
           dmm_prof_scope prof(ctx, DMM_PROF_CHASE, ctx->stream);
-          sb_chase(tp, nsel, ctx->stream);
+          sb_chase(tp, nsel, ctx->stream, ctx->opt_ml_chase_grid);
         } else {
           dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, ctx->stream);
           td_reduce(tp, nsel, ctx->stream);
@@ -1188,7 +1191,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
     if (tp.two_stage) {  // the chase is one wave per matrix, as latency bound as QL: it runs beside the next chunk's sweeps too
       dmm_prof_scope prof(ctx, DMM_PROF_CHASE, S2);
-      sb_chase(tp, nmat, S2);
+      sb_chase(tp, nmat, S2, ctx->opt_ml_chase_grid);
     }
     {
       dmm_prof_scope prof(ctx, DMM_PROF_QL, S2);

@@ -80,7 +80,10 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * "ml_null" (0, default: a tile whose weighted Frobenius norm puts EVERY singular value at or below acond is answered
  * with zero -- what pinv_svd's rule gives -- without a Gram matrix or a decomposition; 1: such tiles are decomposed
  * like any other, with the same result),
- * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies),
+ * "ml_chase_grid" (0, default: one bulge-chase block per matrix; > 0: at most that many persistent blocks, each working
+ * through several matrices -- an A/B of DESIGN 5.5),
+ * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies; 2 = the
+ * single pass with 8 instead of 16 elevations per block),
  * "ml_reduce" (tridiagonal reduction of the eigen path: 0 = two-stage, dense -> band of half-width 8 on the matrix
  * cores over the lower triangle -> tridiagonal by bulge chasing in LDS, for orders whose band fits the LDS, one-stage
  * Householder otherwise; 1 = one-stage always; 2 = two-stage with sweeps over both triangles, the first form),
