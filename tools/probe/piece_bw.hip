@@ -135,7 +135,6 @@ int main() {
     run<256, 16>(buf, rows, nslab, sink, threads);
     run<512, 16>(buf, rows, nslab, sink, threads);
     run<1024, 16>(buf, rows, nslab, sink, threads);
-    run<4096, 16>(buf, rows, nslab, sink, threads);
   }
   return 0;
 }
