@@ -175,3 +175,40 @@ def test_many_baselines_take_smaller_day_groups_and_one_polarisation_falls_back(
         many = t.process_many(days)
         for d in range(D):
             np.testing.assert_array_equal(many[d].map[:], t.process(days[d]).map[:])
+
+
+def test_cfg3_tile_size_days_share_the_reads_bit_identically():
+    """BASELINE cfg-3 tile size (379 baselines, lmax 512; 2 frequencies = 12.8 GB of tiles), 11 days = groups of 8 + 2 + 1:
+    every day's a_lm equals the single-day launch, and the adjointness <B a, v> = <a, B^H v> ties day 10 to k_project."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis._solve import SolveEngine
+    from draco_amd.core.products import SyntheticProvider, TransitTelescope
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    c = osyn.CONFIGS[3]
+    nfreq, D = 2, 11
+    tel = TransitTelescope(osyn.frequencies(nfreq), lmax=c["lmax"], ncyl=c["ncyl"], nfeed_cyl=c["nfeed_cyl"])
+    assert tel.npairs == 379 and tel.lmax == 512
+    eng = SolveEngine(SyntheticProvider(tel, seed=3003), ctx, _lib.DMM_C128, _lib.DMM_B_PACKED, cache=True)
+    gen = torch.Generator(device=ctx.device).manual_seed(4)
+    shape = (tel.lmax + 1, 2, nfreq, tel.npairs)
+    mv = [torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen) for _ in range(D)]
+    mw = [torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) for _ in range(D)]
+    many = eng.solve_many("dirty", mv, mw, list(range(nfreq)), tel.lmax)
+    for d in (0, 7, 8, 9, 10):
+        assert torch.equal(many[d], eng.solve("dirty", mv[d], mw[d], list(range(nfreq)), tel.lmax)), d
+    a = torch.randn(many[10].shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    for m in range(tel.lmax + 1):
+        a[:, :, m, :m] = 0
+    ones = torch.ones(shape, dtype=torch.float64, device=ctx.device)
+    bhv = eng.solve_many("dirty", [mv[10]] * 2, [ones] * 2, list(range(nfreq)), tel.lmax)[1]
+    ba = eng.project(a, list(range(nfreq)), tel.lmax)
+    lhs, rhs = (ba.conj() * mv[10]).sum(), (a.conj() * bhv).sum()
+    assert abs((lhs - rhs).item()) < 1e-12 * abs(lhs.item())
+    del eng
+    from draco_amd.analysis import _solve
+
+    _solve.release_pools()
