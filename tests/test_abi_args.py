@@ -126,3 +126,21 @@ def test_collective_entry_points_validate_their_arguments():
     _arg_error(lib.dmm_allgather_map(FAKE, FAKE, None, 8, BUF), "NULL argument")
     _arg_error(lib.dmm_allgather_map(FAKE, FAKE, BUF, -1, BUF), "negative count")
     assert lib.dmm_comm_destroy(None) == 0  # destroying nothing is fine
+
+
+def test_round4_entries_check_their_arguments():
+    """`dmm_dirty_run_multi`, `dmm_ctx_set_ml_diag` and the new options / counters: NULL handles and bad counts are refused
+    before anything is dereferenced."""
+    lib = _lib.lib
+    PA = C.c_void_p * 2
+    pv = PA(BUF, BUF)
+    _arg_error(lib.dmm_dirty_run_multi(None, BUF, pv, pv, pv, 2), "NULL argument")
+    _arg_error(lib.dmm_dirty_run_multi(FAKE, None, pv, pv, pv, 2), "NULL argument")
+    _arg_error(lib.dmm_dirty_run_multi(FAKE, BUF, None, pv, pv, 2), "NULL argument")
+    _arg_error(lib.dmm_dirty_run_multi(FAKE, BUF, pv, pv, pv, 0), "nday = 0")
+    _arg_error(lib.dmm_dirty_run_multi(FAKE, C.c_void_p(0x2008), pv, pv, pv, 2), "16-byte aligned")
+    _arg_error(lib.dmm_dirty_run_multi(FAKE, BUF, pv, pv, PA(BUF, BUF), 2), "share their alm")
+    _arg_error(lib.dmm_dirty_run_multi(FAKE, BUF, PA(BUF, None), pv, PA(BUF, C.c_void_p(0x3000)), 2), "NULL array of day 1")
+    _arg_error(lib.dmm_ctx_set_ml_diag(None, BUF), "ctx is NULL")
+    _arg_error(lib.dmm_ctx_set_option(None, b"ml_null", 1), "NULL")
+    assert _lib.DMM_E_COMM == -5
