@@ -249,6 +249,7 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   rp.npol = NPOL;
   rp.b = b;
   rp.map = map;
+  rp.map_ref = nullptr;
   rp.npix = 12LL * g.nside * g.nside;
   constexpr int NROWS = NPOL == 4 ? 2 : 1;  // complex transforms per ring (two polarisations each)
   const int force_direct = ctx->opt_sht_variant & 4;
@@ -270,13 +271,15 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
 }
 
 template <int NPOL>
-int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int nf, double2* b, double2* alm, int accumulate) {
+int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int nf, double2* b, double2* alm, int accumulate,
+               const double* map_ref = nullptr) {
   RingParams rp;
   rp.g = g;
   rp.nf = nf;
   rp.npol = NPOL;
   rp.b = b;
   rp.map = const_cast<double*>(map);
+  rp.map_ref = map_ref;
   rp.npix = 12LL * g.nside * g.nside;
   constexpr int NROWS = NPOL == 4 ? 2 : 1;
   const int force_direct = ctx->opt_sht_variant & 4;
@@ -378,10 +381,8 @@ int dmm_map2alm(dmm_ctx* ctx, const double* map, int nfreq, int npol, int lmax, 
     for (int it = 0; it < niter; ++it) {  // a += A(map - S a)
       rc = npol == 4 ? synth_chunk<4>(ctx, g, a, n_m, nf, b, resid) : synth_chunk<1>(ctx, g, a, n_m, nf, b, resid);
       if (rc) return rc;
-      const int64_t n = (int64_t)nf * npol * npix;
-      hipLaunchKernelGGL(k_sub, dim3(2048), dim3(256), 0, ctx->stream, resid, mp, n);
-      DMM_HIP(hipGetLastError());
-      rc = npol == 4 ? anal_chunk<4>(ctx, g, resid, n_m, nf, b, a, 1) : anal_chunk<1>(ctx, g, resid, n_m, nf, b, a, 1);
+      // the residual map - S a is formed by the ring analysis as it reads (one pass over the maps less than a k_sub launch)
+      rc = npol == 4 ? anal_chunk<4>(ctx, g, resid, n_m, nf, b, a, 1, mp) : anal_chunk<1>(ctx, g, resid, n_m, nf, b, a, 1, mp);
       if (rc) return rc;
     }
   }

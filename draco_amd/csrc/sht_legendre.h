@@ -699,10 +699,5 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p)
   }
 }
 
-__global__ void k_sub(double* __restrict__ a, const double* __restrict__ b, int64_t n) {  // a = b - a
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) a[i] = b[i] - a[i];
-}
 
 }  // namespace

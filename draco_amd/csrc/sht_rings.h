@@ -12,6 +12,8 @@ struct RingParams {
   double2* b;     // [nf, npol, nring, mmax+1]
   double* map;    // [nf, npol, npix]
   int64_t npix;
+  const double* map_ref;  // analysis only, or nullptr: the field analysed is map_ref - map (the residual of a Jacobi iteration of
+                          // map2alm, formed on the way in instead of by a pass of its own over the maps)
 };
 
 // A launch covers one CLASS of rings that share an FFT length:
@@ -310,7 +312,8 @@ __global__ __launch_bounds__(kThreads) void k_ring_anal(RingParams p, RingClass 
   const int64_t base = p.g.start[ring];
   for (int idx = threadIdx.x; idx < NPOL * nphi; idx += kThreads) {
     const int pol = idx / nphi, j = idx - pol * nphi;
-    px[idx] = p.map[((int64_t)f * NPOL + pol) * p.npix + base + j];
+    const int64_t pi = ((int64_t)f * NPOL + pol) * p.npix + base + j;
+    px[idx] = p.map_ref ? p.map_ref[pi] - p.map[pi] : p.map[pi];
   }
   __syncthreads();
   const double w = 4.0 * M_PI / (double)p.npix;
@@ -359,8 +362,9 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, Rin
     for (int r = 0; r < NROW; ++r) {
       C<double> v = {0.0, 0.0};
       if (k < n) {
-        v.x = p.map[((int64_t)f * NPOL + (NPOL == 4 ? 2 * (r + rb) : 0)) * p.npix + base + k];
-        if (NPOL == 4) v.y = p.map[((int64_t)f * NPOL + 2 * (r + rb) + 1) * p.npix + base + k];
+        const int64_t p0 = ((int64_t)f * NPOL + (NPOL == 4 ? 2 * (r + rb) : 0)) * p.npix + base + k, p1 = p0 + p.npix;
+        v.x = p.map_ref ? p.map_ref[p0] - p.map[p0] : p.map[p0];
+        if (NPOL == 4) v.y = p.map_ref ? p.map_ref[p1] - p.map[p1] : p.map[p1];
         if (BLUE) v = dmm_fft::cmul<double>(v, l.chirp[k]);
       }
       l.buf[r * P + k] = v;
