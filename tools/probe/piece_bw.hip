@@ -96,6 +96,40 @@ void run_rm(const char* buf, int nm, int npf, double* sink) {
   printf("ring-map order, %d m per wave-load, 128-byte pieces: %.3f ms  %.2f TB/s\n", MPW, best, 2.0 * arr / best / 1e9);
 }
 
+// the same in WRITES: a block owns W bytes of every 4 KB row (what the m-mode pack and the ring-map store do)
+template <int W>
+__global__ __launch_bounds__(1024) void k_write(char* __restrict__ buf, int64_t rows_per_slab, int nslab) {
+  constexpr int LPP = W / 16, RPW = 64 / LPP;
+  const int pieces = 4096 / W;
+  const int slab = blockIdx.x / pieces, piece = blockIdx.x % pieces;
+  if (slab >= nslab) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  char* base = buf + (int64_t)slab * rows_per_slab * 4096 + (int64_t)piece * W + (lane % LPP) * 16;
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d val = {(double)lane, (double)wave};
+  for (int64_t r = (int64_t)wave * RPW + lane / LPP; r < rows_per_slab; r += (int64_t)nwave * RPW)
+    __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(base + r * 4096));
+}
+
+template <int W>
+void run_w(char* buf, int64_t rows_per_slab, int nslab) {
+  const int grid = nslab * (4096 / W);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  float best = 1e9;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((k_write<W>), dim3(grid), dim3(1024), 0, 0, buf, rows_per_slab, nslab);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    if (rep) best = ms < best ? ms : best;
+  }
+  printf("WRITE piece %4d B (16 B per lane, non-temporal), grid %5d: %.3f ms  %.2f TB/s\n", W, grid, best, (double)nslab * rows_per_slab * 4096 / best / 1e9);
+}
+
 template <int W, int LB>
 void run(const char* buf, int64_t rows_per_slab, int nslab, double* sink, int threads) {
   const int grid = nslab * (4096 / W);
@@ -126,6 +160,10 @@ int main() {
   hipMalloc(&buf, (size_t)nslab * rows * 4096);
   hipMalloc(&sink, 8);
   hipMemset(buf, 1, (size_t)nslab * rows * 4096);
+  run_w<64>(buf, rows, nslab);
+  run_w<128>(buf, rows, nslab);
+  run_w<256>(buf, rows, nslab);
+  run_w<512>(buf, rows, nslab);
   run_rm<4>(buf, 1025, 32, sink);
   run_rm<1>(buf, 1025, 32, sink);
   for (int threads : {1024}) {
