@@ -37,10 +37,10 @@ def test_bench_two_ranks_on_one_gpu(scaling):
 
 def test_bench_refuses_more_ranks_than_gpus():
     """`--gpus 8` on a one-GPU box must fail loudly, not run one rank and print n_gpus = 1."""
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-cpu-baseline"], cwd=ROOT,
-                         env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}, capture_output=True, text=True, timeout=300)
     import torch
 
-    if torch.cuda.device_count() >= 8:
+    if torch.cuda.device_count() >= 8:  # (counting devices does not initialise the GPU)
         pytest.skip("an 8-GPU box: the command is a real run here")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-cpu-baseline"], cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "GPU(s) visible" in res.stderr and not res.stdout.strip()
