@@ -48,6 +48,7 @@ struct dmm_ctx {
   int opt_ml_eigen = 0;                    // 0: by batch size (tridiagonalisation + QL for large batches, blocked Jacobi for a few matrices); 1: Jacobi; 4: tridiagonal; 2: tridiagonal with full-matrix trailing updates; 3: tridiagonal with QL made to give up (Jacobi fallback)
   int64_t opt_ml_ws_mib = 0, opt_wiener_ws_mib = 0;  // workspace the ML / Wiener solves size themselves for (0: 20 / 6 GiB)
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
+  int ml_probe_every = 8;                  // how thinly dmm_ml_run probes the certificate while the probes keep failing (8 ... 64 batches; remembered with the rate)
   double ml_pass_rate = 1.0;               // share of the last certificate batch / probe that passed (dmm_ml_run starts the next call from it)
   int opt_ml_chase_grid = 0;               // > 0: the bulge-chase kernel's grid is capped at this many blocks (each loops over matrices)
   int opt_ml_null = 0;                     // 1: no null certificate (tiles whose Frobenius norm puts every singular value below acond are decomposed like any other)

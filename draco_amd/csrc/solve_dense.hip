@@ -345,8 +345,9 @@ __global__ __launch_bounds__(kThreads) void k_ml_filter(JacobiParams jp) {
 // bench.py --maker ml that is every tile above m ~ 300, two fifths of the day's tiles.
 // grid (ntile, kTraceSplit): a block sums the rows of its split, lanes along the contiguous packed row.
 constexpr int kTraceSplit = 4;
-__global__ __launch_bounds__(kThreads) void k_ml_trace(const dmm_tile* __restrict__ tiles, DenseParams p, double* __restrict__ trace) {
-  const dmm_tile tile = tiles[blockIdx.x];
+__global__ __launch_bounds__(kThreads) void k_ml_trace(const dmm_tile* __restrict__ tiles, DenseParams p, double* __restrict__ trace,
+                                                       const int32_t* __restrict__ list) {
+  const dmm_tile tile = tiles[list[blockIdx.x]];  // (trace[blockIdx.x] belongs to tile list[blockIdx.x])
   const int L = p.lmax + 1 - tile.m;
   const int pol_stride = p.full_layout ? p.lmax + 1 : L;
   const int col0 = p.full_layout ? tile.m : 0;
@@ -772,33 +773,70 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   const int inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;  // tools/ml_tune.py
 
   // Null certificate (k_ml_trace): tiles whose Frobenius norm says that EVERY singular value is at or below acond keep
-  // nothing under pinv_svd's rule -- their a_lm is zero and they never see a Gram matrix.  One pass over B; the scratch
+  // nothing under pinv_svd's rule -- their a_lm is zero and they never see a Gram matrix.  Which tiles are worth the pass
+  // is found on a SAMPLE first: a telescope sees the sky up to some m, so per frequency every 16th m is tried from the top
+  // down (6 % of the bytes of B), and only the tiles above the highest sampled m that is NOT null are then checked one by
+  // one (a tile is never called null unseen; a null tile below that m is simply decomposed like any other).  The scratch
   // is the workspace header (the prior tables of the Wiener solve: unused here).  "ml_null" = 1 switches it off.
   std::vector<char> is_null(pl->ntile, 0);
-  if (ctx->opt_ml_null == 0 && acond > 0.0 && (size_t)pl->ntile * (sizeof(double) + sizeof(int32_t)) <= L.header) {
+  if (ctx->opt_ml_null != 1 && acond > 0.0 && (size_t)pl->ntile * (sizeof(double) + sizeof(int32_t)) <= L.header) {
     double* const trace_d = (double*)ws;
-    int32_t* const null_d = (int32_t*)(trace_d + pl->ntile);
-    DMM_HIP(hipMemsetAsync(trace_d, 0, pl->ntile * sizeof(double), ctx->stream));
-    {
-      dmm_prof_scope prof(ctx, DMM_PROF_NULL, ctx->stream);
-      hipLaunchKernelGGL(k_ml_trace, dim3((unsigned)pl->ntile, kTraceSplit), dim3(kThreads), 0, ctx->stream, pl->tiles_d, base, trace_d);
-    }
-    DMM_HIP(hipGetLastError());
-    std::vector<double> trace_h(pl->ntile);
-    DMM_HIP(hipMemcpyAsync(trace_h.data(), trace_d, pl->ntile * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    DMM_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<int32_t> null_h;
+    int32_t* const list_d = (int32_t*)(trace_d + pl->ntile);
     // (the sum is exact to a few ulp; the margin keeps a tile AT the threshold on the decomposing side, where the cut
     // is decided on the eigenvalues themselves)
     const double lim = acond * acond * (1.0 - 1e-9);
-    for (int64_t t = 0; t < pl->ntile; ++t)
-      if (trace_h[t] <= lim) {
-        is_null[t] = 1;
-        null_h.push_back((int32_t)t);
+    std::vector<double> trace_h;
+    auto traces = [&](const std::vector<int32_t>& list) -> int {  // trace_h[i] = trace of tile list[i]
+      if (list.empty()) return DMM_OK;
+      DMM_HIP(hipMemcpyAsync(list_d, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+      DMM_HIP(hipMemsetAsync(trace_d, 0, list.size() * sizeof(double), ctx->stream));
+      {
+        dmm_prof_scope prof(ctx, DMM_PROF_NULL, ctx->stream);
+        hipLaunchKernelGGL(k_ml_trace, dim3((unsigned)list.size(), kTraceSplit), dim3(kThreads), 0, ctx->stream, pl->tiles_d, base, trace_d,
+                           (const int32_t*)list_d);
+      }
+      DMM_HIP(hipGetLastError());
+      trace_h.resize(list.size());
+      DMM_HIP(hipMemcpyAsync(trace_h.data(), trace_d, list.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      DMM_HIP(hipStreamSynchronize(ctx->stream));  // (also: `list` may die now)
+      return DMM_OK;
+    };
+    // per frequency: the tiles sorted by m
+    std::map<int, std::vector<std::pair<int, int32_t>>> by_f;
+    for (int64_t t = 0; t < pl->ntile; ++t) by_f[pl->tiles_h[t].f].push_back({pl->tiles_h[t].m, (int32_t)t});
+    std::vector<int32_t> sample;
+    for (auto& kv : by_f) {
+      std::sort(kv.second.begin(), kv.second.end());
+      for (int64_t i = (int64_t)kv.second.size() - 1; i >= 0; i -= (ctx->opt_ml_null == 2 ? 1 : 16)) sample.push_back(kv.second[i].second);  // ("ml_null" = 2: every tile, the A/B)
+    }
+    int rc = traces(sample);
+    if (rc) return rc;
+    std::map<int32_t, double> seen;
+    for (size_t i = 0; i < sample.size(); ++i) seen[sample[i]] = trace_h[i];
+    std::vector<int32_t> rest;
+    for (auto& kv : by_f) {
+      // from the top: the sampled tiles are null down to (excluding) position `stop`; everything above it is a candidate
+      int64_t stop = -1;
+      for (int64_t i = (int64_t)kv.second.size() - 1; i >= 0; i -= (ctx->opt_ml_null == 2 ? 1 : 16))
+        if (!(seen[kv.second[i].second] <= lim)) {
+          stop = i;
+          break;
+        }
+      for (int64_t i = stop + 1; i < (int64_t)kv.second.size(); ++i)
+        if (!seen.count(kv.second[i].second)) rest.push_back(kv.second[i].second);
+    }
+    rc = traces(rest);
+    if (rc) return rc;
+    for (size_t i = 0; i < rest.size(); ++i) seen[rest[i]] = trace_h[i];
+    std::vector<int32_t> null_h;
+    for (auto& sv : seen)
+      if (sv.second <= lim) {
+        is_null[sv.first] = 1;
+        null_h.push_back(sv.first);
       }
     if (!null_h.empty()) {
-      DMM_HIP(hipMemcpyAsync(null_d, null_h.data(), null_h.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_zero_alm_tiles, dim3((unsigned)null_h.size()), dim3(kThreads), 0, ctx->stream, pl->tiles_d, null_d, base, (double2*)alm);
+      DMM_HIP(hipMemcpyAsync(list_d, null_h.data(), null_h.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_zero_alm_tiles, dim3((unsigned)null_h.size()), dim3(kThreads), 0, ctx->stream, pl->tiles_d, list_d, base, (double2*)alm);
       DMM_HIP(hipGetLastError());
       DMM_HIP(hipStreamSynchronize(ctx->stream));  // null_h dies with this block
       ctx->ml_tiles_null += (int64_t)null_h.size();
@@ -1301,7 +1339,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   // full batch, and while the probes keep failing they thin out: every 8th batch, then every 16th, ... (a full batch of
   // rejects costs a Gram matrix and two factorisations per tile: 6 % of the structured-tile day went there).
   double pass_rate = ctx->ml_pass_rate;
-  int batch_no = 0, probe_every = 8;
+  int batch_no = 0, probe_every = ctx->ml_probe_every;
   auto certify = [&](const std::vector<int64_t>& list, size_t i0, int nmat, bool sky, int np_sky, int off) -> int {
     if (pass_rate < 0.3 && batch_no > 0 && (++batch_no % probe_every) != 0) {
       std::vector<int64_t>& d = sky ? sky_deferred[np_sky] : tel_deferred;
@@ -1319,6 +1357,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     pass_rate = (double)(ctx->ml_tiles_direct - before) / (double)first;
     ctx->ml_pass_rate = pass_rate;
     if (probe) probe_every = pass_rate < 0.3 ? std::min(probe_every * 2, 64) : 8;
+    ctx->ml_probe_every = probe_every;
     if (rc || first == nmat) return rc;
     if (pass_rate >= 0.3) return run_batch(list, i0 + first, nmat - first, sky, np_sky, false, off);
     std::vector<int64_t>& d = sky ? sky_deferred[np_sky] : tel_deferred;

@@ -78,8 +78,9 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give
  * up on every other matrix, which exercises the Jacobi fallback),
  * "ml_null" (0, default: a tile whose weighted Frobenius norm puts EVERY singular value at or below acond is answered
- * with zero -- what pinv_svd's rule gives -- without a Gram matrix or a decomposition; 1: such tiles are decomposed
- * like any other, with the same result),
+ * with zero -- what pinv_svd's rule gives -- without a Gram matrix or a decomposition, the candidates found on a sample of
+ * every 16th m per frequency; 1: such tiles are decomposed like any other, with the same result; 2: every tile's norm is
+ * taken, the A/B of the sampling),
  * "ml_chase_grid" (0, default: one bulge-chase block per matrix; > 0: at most that many persistent blocks, each working
  * through several matrices -- an A/B of DESIGN 5.5),
  * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies; 2 = the
