@@ -50,6 +50,7 @@ struct dmm_ctx {
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
   int ml_probe_every = 8;                  // how thinly dmm_ml_run probes the certificate while the probes keep failing (8 ... 64 batches; remembered with the rate)
   double ml_pass_rate = 1.0;               // share of the last certificate batch / probe that passed (dmm_ml_run starts the next call from it)
+  int opt_ml_chase_layout = 0;             // 1: the bulge chase uses the bank-spread band layout in LDS (A/B; no effect on its run time)
   int opt_ml_chase_grid = 0;               // > 0: the bulge-chase kernel's grid is capped at this many blocks (each loops over matrices)
   int opt_ml_null = 0;                     // 1: no null certificate (tiles whose Frobenius norm puts every singular value below acond are decomposed like any other)
   int64_t ml_gram_flops = 0, ml_band_bytes = 0;  // counters: useful flops of the ML Gram launches (4 k^2 K per tile), algorithmic bytes of stage 1 of the two-stage reduction (8.5 KB per lower-triangle tile and panel)

@@ -45,6 +45,8 @@ __host__ __device__ constexpr int64_t sb_nlog(int n) { return sb_total(n - 1); }
 __host__ __device__ constexpr int64_t sb_tail(int n) { return (int64_t)sb_npanel(n) * 64 + sb_nlog(n) * kSbB; }
 // LDS of the chase kernel: band [9][n+1] + bulge triangles [n/8 + 2][21], double2
 __host__ __device__ constexpr size_t sb_chase_lds(int n) { return ((size_t)(kSbB + 1) * (n + 2) + (size_t)(n / kSbB + 2) * 21) * sizeof(double2); }
+// the same for the bank-spread layout of round 4 (pitch n + 1, diagonals 2.. shifted by 6 entries, bulge pitch 22): used where it fits
+__host__ __device__ constexpr size_t sb_chase_lds2(int n) { return ((size_t)(kSbB + 1) * (n + 1) + 6 + (size_t)(n / kSbB + 2) * 22) * sizeof(double2); }
 
 // where a matrix's work arrays live in its log region (single pointers: a struct of them ends up in scratch / LDS)
 __device__ __forceinline__ double2* sb_base(const TdParams& tp, int mat) { return tp.log_cs + (int64_t)mat * tp.log_stride; }
@@ -699,10 +701,17 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
   __shared__ int s_prog[kSbCW];
   __shared__ __align__(16) double2 s_scr[kSbCW][64];
   const DenseParams& p = tp.d;
-  const int n = p.Np, pitch = sb_pitch(n);
+  // Layout of the band image.  tp.chase_layout = 0 (rounds 3): diagonal d at d * (n + 2), bulge pitch 21.  1 (round 4, from the
+  // bank model tools/proto/chase_banks.py: 63-65 instead of 151 extra LDS cycles per step): diagonal d at d * (n + 1) + (6 from
+  // d = 2 on), bulge pitch 22, and the wave's octets take the slots 0 1 4 5 2 3 6 7 -- so that the lanes of one
+  // ds_read_b128 group ({0-3, 12-15, 20-27}, ...) fall on different 16-byte bank slots for every element index.
+  const int n = p.Np, lay = tp.chase_layout;
+  const int pitch = lay ? n + 1 : sb_pitch(n), jump = lay ? 6 : 0, bgp = lay ? 22 : 21;
   double2* ab = reinterpret_cast<double2*>(smem_sb);
-  const int bg0 = (kSbB + 1) * pitch;  // the bulge triangles follow the band
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, c = lane & 7;
+  const int bg0 = (kSbB + 1) * pitch + jump;  // the bulge triangles follow the band
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 7;
+  const int oct = lane >> 3, g = lay ? ((oct & 1) | ((oct & 2) << 1) | ((oct & 4) >> 1)) : oct;
+#define SB_DIAG(d) ((d) * pitch + ((d) >= 2 ? jump : 0))
   // a block works through the matrices bi = blockIdx.x, blockIdx.x + gridDim.x, ... (grid < nmat: "ml_chase_grid")
   for (int bi = blockIdx.x; bi < nmat; bi += gridDim.x) {
   const int mat = p.msel ? p.msel[bi] : bi;
@@ -717,9 +726,9 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
 #define SB_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   for (int e = threadIdx.x; e < (kSbB + 1) * n; e += 64 * kSbCW) {
     const int d = e / n, col = e - d * n;
-    ab[d * pitch + col] = col + d < n ? A[(int64_t)(col + d) * n + col] : SB_ZERO;
+    ab[SB_DIAG(d) + col] = col + d < n ? A[(int64_t)(col + d) * n + col] : SB_ZERO;
   }
-  for (int e = threadIdx.x; e < (n / kSbB + 2) * 21; e += 64 * kSbCW) ab[bg0 + e] = SB_ZERO;
+  for (int e = threadIdx.x; e < (n / kSbB + 2) * bgp; e += 64 * kSbCW) ab[bg0 + e] = SB_ZERO;
   if (threadIdx.x < kSbCW) s_prog[threadIdx.x] = 0;
   __syncthreads();
   // The progress words are read and written with relaxed workgroup-scope atomics ON THE __shared__ ARRAY: ds_read_b32 /
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
   // No branches inside a step (every one of them would end in a wait for its loads, with one wave per SIMD and nothing
   // to hide it): a load that is masked out reads a spare bulge entry that stays zero, a store that is masked out goes to
   // one of 16 spare entries nobody reads.
-  const int zero_at = bg0 + (n / kSbB + 1) * 21 + 16, junk_at = bg0 + (n / kSbB + 1) * 21 + (lane & 15);
+  const int zero_at = bg0 + (n / kSbB + 1) * bgp + 16, junk_at = bg0 + (n / kSbB + 1) * bgp + (lane & 15);
   for (int G = wave; G < ngroup; G += kSbCW) {
     const int j = 8 * G + g;
     const int Tj = j <= n - 2 ? (n - 2 - j) / 8 + 1 : 0;  // iterations of the slot's sweep (the last one has no block below it)
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
         double xn2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          x[i] = ab[r0 + i < n ? (1 + i) * pitch + j : zero_at];
+          x[i] = ab[r0 + i < n ? SB_DIAG(1 + i) + j : zero_at];
           if (i > 0) xn2 += x[i].x * x[i].x + x[i].y * x[i].y;
         }
         const SbRefl rf = sb_larfg(x[0], xn2);
@@ -772,9 +781,9 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
         if (c == 0) {
           ee[j] = rf.beta;
           dd[j] = ab[j].x;
-          ab[1 * pitch + j] = make_double2(rf.beta, 0.0);
+          ab[SB_DIAG(1) + j] = make_double2(rf.beta, 0.0);
 #pragma unroll
-          for (int i = 1; i < 8; ++i) ab[r0 + i < n ? (1 + i) * pitch + j : junk_at] = SB_ZERO;
+          for (int i = 1; i < 8; ++i) ab[r0 + i < n ? SB_DIAG(1 + i) + j : junk_at] = SB_ZERO;
           rlog[lpos * kSbB] = tau;
 #pragma unroll
           for (int i = 1; i < 8; ++i) rlog[lpos * kSbB + i] = v[i];
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const bool in = inc && r0 + i < n;
-          at[i] = in ? (i >= c ? (i - c) * pitch + r0 + c : (c - i) * pitch + r0 + i) : zero_at;
+          at[i] = in ? (i >= c ? SB_DIAG(i - c) + r0 + c : SB_DIAG(c - i) + r0 + i) : zero_at;
           D[i] = ab[at[i]];
         }
         double2 u = SB_ZERO;
@@ -826,7 +835,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const bool in = inc && q0 + i < n;
-          at[i] = in ? (i <= c ? (kSbB + i - c) * pitch + r0 + c : bg0 + it * 21 + i * (i - 1) / 2 + c) : zero_at;
+          at[i] = in ? (i <= c ? SB_DIAG(kSbB + i - c) + r0 + c : bg0 + it * bgp + i * (i - 1) / 2 + c) : zero_at;
           O[i] = ab[in && (i <= c || i <= kSbB - 2) ? at[i] : zero_at];
         }
         // O <- O H = O - tau (O v) v^H
@@ -868,7 +877,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
           cfma(O[i], nf, v2[i]);
           if (i == 0) O[0] = sel2(c == 0, make_double2(rf.beta, 0.0), O[0]);
           // band part back in place; below it (c >= 1) the bulge, in the next sweep's coordinates (i - 1, c - 1)
-          const int to = i <= c ? at[i] : bg0 + it * 21 + (i - 1) * (i - 2) / 2 + c - 1;
+          const int to = i <= c ? at[i] : bg0 + it * bgp + (i - 1) * (i - 2) / 2 + c - 1;
           ab[at[i] != zero_at && (i <= c || c >= 1) ? to : junk_at] = O[i];
         }
         if (c == 0 && oact) {
@@ -897,6 +906,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
   __syncthreads();  // (the next matrix's band overwrites the image)
   }
 #undef SB_FENCE
+#undef SB_DIAG
 #undef SB_PROG_LOAD
 #undef SB_PROG_STORE
 }

@@ -49,6 +49,7 @@ struct TdParams {
   int two_stage;       // 1: the matrices were reduced by herm_band.h (dense -> band -> tridiagonal): k_td_solve applies
                        // Q = Q1 Q2 from the block reflectors in A's upper triangle and the reflector log instead
   int sb_lower;        // 1: stage 1 sweeps the lower triangle only (k_sb_sweep_lo)
+  int chase_layout;    // LDS layout of the bulge chase's band image: 0 = round 3's, 1 = the bank-spread one (herm_band.h)
 };
 
 // pending pair q of a matrix: v at pend + q n, w at pend + (kTdPend + q) n; the arrays live at the head of the

@@ -87,6 +87,9 @@ void td_reduce(TdParams& tp, int nmat, hipStream_t st) {
 
 // ---- two-stage reduction (herm_band.h): dense -> band of half-width 8 on the MFMA units, band -> tridiagonal in LDS
 constexpr size_t kSbLdsMax = 160 * 1024;
+// "ml_chase_layout" = 1: the bank-spread band image of round 4 wherever it fits the LDS (the A/B: it removes most of the
+// chase's LDS bank conflicts and changes nothing in its run time); 0, default: round 3's
+int sb_chase_layout(const dmm_ctx* ctx, int n) { return ctx->opt_ml_chase_layout == 1 && sb_chase_lds2(n) + 4608 <= kSbLdsMax ? 1 : 0; }
 bool sb_usable(const dmm_ctx* ctx, int n) {
   if (ctx->opt_ml_reduce == 1) return false;
   return n >= 64 && n % 64 == 0 && n <= kSbRows * kThreads && sb_chase_lds(n) + 4608 <= kSbLdsMax;  // (+ the chase kernel's static scratch)
@@ -119,7 +122,8 @@ void sb_chase(const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0) {
   // grid_cap > 0 ("ml_chase_grid"): at most that many blocks, each working through several matrices -- the chase keeps a
   // CU's whole LDS, so a capped grid confines it to that many CUs instead of letting it take every CU in turn
   const int grid = grid_cap > 0 && grid_cap < nmat ? grid_cap : nmat;
-  hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), sb_chase_lds(tp.d.Np), st, tp, nmat);
+  const size_t lds = tp.chase_layout ? sb_chase_lds2(tp.d.Np) : sb_chase_lds(tp.d.Np);
+  hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), lds, st, tp, nmat);
 }
 
 // QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
@@ -873,7 +877,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
-    if (sb_usable(ctx, L.Np)) DMM_HIP(hipFuncSetAttribute((const void*)k_sb_chase, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_chase_lds(L.Np)));
+    if (sb_usable(ctx, L.Np)) DMM_HIP(hipFuncSetAttribute((const void*)k_sb_chase, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(sb_chase_lds(L.Np), sb_chase_layout(ctx, L.Np) ? sb_chase_lds2(L.Np) : (size_t)0)));
   }
 
   std::vector<dmm_tile> tiles_c;
@@ -1009,6 +1013,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
         tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
+        tp.chase_layout = sb_chase_layout(ctx, n);
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
         DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
         if (tp.two_stage) {
@@ -1214,6 +1219,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.tri = n <= 2048 ? 1 : 0;
     tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
     tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
+    tp.chase_layout = sb_chase_layout(ctx, n);
     if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
     if (tp.two_stage) {

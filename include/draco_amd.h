@@ -81,6 +81,8 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * with zero -- what pinv_svd's rule gives -- without a Gram matrix or a decomposition, the candidates found on a sample of
  * every 16th m per frequency; 1: such tiles are decomposed like any other, with the same result; 2: every tile's norm is
  * taken, the A/B of the sampling),
+ * "ml_chase_layout" (0, default: the bulge chase's band image in LDS as in round 3; 1: a layout meant to spread the bank
+ * conflicts -- an A/B of DESIGN 5.5: the counted conflicts change, the run time does not),
  * "ml_chase_grid" (0, default: one bulge-chase block per matrix; > 0: at most that many persistent blocks, each working
  * through several matrices -- an A/B of DESIGN 5.5),
  * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies; 2 = the
