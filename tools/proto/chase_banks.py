@@ -3,7 +3,11 @@
 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32; a 16-byte slot's bank group is (address / 16) mod 16;
 ds_write_b128 in eight 8-lane groups with (address / 16) mod 8.  Counts the extra cycles of one steady-state block
 iteration for a layout  slot(d, col) = base[d] + col  of the band's diagonals and a pitch of the bulge triangles,
-and searches the bases.  Run: python tools/proto/chase_banks.py"""
+and searches the bases.  Run: python tools/proto/chase_banks.py
+
+What became of it (profiles/r04_ml_band_pmc.txt): the best layout found was built into k_sb_chase
+("ml_chase_layout" = 1).  SQ_LDS_BANK_CONFLICT DOUBLED with it -- this model does not describe the hardware's banking of
+these accesses -- and the kernel's run time did not change at all: the conflicts are not on the chase's dependency chain."""
 import itertools
 import random
 
