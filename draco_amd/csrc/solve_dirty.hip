@@ -765,14 +765,15 @@ int dmm_dirty_run_multi(dmm_plan* pl, const void* B, const void* const* mvis, co
   DMM_HIP(hipSetDevice(ctx->device));
   // groups of 8, 4, 2 days per read of B (8 days' w = Ni o v take 8 x 12 KB of LDS at cfg 3); a last single day goes
   // through the one-day kernel
-  const int nd_max = (size_t)2 * pl->npairs * 8 * sizeof(double2) <= 128 * 1024 ? 8 : ((size_t)2 * pl->npairs * 4 * sizeof(double2) <= 128 * 1024 ? 4 : 2);
+  const size_t w_day = (size_t)2 * pl->npairs * sizeof(double2);  // LDS of one day's w = Ni o v
+  const int nd_max = 8 * w_day <= 128 * 1024 ? 8 : (4 * w_day <= 128 * 1024 ? 4 : (2 * w_day <= 128 * 1024 ? 2 : 1));
   int d = 0;
   while (d < nday) {
     const int left = nday - d;
     int rc;
     if (left >= 8 && nd_max >= 8) { rc = launch_dirty_multi<8>(pl, B, mvis + d, mweight + d, alm + d); d += 8; }
     else if (left >= 4 && nd_max >= 4) { rc = launch_dirty_multi<4>(pl, B, mvis + d, mweight + d, alm + d); d += 4; }
-    else if (left >= 2) { rc = launch_dirty_multi<2>(pl, B, mvis + d, mweight + d, alm + d); d += 2; }
+    else if (left >= 2 && nd_max >= 2) { rc = launch_dirty_multi<2>(pl, B, mvis + d, mweight + d, alm + d); d += 2; }
     else { SolveParams p = base_params(pl); rc = launch_dirty<false>(pl, p, B, (const double2*)mvis[d], mweight[d], (double2*)alm[d]); d += 1; }
     if (rc) return rc;
   }
