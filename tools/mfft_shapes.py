@@ -1,4 +1,13 @@
-import sys; sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python
+"""`dmm_mfft_pack` (sidereal-time -> m FFT + +/-m pack) at four shapes: nra 1024 / 2048, complex128 / complex64 output
+(the `HybridVisStream` form): HIP-event time and fraction of the HBM peak on the algorithmic bytes.  The output's
+(m, +/-) slots receive rows-per-block x element-size bytes: 128 / 64 bytes at nra 1024, 64 / 32 at nra 2048.
+
+    python tools/mfft_shapes.py
+"""
+import os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np, json
 from draco_amd import _lib
 from draco_amd.device import Context, ptr
