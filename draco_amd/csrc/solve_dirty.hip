@@ -500,10 +500,15 @@ __global__ __launch_bounds__(kThreads) void k_project_rg(SolveParams p, const BT
         row[k] = B + tile.b_off + (int64_t)i * row_stride + col0;
         acc[2 * k] = acc[2 * k + 1] = 0.0;
       }
-      for (int pol = 0; pol < p.npol; ++pol) {
+      // packed tiles: a row is npol * L contiguous elements in the order of `a` -- ONE loop over them (at m = 0, L = 513:
+      // 33 wave-loads per row instead of 4 x 9 with a one-lane runt at the end of every polarisation); full-layout tiles
+      // (gaps of m elements between the polarisations) keep the loop per polarisation
+      const int npass = p.full_layout ? p.npol : 1;
+      const int plen = p.full_layout ? L : ncol;
+      for (int pol = 0; pol < npass; ++pol) {
         const int64_t so = (int64_t)pol * pol_stride;
         const double2* as = a + pol * L;
-        for (int lrel = lane; lrel < L; lrel += 64) {
+        for (int lrel = lane; lrel < plen; lrel += 64) {
           const double2 av = as[lrel];
           double br[RG], bi[RG];
 #pragma unroll
