@@ -424,7 +424,7 @@ def dense_day(args, kind):
     torch.cuda.set_device(0)
     ctx = Context.get()
     cfg = wl.CONFIGS[args.config]
-    for opt in ("ml_reduce", "gram_stage", "wiener_overlap", "ml_chase_grid", "ml_null", "ml_chase_layout"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
+    for opt in ("ml_reduce", "gram_stage", "wiener_overlap", "ml_chase_grid", "ml_null", "ml_chase_layout", "ml_rank_stop"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
         if os.environ.get("DMM_" + opt.upper()):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt.encode(), int(os.environ["DMM_" + opt.upper()])))
     tiles = args.tiles or "screen"
@@ -473,7 +473,7 @@ def dense_day(args, kind):
     eng = task._get_engine()
     fills_before = eng.fills
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
-    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed", b"ml_tiles_null", b"ml_gram_flops", b"ml_band_bytes")}
+    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed", b"ml_tiles_null", b"ml_gram_flops", b"ml_band_bytes", b"ml_tiles_stopped", b"ml_stop_cols")}
     mem0 = torch.cuda.memory_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -549,7 +549,9 @@ def dense_day(args, kind):
             "solves_per_s": (lmax + 1) * nfreq / day_s,
             "ms_per_solve": day_s * 1e3 / ((lmax + 1) * nfreq),
             "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "null_certificate": (c1[b"ml_tiles_null"] - c0[b"ml_tiles_null"]) // max(args.steps, 1),
-                         "ql_failed": c1[b"ml_tiles_ql_failed"] - c0[b"ml_tiles_ql_failed"]} if kind == "ml" else None,
+                         "ql_failed": c1[b"ml_tiles_ql_failed"] - c0[b"ml_tiles_ql_failed"],
+                         "rank_stopped": (c1[b"ml_tiles_stopped"] - c0[b"ml_tiles_stopped"]) // max(args.steps, 1),
+                         "rank_stop_mean_order": (c1[b"ml_stop_cols"] - c0[b"ml_stop_cols"]) / max(c1[b"ml_tiles_stopped"] - c0[b"ml_tiles_stopped"], 1)} if kind == "ml" else None,
         },
         "roofline": roofline,
         "roofline_secondary": secondary,

@@ -129,6 +129,7 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "sht_variant")) c->opt_sht_variant = (int)value;
   else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
   else if (!strcmp(name, "ml_null")) c->opt_ml_null = (int)value;
+  else if (!strcmp(name, "ml_rank_stop")) c->opt_ml_rank_stop = (int)value;
   else if (!strcmp(name, "ml_chase_grid")) c->opt_ml_chase_grid = (int)value;
   else if (!strcmp(name, "ml_chase_layout")) c->opt_ml_chase_layout = (int)value;
   else if (!strcmp(name, "dirty_prio")) c->opt_dirty_prio = (int)value;
@@ -153,6 +154,8 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   if (!strcmp(name, "ml_tiles_direct")) *value = c->ml_tiles_direct;
   else if (!strcmp(name, "ml_tiles_eigen")) *value = c->ml_tiles_eigen;
   else if (!strcmp(name, "ml_tiles_null")) *value = c->ml_tiles_null;
+  else if (!strcmp(name, "ml_tiles_stopped")) *value = c->ml_tiles_stopped;
+  else if (!strcmp(name, "ml_stop_cols")) *value = c->ml_stop_cols;
   else if (!strcmp(name, "ml_gram_flops")) *value = c->ml_gram_flops;
   else if (!strcmp(name, "ml_band_bytes")) *value = c->ml_band_bytes;
   else if (!strcmp(name, "ml_tiles_ql_failed")) *value = c->ml_tiles_ql_failed;

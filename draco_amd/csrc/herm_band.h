@@ -60,6 +60,29 @@ __device__ __forceinline__ double* sb_Zp(const TdParams& tp, int mat) { return s
 __device__ __forceinline__ double2* sb_T(const TdParams& tp, int mat) { return sb_base(tp, mat) + tp.log_stride - sb_tail(tp.d.Np); }
 __device__ __forceinline__ double2* sb_rlog(const TdParams& tp, int mat) { return sb_T(tp, mat) + (int64_t)sb_npanel(tp.d.Np) * 64; }
 
+// Rank stop (tp.stop_tol > 0).  The trailing matrix T_k of the reduction is a compression of a positive semi-definite G:
+// lambda_max(T_k) <= trace(T_k).  Once trace(T_k) <= stop_tol * lb, lb a lower bound of lambda_max(G) (the largest
+// diagonal entry met so far: a Rayleigh quotient), the reduction stops at panel k: the band of order 8 (k + 1) -- with
+// the finished diagonal block (k, k) -- is the matrix, what lies below it is dropped.  What is dropped is the coupling C
+// (||C||^2 <= trace(T_k)^2, positive semi-definiteness again) and T_{k+1}: every eigenvalue lambda of the kept band
+// moves by at most ||C||^2 / (lambda - trace T_k) -- for the smallest eigenvalue pinv_svd's cut keeps (lambda >=
+// rcond^2 lambda_max = 1e-6 lambda_max, mapmaker.py:296) and stop_tol = 1e-13 a relative 1e-20 --, its eigenvector by
+// ||C|| / lambda <= 1e-7, and the dropped eigenvalues are <= 1e-13 lambda_max: below the cut either way.  Beam transfers
+// have a numerical rank far below their order (the spectrum of the structured cfg-3 tiles falls a decade per 8-16
+// columns): stage 1 stops after 150-340 of 758 columns, and the chase, QL and both back-transformations work on that order.
+// Per-matrix state in vector slot 2 of the matrix (free on the two-stage path): [0] lb, ((int*)&[1])[0] the effective order (0: none).
+__device__ __forceinline__ double* sb_state(const TdParams& tp, int mat) {
+  return reinterpret_cast<double*>(tp.vec + ((int64_t)mat * td_slots(tp.d.Np) + 2) * tp.d.Np);
+}
+__device__ __forceinline__ int sb_stopped(const TdParams& tp, int mat) {
+  return tp.stop_tol > 0.0 ? *reinterpret_cast<const int*>(sb_state(tp, mat) + 1) : 0;
+}
+__device__ __forceinline__ int sb_order(const TdParams& tp, int mat) {
+  const int ne = sb_stopped(tp, mat);
+  return ne ? ne : tp.d.Np;
+}
+constexpr int kSbStopMinPanel = 3;  // no stop before this panel (orders below 32 are not worth a special case)
+
 __device__ __forceinline__ void sb_solve_ptrs(const TdParams& tp, int mat, const double2** T, const double2** rlog) {
   *T = sb_T(tp, mat);
   *rlog = sb_rlog(tp, mat);
@@ -135,6 +158,11 @@ __global__ __launch_bounds__(kThreads) void k_sb_zero(TdParams tp) {
   double2* base = tp.log_cs + (int64_t)mat * tp.log_stride;
   const int64_t cnt = (int64_t)3 * n * kSbB;
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * kThreads) base[e] = make_double2(0.0, 0.0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double* st = sb_state(tp, mat);
+    st[0] = 0.0;
+    *reinterpret_cast<int*>(st + 1) = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- stage 1: panel
@@ -150,6 +178,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   __shared__ __align__(16) double2 s_T[64], s_S[64], s_tmp[64];
   __shared__ __align__(16) double2 s_vrow[kSbB][kSbB], s_xrow[kSbB][kSbB];
   __shared__ double s_red[256];
+  __shared__ double s_dg[kSbB];
   const DenseParams& p = tp.d;
   const int n = p.Np, k = tp.j, K = sb_npanel(n);
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
@@ -162,7 +191,20 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   const double* const Mpa = sb_Mp(tp, mat);
   const int j0 = kSbB * k, o = j0 + kSbB;
   const int t = threadIdx.x;
-  const bool last = k == K;
+  if (sb_stopped(tp, mat)) return;  // the rank stop cut this matrix off at an earlier panel
+  double* const stt = sb_state(tp, mat);
+  double trp = 0.0;  // this thread's share of trace(T_k), T_k = the trailing matrix from (j0, j0) with update k-1 applied
+  if (k == 0 && tp.stop_tol > 0.0) {  // lb = the largest diagonal entry of G
+    double mx = 0.0;
+    for (int r = t; r < n; r += kThreads) mx = fmax(mx, A[(int64_t)r * n + r].x);
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) mx = fmax(mx, __shfl_xor(mx, sh));
+    if ((t & 63) == 0) s_red[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) stt[0] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    __syncthreads();
+  }
+  bool last = k == K;
 
   // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
   if (k > 0) {
@@ -230,6 +272,12 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) Xa[(int64_t)r * kSbB + c] = x[c];
+      if (tp.stop_tol > 0.0) {  // diagonal entry of T_k: A[r][r] - 2 Re sum_q X[r][q] conj(V[r][q])
+        double dg = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dg += x[c].x * v[c].x + x[c].y * v[c].y;
+        trp += A[(int64_t)r * n + r].x - 2.0 * dg;
+      }
       if (r < o) {  // the panel's own rows: their V and X rows are what the look-ahead below needs
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -239,6 +287,11 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       }
     }
     __syncthreads();
+    if (tp.stop_tol > 0.0 && k >= kSbStopMinPanel && !last) {  // (uniform over the block: everybody gets the same sum)
+      const double2 tr = block_sum2(make_double2(trp, 0.0), s_red);
+      if (tr.x <= tp.stop_tol * stt[0]) last = true;  // the rank stop: this panel only finishes its diagonal block
+      __syncthreads();
+    }
   }
 
   // ---- the panel's columns with update k-1 applied:  P[r][c] = A[r][j0+c] - sum_q X[r][q] conj(V[j0+c][q]) + V[r][q] conj(X[j0+c][q])
@@ -288,7 +341,11 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       Vnew[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
     }
   }
-  if (last) return;
+  if (t < kSbB) s_dg[t] = P[0][t].x;  // the block's diagonal: Rayleigh quotients, lower bounds of lambda_max
+  if (last) {
+    if (k < K && t == 0) *reinterpret_cast<int*>(stt + 1) = o;  // effective order of the matrix from here on
+    return;
+  }
 
   // ---- QR of the sub-panel rows >= o, column by column.  One reduction round per column carries everything: for
   // cc >= c the raw products g_cc = sum_{r > pivot} conj(P[r][c]) P[r][cc] (norm and v^H P of the reflector), for a < c
@@ -364,6 +421,12 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     __syncthreads();  // s_a[0] is rewritten by the next column
   }
   if (t < 64) Ta[(int64_t)k * 64 + t] = s_T[t];
+  if (t == 0 && tp.stop_tol > 0.0) {
+    double mx = stt[0];
+#pragma unroll
+    for (int c = 0; c < kSbB; ++c) mx = fmax(mx, s_dg[c]);
+    stt[0] = mx;
+  }
   // ---- outputs: R into the lower band, V into the upper triangle (row j0 + c, columns >= o) and the operand array
 #pragma unroll
   for (int u = 0; u < ROWS; ++u) {
@@ -389,6 +452,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_sweep(TdParams tp) {
   const DenseParams& p = tp.d;
   const int n = p.Np, k = tp.j;
   const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
+  if (sb_stopped(tp, mat)) return;
   double2* A = p.A + (int64_t)mat * n * n;
   const double2* Vold = sb_V(tp, mat, k + 1);
   const double2* Vnew = sb_V(tp, mat, k);
@@ -499,6 +563,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
   // grid (matrices, column blocks): the blocks with the tallest strips (column block 0 of every matrix) are dispatched
   // first, the launch ends on the shortest ones
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  if (sb_stopped(tp, mat)) return;  // (uniform over the block)
   const int bx = blockIdx.y;
   double2* A = p.A + (int64_t)mat * n * n;
   const double2* Vold = sb_V(tp, mat, k + 1);
@@ -705,28 +770,31 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
   // bank model tools/proto/chase_banks.py: 63-65 instead of 151 extra LDS cycles per step): diagonal d at d * (n + 1) + (6 from
   // d = 2 on), bulge pitch 22, and the wave's octets take the slots 0 1 4 5 2 3 6 7 -- so that the lanes of one
   // ds_read_b128 group ({0-3, 12-15, 20-27}, ...) fall on different 16-byte bank slots for every element index.
-  const int n = p.Np, lay = tp.chase_layout;
-  const int pitch = lay ? n + 1 : sb_pitch(n), jump = lay ? 6 : 0, bgp = lay ? 22 : 21;
+  const int nA = p.Np, lay = tp.chase_layout;
   double2* ab = reinterpret_cast<double2*>(smem_sb);
-  const int bg0 = (kSbB + 1) * pitch + jump;  // the bulge triangles follow the band
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 7;
   const int oct = lane >> 3, g = lay ? ((oct & 1) | ((oct & 2) << 1) | ((oct & 4) >> 1)) : oct;
 #define SB_DIAG(d) ((d) * pitch + ((d) >= 2 ? jump : 0))
   // a block works through the matrices bi = blockIdx.x, blockIdx.x + gridDim.x, ... (grid < nmat: "ml_chase_grid")
   for (int bi = blockIdx.x; bi < nmat; bi += gridDim.x) {
   const int mat = p.msel ? p.msel[bi] : bi;
-  const double2* A = p.A + (int64_t)mat * n * n;
+  // the matrix's effective order (the rank stop of stage 1): the band image, the sweeps and the reflector log are those
+  // of an order-n matrix; only A's row pitch and the vector slots keep the padded order nA
+  const int n = sb_order(tp, mat);
+  const int pitch = lay ? n + 1 : sb_pitch(n), jump = lay ? 6 : 0, bgp = lay ? 22 : 21;
+  const int bg0 = (kSbB + 1) * pitch + jump;  // the bulge triangles follow the band
+  const double2* A = p.A + (int64_t)mat * nA * nA;
   double2* const rlog = sb_rlog(tp, mat);
-  double2* vbm = tp.vec + (int64_t)mat * td_slots(n) * n;
-  double* dd = reinterpret_cast<double*>(vbm + 5 * n);
-  double* ee = dd + n;
+  double2* vbm = tp.vec + (int64_t)mat * td_slots(nA) * nA;
+  double* dd = reinterpret_cast<double*>(vbm + 5 * nA);
+  double* ee = dd + nA;
   // (Tried: s_setprio(3) for this kernel's and the serial QL's waves -- beside the next chunk's Gram / sweep kernels a
   // chase launch takes 2.4 x what it takes alone.  No change: 668 against 680 ms of chase per 32 frequencies.  What the
   // chase waits for in the step is a CU whose LDS is EMPTY, not issue slots.)
 #define SB_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   for (int e = threadIdx.x; e < (kSbB + 1) * n; e += 64 * kSbCW) {
     const int d = e / n, col = e - d * n;
-    ab[SB_DIAG(d) + col] = col + d < n ? A[(int64_t)(col + d) * n + col] : SB_ZERO;
+    ab[SB_DIAG(d) + col] = col + d < n ? A[(int64_t)(col + d) * nA + col] : SB_ZERO;
   }
   for (int e = threadIdx.x; e < (n / kSbB + 2) * bgp; e += 64 * kSbCW) ab[bg0 + e] = SB_ZERO;
   if (threadIdx.x < kSbCW) s_prog[threadIdx.x] = 0;
@@ -915,8 +983,8 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
 // ---------------------------------------------------------------------------------------------------- applications
 // b (LDS, n entries) <- Q1^H b (ADJ) or Q1 b,  Q1 = prod_k (I - V_k T_k V_k^H);  256 threads, `red`: >= 5 * 16 doubles
 template <bool ADJ>
-__device__ __forceinline__ void sb_apply_q1(double2* b, const double2* A, const double2* T, int n, double* red) {
-  const int K = sb_npanel(n), t = threadIdx.x;
+__device__ __forceinline__ void sb_apply_q1(double2* b, const double2* A, const double2* T, int n, int ne, double* red) {
+  const int K = sb_npanel(ne), t = threadIdx.x;  // (a matrix the rank stop cut off at order ne has ne / 8 - 1 panels of reflectors, all n rows long)
   __shared__ double2 s_s[kSbB];
   for (int kk = 0; kk < K; ++kk) {
     const int k = ADJ ? kk : K - 1 - kk;

@@ -50,6 +50,9 @@ struct TdParams {
                        // Q = Q1 Q2 from the block reflectors in A's upper triangle and the reflector log instead
   int sb_lower;        // 1: stage 1 sweeps the lower triangle only (k_sb_sweep_lo)
   int chase_layout;    // LDS layout of the bulge chase's band image: 0 = round 3's, 1 = the bank-spread one (herm_band.h)
+  double stop_tol;     // > 0: rank stop of the band reduction (herm_band.h) -- a matrix whose trailing trace has fallen to
+                       // stop_tol * (lower bound of lambda_max) is cut off there: its effective order (sb_order) is what the
+                       // chase, QL and the back-transformation work on
 };
 
 // pending pair q of a matrix: v at pend + q n, w at pend + (kTdPend + q) n; the arrays live at the head of the
@@ -106,10 +109,11 @@ __device__ __forceinline__ double2 block_sum2(double2 v, double* red) {
 }
 
 template <bool ADJ>
-__device__ __forceinline__ void sb_apply_q1(double2* b, const double2* A, const double2* T, int n, double* red);
+__device__ __forceinline__ void sb_apply_q1(double2* b, const double2* A, const double2* T, int n, int ne, double* red);
 template <bool ADJ>
 __device__ __forceinline__ void sb_apply_q2(double2* b, const double2* rlog, int n);
 __device__ __forceinline__ void sb_solve_ptrs(const TdParams& tp, int mat, const double2** T, const double2** rlog);
+__device__ __forceinline__ int sb_order(const TdParams& tp, int mat);
 
 // The column step of matrix `mat`: finishes step j-1 and forms the reflector of column j.  One whole block; `smem`: 2 n
 // double2 of LDS.  Called by k_td_col, and by the LAST block of a sweep that finishes for its matrix (k_td_trail_tri
@@ -546,14 +550,17 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   double* dl = PH == 2 ? reinterpret_cast<double*>(smem_td) : reinterpret_cast<double*>(b + n);  // [n]
   double* el = dl + n;                                    // [n]
   const int Lsky = p.lmax + 1 - tile.m, N = order_of(p, tile);
+  // effective order: where the band reduction's rank stop cut the matrix off (herm_band.h); everything beyond is an
+  // eigenvalue 0 -- below the cut
+  const int ne = tp.two_stage ? sb_order(tp, mat) : n;
 
   if (PH == 2) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      dl[i] = dd[i];
-      el[i] = i < n - 1 ? ee[i] : 0.0;
+      dl[i] = i < ne ? dd[i] : 0.0;
+      el[i] = i < ne - 1 ? ee[i] : 0.0;
     }
   } else if (PH == 3) {
-    if (tp.fail[blockIdx.x]) return;  // QL gave up: the fallback owns this matrix
+    if (tp.fail[blockIdx.x] & 1) return;  // QL gave up: the fallback owns this matrix
     for (int i = threadIdx.x; i < n; i += kThreads) {
       b[i] = zbuf[i];
       dl[i] = lam[i];
@@ -579,8 +586,8 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     }
     b[i] = v;
     if (PH == 0) {  // (PH 1 has the vector alone in LDS)
-      dl[i] = dd[i];
-      el[i] = i < n - 1 ? ee[i] : 0.0;
+      dl[i] = i < ne ? dd[i] : 0.0;
+      el[i] = i < ne - 1 ? ee[i] : 0.0;
     }
   }
   TD_T(0);
@@ -592,8 +599,8 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     __shared__ double red_sb[5 * 16];
     const double2 *Tq, *rl;
     sb_solve_ptrs(tp, mat, &Tq, &rl);
-    sb_apply_q1<true>(b, A, Tq, n, red_sb);
-    sb_apply_q2<true>(b, rl, n);
+    sb_apply_q1<true>(b, A, Tq, n, ne, red_sb);
+    sb_apply_q2<true>(b, rl, ne);
   } else
   if (PH == 0 || PH == 1)
   for (int j = 0; j < n - 1; ++j) {
@@ -633,17 +640,17 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     // iteration cap and the tile falls back to the Jacobi solver (8x slower).  The absolute floor costs nothing in
     // accuracy: the reduction to tridiagonal form has already perturbed every eigenvalue by O(eps ||T||).
     double anorm = 0.0;
-    for (int k = lane; k < n; k += 64) anorm = fmax(anorm, fabs(dl[k]) + fabs(el[k]));
+    for (int k = lane; k < ne; k += 64) anorm = fmax(anorm, fabs(dl[k]) + fabs(el[k]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) anorm = fmax(anorm, __shfl_xor(anorm, o));
     const double tol_abs = eps * anorm;
-    for (int l = 0; l < n && !fail; ++l) {
+    for (int l = 0; l < ne && !fail; ++l) {
       int iter = 0;
       while (true) {
-        int m = n - 1;  // first m >= l whose sub-diagonal is negligible
-        for (int base = l; base < n - 1; base += 64) {
+        int m = ne - 1;  // first m >= l whose sub-diagonal is negligible
+        for (int base = l; base < ne - 1; base += 64) {
           const int k = base + lane;
-          const bool small = k < n - 1 && fabs(el[k]) <= fmax(eps * (fabs(dl[k]) + fabs(dl[k + 1])), tol_abs);
+          const bool small = k < ne - 1 && fabs(el[k]) <= fmax(eps * (fabs(dl[k]) + fabs(dl[k + 1])), tol_abs);
           const unsigned long long mask = __ballot(small);
           if (mask) {
             m = base + __ffsll((long long)mask) - 1;
@@ -772,8 +779,8 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     __shared__ double red_sb2[5 * 16];
     const double2 *Tq, *rl;
     sb_solve_ptrs(tp, mat, &Tq, &rl);
-    sb_apply_q2<false>(b, rl, n);
-    sb_apply_q1<false>(b, A, Tq, n, red_sb2);
+    sb_apply_q2<false>(b, rl, ne);
+    sb_apply_q1<false>(b, A, Tq, n, ne, red_sb2);
   } else
   for (int j = n - 2; j >= 0; --j) {
     const double2 t = tau[j];
@@ -800,6 +807,7 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     printf("td_solve n=%d runs=%d: Qhb %.3f ms, QL %.3f, fwd %.3f, cut+bwd %.3f, Qy %.3f\n", n, s_nrot, (td_t[1] - td_t[0]) * 1e-5,
            (td_t[2] - td_t[1]) * 1e-5, (td_t[3] - td_t[2]) * 1e-5, (td_t[4] - td_t[3]) * 1e-5, (td_t[5] - td_t[4]) * 1e-5);
 #endif
+  if (threadIdx.x == 0 && ne < n) tp.fail[blockIdx.x] = ne << 8;  // (bit 0 = "QL gave up" stays clear: the host counts the stops)
   for (int i = threadIdx.x; i < N; i += kThreads) {
     const double2 acc = b[i];
     if (p.sky) {

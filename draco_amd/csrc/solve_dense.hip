@@ -95,6 +95,17 @@ bool sb_usable(const dmm_ctx* ctx, int n) {
   return n >= 64 && n % 64 == 0 && n <= kSbRows * kThreads && sb_chase_lds(n) + 4608 <= kSbLdsMax;  // (+ the chase kernel's static scratch)
 }
 // QL's rotation log shares the matrix's log region with the T factors and the chase's reflector log at its tail
+// "ml_rank_stop": the tolerance of the band reduction's rank stop (herm_band.h), relative to the lower bound of lambda_max
+double sb_stop_tol(const dmm_ctx* ctx) {
+  const int v = ctx->opt_ml_rank_stop;
+  if (v == 1) return 0.0;
+  double t = 1e-13;
+  if (v >= 8) {
+    t = 1.0;
+    for (int i = 0; i < v && i < 30; ++i) t *= 0.1;
+  }
+  return t;
+}
 int64_t sb_log_cap(int64_t log_stride, int n, int runs) {
   return log_stride - sb_tail(n) - ((int64_t)3 * runs * (int64_t)sizeof(int) + 15) / 16;
 }
@@ -772,6 +783,17 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     }
     ctx->ml_band_bytes += (int64_t)(by * nmat);
   };
+  // a matrix the rank stop cut off at order ne: the sweeps from panel ne / 8 - 1 on did not run; counted as stopped
+  auto count_stop = [&](int n, int ne) {
+    double by = 0.0;
+    for (int k = ne / 8 - 1; k < n / 8 - 1; ++k) {
+      const double t = (n - ((8 * (k + 1)) & ~15)) / 16;
+      by += t * (t + 1) / 2 * 8.5 * 1024;
+    }
+    ctx->ml_band_bytes -= (int64_t)by;
+    ++ctx->ml_tiles_stopped;
+    ctx->ml_stop_cols += ne;
+  };
   const bool shortcut = ctx->opt_ml_shortcut != 2;  // 2: always take the eigen path (tests, timing)
   const int max_sweeps = ctx->opt_ml_outer_sweeps > 0 ? ctx->opt_ml_outer_sweeps : 60;
   const int inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;  // tools/ml_tune.py
@@ -1014,6 +1036,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
         tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
         tp.chase_layout = sb_chase_layout(ctx, n);
+        tp.stop_tol = sb_stop_tol(ctx);
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
         DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
         if (tp.two_stage) {
@@ -1040,7 +1063,8 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         // already replaced their right-hand side by the solution -- go through Jacobi on re-formed Gram matrices
         std::vector<int> redo;
         for (int k = 0; k < nsel; ++k)
-          if (td_fail_h[k]) redo.push_back(msel_h[k]);
+          if (td_fail_h[k] & 1) redo.push_back(msel_h[k]);
+          else if (td_fail_h[k] >> 8) count_stop(n, td_fail_h[k] >> 8);  // (the rank stop's effective order)
         ctx->ml_tiles_ql_failed += (int64_t)redo.size();
         solved = redo.empty();
         if (!solved) {
@@ -1119,7 +1143,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     std::vector<dmm_tile> tiles;
     std::vector<int32_t> work;
     std::vector<int64_t> ids;
-    int nmat = 0, off = 0;
+    int nmat = 0, off = 0, np = 0;
     bool busy = false;
   } half[2];
   std::vector<int64_t> redo_tel;
@@ -1145,9 +1169,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipEventSynchronize(ctx->aux_ev[2 + h]));
     const int* fl = ctx->aux_pinned + (size_t)H.off;
     for (int k = 0; k < H.nmat; ++k)
-      if (fl[k]) {
+      if (fl[k] & 1) {
         (redo_is_sky[h] ? redo_sky[redo_np[h]] : redo_tel).push_back(H.ids[k]);
         ++ctx->ml_tiles_ql_failed;
+      } else if (fl[k] >> 8) {  // the rank stop's effective order
+        count_stop(H.np, fl[k] >> 8);
       }
     H.busy = false;
     return DMM_OK;
@@ -1176,6 +1202,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     p.T = p.Np / TB;
     p.alm = (double2*)alm;
     H.nmat = nmat;
+    H.np = p.Np;
     H.tiles.resize(nmat);
     H.work.assign(nmat + 1, 0);
     H.ids.assign(list.begin() + i0, list.begin() + i0 + nmat);
@@ -1220,6 +1247,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
     tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
     tp.chase_layout = sb_chase_layout(ctx, n);
+    tp.stop_tol = sb_stop_tol(ctx);
     if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
     if (tp.two_stage) {
