@@ -130,6 +130,7 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
   else if (!strcmp(name, "ml_null")) c->opt_ml_null = (int)value;
   else if (!strcmp(name, "ml_rank_stop")) c->opt_ml_rank_stop = (int)value;
+  else if (!strcmp(name, "ml_chase_split")) c->opt_ml_chase_split = (int)value;
   else if (!strcmp(name, "ml_chase_grid")) c->opt_ml_chase_grid = (int)value;
   else if (!strcmp(name, "ml_chase_layout")) c->opt_ml_chase_layout = (int)value;
   else if (!strcmp(name, "dirty_prio")) c->opt_dirty_prio = (int)value;

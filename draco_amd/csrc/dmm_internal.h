@@ -55,7 +55,9 @@ struct dmm_ctx {
   int opt_ml_null = 0;                     // 1: no null certificate (tiles whose Frobenius norm puts every singular value below acond are decomposed like any other)
   int64_t ml_gram_flops = 0, ml_band_bytes = 0;  // counters: useful flops of the ML Gram launches (4 k^2 K per tile), algorithmic bytes of stage 1 of the two-stage reduction (8.5 KB per lower-triangle tile and panel)
   int64_t ml_tiles_null = 0;               // counter: tiles the null certificate answered with zero
+  int opt_ml_chase_split = 0;              // 1: the bulge chase is always one launch with the full band image in LDS (A/B of the LDS sized from the orders' history)
   int opt_ml_rank_stop = 0;                // rank stop of the two-stage reduction: 0 = on at 1e-13 of lambda_max's lower bound, 1 = off, v >= 8: on at 10^-v
+  int64_t ml_order_hist[17] = {};           // effective orders of the eigen-decomposed tiles so far, in buckets of 64 (a property of the telescope: sizes the bulge chase's LDS)
   int64_t ml_tiles_stopped = 0, ml_stop_cols = 0;  // counters: eigen-decomposed tiles whose reduction the rank stop cut off, and the sum of their effective orders
   int64_t ml_tiles_direct = 0, ml_tiles_eigen = 0;  // counters: tiles solved by the shortcut / by the eigen path
   int64_t ml_tiles_ql_failed = 0;          // ... of the latter: QL gave up, the tile was redone by the Jacobi solver

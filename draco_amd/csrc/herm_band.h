@@ -761,7 +761,10 @@ __device__ __forceinline__ double2 sb_shfl2(double2 v, int src) { return make_do
 constexpr int kSbCW = 4;
 constexpr int kSbLag = 2;  // iterations between consecutive sweeps (see the kernel's comment)
 __host__ __device__ constexpr int sb_pitch(int n) { return n + 2; }  // a column's 8 lanes (stride pitch - 1 or pitch) spread over the banks
-__global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) {
+// ne_lo < (effective order) <= ne_hi: the matrices this launch works on -- the host sizes the LDS of a launch for ne_hi
+// (sb_chase below: most matrices of a telescope stop at a fraction of their order, and a chase block that needs half
+// the LDS shares its CU with the next chunk's sweep blocks instead of waiting for an empty one)
+__global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat, int ne_lo, int ne_hi) {
   extern __shared__ __align__(16) unsigned char smem_sb[];
   __shared__ int s_prog[kSbCW];
   __shared__ __align__(16) double2 s_scr[kSbCW][64];
@@ -781,6 +784,7 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat) 
   // the matrix's effective order (the rank stop of stage 1): the band image, the sweeps and the reflector log are those
   // of an order-n matrix; only A's row pitch and the vector slots keep the padded order nA
   const int n = sb_order(tp, mat);
+  if (n <= ne_lo || n > ne_hi) continue;  // (uniform over the block)
   const int pitch = lay ? n + 1 : sb_pitch(n), jump = lay ? 6 : 0, bgp = lay ? 22 : 21;
   const int bg0 = (kSbB + 1) * pitch + jump;  // the bulge triangles follow the band
   const double2* A = p.A + (int64_t)mat * nA * nA;

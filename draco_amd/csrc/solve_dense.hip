@@ -129,12 +129,36 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   tp.j = K;
   panel();
 }
-void sb_chase(const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0) {
+void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0) {
   // grid_cap > 0 ("ml_chase_grid"): at most that many blocks, each working through several matrices -- the chase keeps a
   // CU's whole LDS, so a capped grid confines it to that many CUs instead of letting it take every CU in turn
   const int grid = grid_cap > 0 && grid_cap < nmat ? grid_cap : nmat;
-  const size_t lds = tp.chase_layout ? sb_chase_lds2(tp.d.Np) : sb_chase_lds(tp.d.Np);
-  hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), lds, st, tp, nmat);
+  const int n = tp.d.Np;
+  auto lds_of = [&](int order) { return tp.chase_layout ? sb_chase_lds2(order) : sb_chase_lds(order); };
+  // The rank stop leaves most matrices of a telescope at a fraction of their order, and which fraction is known from the
+  // chunks before (ctx->ml_order_hist).  A launch sized for the order that 98 % of them stayed under takes (and keeps)
+  // half a CU's LDS or less -- its blocks start beside the next chunk's sweep / Gram blocks instead of waiting for a CU
+  // whose LDS is empty --; the few matrices above go through a second, small persistent launch with the full image.
+  int cap = n;
+  if (tp.stop_tol > 0.0 && ctx->opt_ml_chase_split != 1) {
+    int64_t total = 0, cum = 0;
+    for (int64_t h : ctx->ml_order_hist) total += h;
+    if (total >= 64) {
+      for (int b = 0; b < 17; ++b) {
+        cum += ctx->ml_order_hist[b];
+        if ((double)cum >= 0.98 * (double)total) {
+          cap = std::max(64 * b, 128);
+          break;
+        }
+      }
+    }
+  }
+  if (cap + 64 >= n) {
+    hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), lds_of(n), st, tp, nmat, 0, n);
+    return;
+  }
+  hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), lds_of(cap), st, tp, nmat, 0, cap);
+  hipLaunchKernelGGL(k_sb_chase, dim3(std::min(nmat, 32)), dim3(64 * kSbCW), lds_of(n), st, tp, nmat, cap, n);
 }
 
 // QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
@@ -785,6 +809,8 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   };
   // a matrix the rank stop cut off at order ne: the sweeps from panel ne / 8 - 1 on did not run; counted as stopped
   auto count_stop = [&](int n, int ne) {
+    ++ctx->ml_order_hist[std::min(((ne ? ne : n) + 63) / 64, 16)];
+    if (!ne) return;
     double by = 0.0;
     for (int k = ne / 8 - 1; k < n / 8 - 1; ++k) {
       const double t = (n - ((8 * (k + 1)) & ~15)) / 16;
@@ -1046,7 +1072,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
             sb_reduce(tp, nsel, ctx->stream);
           }
           dmm_prof_scope prof(ctx, DMM_PROF_CHASE, ctx->stream);
-          sb_chase(tp, nsel, ctx->stream, ctx->opt_ml_chase_grid);
+          sb_chase(ctx, tp, nsel, ctx->stream, ctx->opt_ml_chase_grid);
         } else {
           dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, ctx->stream);
           td_reduce(tp, nsel, ctx->stream);
@@ -1064,7 +1090,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         std::vector<int> redo;
         for (int k = 0; k < nsel; ++k)
           if (td_fail_h[k] & 1) redo.push_back(msel_h[k]);
-          else if (td_fail_h[k] >> 8) count_stop(n, td_fail_h[k] >> 8);  // (the rank stop's effective order)
+          else count_stop(n, td_fail_h[k] >> 8);  // (the rank stop's effective order, 0: none)
         ctx->ml_tiles_ql_failed += (int64_t)redo.size();
         solved = redo.empty();
         if (!solved) {
@@ -1172,7 +1198,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       if (fl[k] & 1) {
         (redo_is_sky[h] ? redo_sky[redo_np[h]] : redo_tel).push_back(H.ids[k]);
         ++ctx->ml_tiles_ql_failed;
-      } else if (fl[k] >> 8) {  // the rank stop's effective order
+      } else {  // the rank stop's effective order (0: none)
         count_stop(H.np, fl[k] >> 8);
       }
     H.busy = false;
@@ -1263,7 +1289,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
     if (tp.two_stage) {  // the chase is one wave per matrix, as latency bound as QL: it runs beside the next chunk's sweeps too
       dmm_prof_scope prof(ctx, DMM_PROF_CHASE, S2);
-      sb_chase(tp, nmat, S2, ctx->opt_ml_chase_grid);
+      sb_chase(ctx, tp, nmat, S2, ctx->opt_ml_chase_grid);
     }
     {
       dmm_prof_scope prof(ctx, DMM_PROF_QL, S2);

@@ -83,6 +83,11 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * taken, the A/B of the sampling),
  * "ml_chase_layout" (0, default: the bulge chase's band image in LDS as in round 3; 1: a layout meant to spread the bank
  * conflicts -- an A/B of DESIGN 5.5: the counted conflicts change, the run time does not),
+ * "ml_rank_stop" (rank stop of the two-stage reduction, DESIGN 5.5: once the trace of a Gram matrix's trailing matrix has
+ * fallen to 1e-13 of a lower bound of its largest eigenvalue -- seven decades below pinv_svd's relative cut -- the matrix is
+ * cut off at that order and the bulge chase, QL and both back-transformations work on it; 0, default: on; 1: off; v >= 8:
+ * on at 10^-v), "ml_chase_split" (0, default: the bulge chase's LDS is sized for the effective order 98 % of the
+ * context's matrices so far stayed under, the few above go through a second small launch; 1: one launch, full band image),
  * "ml_chase_grid" (0, default: one bulge-chase block per matrix; > 0: at most that many persistent blocks, each working
  * through several matrices -- an A/B of DESIGN 5.5),
  * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies; 2 = the
@@ -100,7 +105,8 @@ int dmm_ctx_sync(dmm_ctx* ctx);
 int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
 /* diagnostics counters, cumulative per context: "ml_tiles_direct" (tiles whose pseudo-inverse was
  * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed), "ml_tiles_null" (tiles answered with zero by the null certificate: every
- * singular value at or below acond), "ml_gram_flops" / "ml_band_bytes" (useful flops 4 k^2 K of the
+ * singular value at or below acond), "ml_tiles_stopped" / "ml_stop_cols" (eigen-decomposed tiles whose reduction the rank stop cut off,
+ * and the sum of their effective orders), "ml_gram_flops" / "ml_band_bytes" (useful flops 4 k^2 K of the
  * Gram matrices dmm_ml_run formed, algorithmic bytes of stage 1 of its two-stage reductions: the numerators of
  * bench.py's rooflines), "ml_tiles_ql_failed"
  * (of those: tridiagonal QL did not converge, the tile was redone by the blocked Jacobi solver), "ml_early_chunks"

@@ -84,12 +84,14 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
 
     diag = torch.full((nfreq, n_m, 4), -1.0, dtype=torch.float64, device=ctx.device)
     e0, d0, z0 = counter(b"ml_tiles_eigen"), counter(b"ml_tiles_direct"), counter(b"ml_tiles_null")
+    st0, sc0 = counter(b"ml_tiles_stopped"), counter(b"ml_stop_cols")
     _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, ptr(diag)))
     try:
-        alm = task.make_alm(mm)  # the batched default pass (certificate probe, deferred eigen pass, two-stage reduction)
+        alm = task.make_alm(mm)  # the batched default pass (certificate probe, deferred eigen pass, two-stage reduction with its rank stop)
         ctx.sync()
     finally:
         _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, None))
+    n_stop, stop_cols = counter(b"ml_tiles_stopped") - st0, counter(b"ml_stop_cols") - sc0
     n_eig, n_dir, n_null = counter(b"ml_tiles_eigen") - e0, counter(b"ml_tiles_direct") - d0, counter(b"ml_tiles_null") - z0
     assert n_eig + n_dir + n_null == nfreq * n_m
     # the null certificate is a shortcut, never a different answer: switched off, the same tiles are decomposed to the same zeros
@@ -153,7 +155,7 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
             worst = max(worst, err)
         # l < m stays exactly zero, like the reference's output for a provider that zeroes those columns
         assert not np.any(alm[f, :, m, :m])
-    report = {"screen": name, "screen_parameters": bt.model() and {k: v for k, v in bt.model().items() if np.isscalar(v)}, "cyl_sep": bt.cyl_sep, "tiles": nfreq * n_m, "eigen_decomposed": n_eig, "certified": n_dir, "null_certificate": n_null, "tiles_the_cut_truncates": int(truncated.sum()),
+    report = {"screen": name, "screen_parameters": bt.model() and {k: v for k, v in bt.model().items() if np.isscalar(v)}, "cyl_sep": bt.cyl_sep, "tiles": nfreq * n_m, "eigen_decomposed": n_eig, "certified": n_dir, "null_certificate": n_null, "rank_stopped": n_stop, "rank_stop_mean_order": stop_cols / max(n_stop, 1), "tiles_the_cut_truncates": int(truncated.sum()),
               "smallest_gap_to_cut_over_all_tiles": float(gap.min()), "worst_rel_err_where_ranks_agree": worst, "rows": rows}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"r04_ml_structured_vs_oracle_{name}.json"), "w") as fh:
@@ -186,3 +188,69 @@ def test_cfg3_wiener_batched_pass_on_structured_tiles_against_the_oracle():
         ref = omm.wiener_solve(bt.beam_m(m, fi=f), m, mv_h[m, :, f], mw_h[m, :, f], task.prior_amp, task.prior_tilt)
         worst = max(worst, _rel(alm[f, :, m, :], ref))
     assert worst < 1e-9, worst
+
+
+def test_rank_stop_of_the_band_reduction_changes_no_rank_and_no_solution():
+    """The rank stop (herm_band.h: trailing trace <= 1e-13 of lambda_max's lower bound) cuts the reduction of a Gram matrix
+    off where what is left is below pinv_svd's cut by seven decades (mapmaker.py:296).  On and off must keep the same
+    modes on every tile and give the same a_lm; on well-conditioned tiles it never fires and the pass is bit-identical."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import ptr
+
+    nfreq = 1
+    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, seed=13)
+    n_m = tel.lmax + 1
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    def run(provider, stop, shortcut=0):
+        task = MaximumLikelihoodMapMaker(nside=64, pool_bytes=nfreq * per_f + (1 << 20))
+        task.setup(provider)
+        diag = torch.full((nfreq, n_m, 4), -1.0, dtype=torch.float64, device=ctx.device)
+        s0, c0 = counter(b"ml_tiles_stopped"), counter(b"ml_stop_cols")
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_rank_stop", stop))
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", shortcut))
+        _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, ptr(diag)))
+        try:
+            alm = task.make_alm(mm)
+            ctx.sync()
+        finally:
+            _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, None))
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_rank_stop", 0))
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
+        return alm.cpu().numpy(), diag.cpu().numpy(), counter(b"ml_tiles_stopped") - s0, counter(b"ml_stop_cols") - c0
+
+    a_on, d_on, n_on, cols_on = run(bt, 0)
+    a_off, d_off, n_off, _ = run(bt, 1)
+    a_loose, d_loose, n_loose, cols_loose = run(bt, 10)  # 1e-10: stops a few columns earlier, still far below the cut
+    dec = d_off[..., 0] >= 0
+    assert n_off == 0 and n_on > 0.9 * dec.sum() and n_loose >= n_on
+    assert cols_on / n_on < 0.5 * 2 * tel.npairs and cols_loose / n_loose <= cols_on / n_on  # mean effective order: under half of 758
+    assert np.array_equal(d_on[..., 0], d_off[..., 0]) and np.array_equal(d_loose[..., 0], d_off[..., 0])  # the same modes kept on every tile
+    scale = np.abs(a_off).max()
+    # (each pass is within ~2e-9 of the oracle's SVD on these tiles -- the Gram route's own resolution at the cut, see the test
+    # above --, and the two reductions round differently: their distance is of that size, not smaller)
+    assert np.abs(a_on - a_off).max() < 1e-8 * scale, np.abs(a_on - a_off).max() / scale
+    assert np.abs(a_loose - a_off).max() < 1e-7 * scale, np.abs(a_loose - a_off).max() / scale
+    kept = dec & (d_off[..., 0] > 0)
+    assert np.abs(d_on[..., 2][kept] / d_off[..., 2][kept] - 1.0).max() < 1e-8  # the smallest kept sigma of every tile
+    # well-conditioned tiles: all the stop can cut off are EXACT zeros -- the padding of a sky-side system decomposed at a
+    # larger padded order, the rows of zero-weight baselines (2 % here), the empty half of the m = 0 tile --: only the tail
+    # of a reduction is saved, and nothing changes
+    syn = SyntheticProvider(tel, seed=77)
+    s_on, ds_on, ns_on, cols_s = run(syn, 0, shortcut=2)
+    s_off, ds_off, ns_off, _ = run(syn, 1, shortcut=2)
+    assert ns_off == 0
+    assert ns_on == 0 or cols_s / ns_on > 0.8 * (cols_on / n_on) * 3  # (mean effective order: most of the matrix, not a third of it)
+    assert np.array_equal(ds_on[..., 0], ds_off[..., 0])
+    assert np.abs(s_on - s_off).max() < 1e-11 * np.abs(s_off).max(), np.abs(s_on - s_off).max() / np.abs(s_off).max()
