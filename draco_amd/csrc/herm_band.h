@@ -171,6 +171,11 @@ __global__ __launch_bounds__(kThreads) void k_sb_zero(TdParams tp) {
 // (reflectors into the upper triangle of A and the operand array of the next sweep, R into the lower band, T aside).
 // k == npanel: only the trailing 8 x 8 block is finished.  Rows of a thread: j0 + threadIdx.x + 256 u.
 constexpr int kSbRows = 4;  // most rows per thread: orders up to 1024
+#ifdef SB_TIMING
+#define SB_T(i) sb_t[i] = wall_clock64()
+#else
+#define SB_T(i)
+#endif
 template <int ROWS>  // rows per thread: 3 up to order 768, 4 up to 1024
 __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   __shared__ __align__(16) double2 s_a[1][kSbB];  // the pivot row of the current column
@@ -192,6 +197,10 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   const int j0 = kSbB * k, o = j0 + kSbB;
   const int t = threadIdx.x;
   if (sb_stopped(tp, mat)) return;  // the rank stop cut this matrix off at an earlier panel
+#ifdef SB_TIMING
+  long long sb_t[8];
+#endif
+  SB_T(0);
   double* const stt = sb_state(tp, mat);
   double trp = 0.0;  // this thread's share of trace(T_k), T_k = the trailing matrix from (j0, j0) with update k-1 applied
   if (k == 0 && tp.stop_tol > 0.0) {  // lb = the largest diagonal entry of G
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       s_S[t] = make_double2(0.5 * a.x, 0.5 * a.y);
     }
     __syncthreads();
+    SB_T(1);
     // X = Z T - V S for the rows >= j0, one row per thread and pass.  (The memory clobber keeps the 128 table entries in
     // LDS: hoisted out of the row loop as loop invariants they are every register a thread can have.)
 #pragma unroll 1
@@ -247,15 +257,27 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       }
       if (tp.sb_lower) {  // + the row contributions of the column blocks left of this row's tile (in block order)
         const int nb = ((r - org_prev) / 16 * 16 + 63) / 64;
-        for (int b = 0; b < nb; ++b) {
-          const double2* zp = reinterpret_cast<const double2*>(Zpa + ((int64_t)b * n + r) * 16);
-          double2 w[8];
+        // (ROWS = 3, the kernel of the early panels -- 256 registers anyway --: three blocks' partials in flight at a time.
+        // One at a time, a row waited for up to twelve round trips to memory in turn: a third of the kernel's time.  The
+        // additions keep their order.  The later panels' kernels keep their smaller register budgets.)
+        constexpr int NB = ROWS >= 3 ? 3 : 1;
+        for (int b0 = 0; b0 < nb; b0 += NB) {
+          double2 w[NB][8];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) w[c] = zp[c];
+          for (int bb = 0; bb < NB; ++bb) {
+            const double2* zp = reinterpret_cast<const double2*>(Zpa + ((int64_t)min(b0 + bb, nb - 1) * n + r) * 16);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            z[2 * c].x += w[c].x, z[2 * c + 1].x += w[c].y;
-            z[2 * c].y += w[4 + c].x, z[2 * c + 1].y += w[4 + c].y;
+            for (int c = 0; c < 8; ++c) w[bb][c] = zp[c];
+          }
+#pragma unroll
+          for (int bb = 0; bb < NB; ++bb) {
+            if (b0 + bb < nb) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                z[2 * c].x += w[bb][c].x, z[2 * c + 1].x += w[bb][c].y;
+                z[2 * c].y += w[bb][4 + c].x, z[2 * c + 1].y += w[bb][4 + c].y;
+              }
+            }
           }
         }
       }
@@ -294,6 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     }
   }
 
+  SB_T(2);
   // ---- the panel's columns with update k-1 applied:  P[r][c] = A[r][j0+c] - sum_q X[r][q] conj(V[j0+c][q]) + V[r][q] conj(X[j0+c][q])
   double2 P[ROWS][kSbB];
 #pragma unroll
@@ -327,6 +350,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     }
   }
   __syncthreads();  // everybody has read rows [j0, o) of V_{k-1} / X_{k-1} (from LDS) and its own rows of them
+  SB_T(3);
   // rows [j0, o): the finished diagonal block goes back; their operand rows are zeroed -- the sweep then leaves every
   // tile row / column above o alone, whatever its 16-aligned origin
   if (t < kSbB) {
@@ -341,7 +365,9 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       Vnew[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
     }
   }
-  if (t < kSbB) s_dg[t] = P[0][t].x;  // the block's diagonal: Rayleigh quotients, lower bounds of lambda_max
+#pragma unroll
+  for (int c = 0; c < kSbB; ++c)  // (every index into P[][] a compile-time constant: a run-time one sends the whole array to scratch)
+    if (t == c) s_dg[c] = P[0][c].x;  // the block's diagonal: Rayleigh quotients, lower bounds of lambda_max
   if (last) {
     if (k < K && t == 0) *reinterpret_cast<int*>(stt + 1) = o;  // effective order of the matrix from here on
     return;
@@ -420,6 +446,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     }
     __syncthreads();  // s_a[0] is rewritten by the next column
   }
+  SB_T(4);
   if (t < 64) Ta[(int64_t)k * 64 + t] = s_T[t];
   if (t == 0 && tp.stop_tol > 0.0) {
     double mx = stt[0];
@@ -442,6 +469,12 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       }
     }
   }
+  SB_T(5);
+#ifdef SB_TIMING
+  if (t == 0 && blockIdx.x == 7 && (k == 4 || k == 20))
+    printf("sb_panel<%d> k=%d: M/S %.1f us, X loop %.1f, P %.1f, QR %.1f, out %.1f\n", ROWS, k, (sb_t[1] - sb_t[0]) * 1e-2, (sb_t[2] - sb_t[1]) * 1e-2,
+           (sb_t[3] - sb_t[2]) * 1e-2, (sb_t[4] - sb_t[3]) * 1e-2, (sb_t[5] - sb_t[4]) * 1e-2);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------- stage 1: sweep
