@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
   if (k > 0) {
     const int org_prev = (kSbB * k) & ~15;
-    const int nw = tp.sb_lower ? 4 * ((n - org_prev + 63) / 64) : (n - org_prev) / 16;
+    const int nw = tp.sb_lower ? (n - org_prev + 63) / 64 : (n - org_prev) / 16;  // pieces of M: one per column block (lower sweeps) / per wave
     const double* const Zpa = sb_Zp(tp, mat);
     double acc = 0.0;
     for (int w = 0; w < nw; ++w) acc += Mpa[(int64_t)w * 256 + t];
@@ -740,9 +740,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     }
     __syncthreads();
   }
-  double* Mw = sb_Mp(tp, mat) + (int64_t)(4 * bx + wave) * 256;
+  // the block's share of M = V'^H Z: its four waves' pieces summed here (in wave order), one 16 x 16 block per column
+  // block for the panel kernel to add up
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) Mw[(lk + 4 * reg) * 16 + lr] = mp[reg];
+  for (int reg = 0; reg < 4; ++reg) sR[wave * 256 + reg * 64 + lane] = mp[reg];
+  __syncthreads();
+  if (wave == 0) {
+    double* Mw = sb_Mp(tp, mat) + (int64_t)bx * 256;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+      Mw[(lk + 4 * reg) * 16 + lr] = (sR[reg * 64 + lane] + sR[256 + reg * 64 + lane]) + (sR[512 + reg * 64 + lane] + sR[768 + reg * 64 + lane]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- stage 2: chase
