@@ -135,30 +135,27 @@ void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, 
   const int grid = grid_cap > 0 && grid_cap < nmat ? grid_cap : nmat;
   const int n = tp.d.Np;
   auto lds_of = [&](int order) { return tp.chase_layout ? sb_chase_lds2(order) : sb_chase_lds(order); };
-  // The rank stop leaves most matrices of a telescope at a fraction of their order, and which fraction is known from the
-  // chunks before (ctx->ml_order_hist).  A launch sized for the order that 98 % of them stayed under takes (and keeps)
-  // half a CU's LDS or less -- its blocks start beside the next chunk's sweep / Gram blocks instead of waiting for a CU
-  // whose LDS is empty --; the few matrices above go through a second, small persistent launch with the full image.
+  // The rank stop leaves the matrices of a telescope at a fraction of their order, and which fraction is known from the
+  // chunks before (ctx->ml_order_hist).  A launch sized for the largest order seen so far plus 64 columns (the orders
+  // drift with frequency and m, a few columns from one chunk to the next) takes (and keeps) half a CU's LDS or less --
+  // its blocks start beside the next chunk's sweep / Gram blocks instead of waiting for a CU whose LDS is empty --; a
+  // matrix above that goes through a second, small persistent launch with the full image.
   int cap = n;
   if (tp.stop_tol > 0.0 && ctx->opt_ml_chase_split != 1) {
-    int64_t total = 0, cum = 0;
-    for (int64_t h : ctx->ml_order_hist) total += h;
-    if (total >= 64) {
-      for (int b = 0; b < 17; ++b) {
-        cum += ctx->ml_order_hist[b];
-        if ((double)cum >= 0.98 * (double)total) {
-          cap = std::max(64 * b, 128);
-          break;
-        }
-      }
+    int64_t total = 0;
+    int top = 0;
+    for (int b = 0; b < 17; ++b) {
+      total += ctx->ml_order_hist[b];
+      if (ctx->ml_order_hist[b]) top = b;
     }
+    if (total >= 64) cap = std::max(64 * (top + 1), 128);
   }
   if (cap + 64 >= n) {
     hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), lds_of(n), st, tp, nmat, 0, n);
     return;
   }
   hipLaunchKernelGGL(k_sb_chase, dim3(grid), dim3(64 * kSbCW), lds_of(cap), st, tp, nmat, 0, cap);
-  hipLaunchKernelGGL(k_sb_chase, dim3(std::min(nmat, 32)), dim3(64 * kSbCW), lds_of(n), st, tp, nmat, cap, n);
+  hipLaunchKernelGGL(k_sb_chase, dim3(std::min(nmat, 64)), dim3(64 * kSbCW), lds_of(n), st, tp, nmat, cap, n);
 }
 
 // QL, the cut and the back-transformation of the reduced matrices: x into wbuf (telescope side) or alm (sky side)
