@@ -587,6 +587,9 @@ __global__ __launch_bounds__(kThreads) void k_sb_sweep(TdParams tp) {
 // the upper triangle is never touched again (the reflectors of finished panels stay there).
 // The J-side operands (X, V of update k-1, V' of panel k for the block's 64 columns) sit in LDS in the lane order of
 // the MFMA B operands.
+// UPD = false: sweep 0, which has no update pending -- it only reads (4.5 KB per tile instead of 8.5, on the largest
+// trailing matrix of all) and forms Z_0.
+template <bool UPD>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_sb_sweep_lo(TdParams tp) {
   __shared__ double sJ[4][kSbB][64];   // Xr, Xi, Vr, Vi: [q][column]
   __shared__ double sB[2][64][16];     // per column [V'r | V'i] and [-V'i | V'r] (entries q = 0..7 each)
@@ -671,22 +674,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
           }
         }
         // C -= V_I X_J^H + X_I V_J^H:  Re = Vr Xr + Vi Xi + Xr Vr + Xi Vi,  Im = Vi Xr - Vr Xi + Xi Vr - Xr Vi
+        if (UPD) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int q = lk + 4 * h, c = 16 * cb + (lr ^ (2 * q));
-          const double jxr = sJ[0][q][c], jxi = sJ[1][q][c], jvr = sJ[2][q][c], jvi = sJ[3][q][c];
-          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvr[h], jxr, cre, 0, 0, 0);
-          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxr, cim, 0, 0, 0);
-          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxi, cre, 0, 0, 0);
-          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pvr[h], jxi, cim, 0, 0, 0);
-          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxr[h], jvr, cre, 0, 0, 0);
-          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvr, cim, 0, 0, 0);
-          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvi, cre, 0, 0, 0);
-          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pxr[h], jvi, cim, 0, 0, 0);
+          for (int h = 0; h < 2; ++h) {
+            const int q = lk + 4 * h, c = 16 * cb + (lr ^ (2 * q));
+            const double jxr = sJ[0][q][c], jxi = sJ[1][q][c], jvr = sJ[2][q][c], jvi = sJ[3][q][c];
+            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvr[h], jxr, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxr, cim, 0, 0, 0);
+            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxi, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pvr[h], jxi, cim, 0, 0, 0);
+            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxr[h], jvr, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvr, cim, 0, 0, 0);
+            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvi, cre, 0, 0, 0);
+            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pxr[h], jvi, cim, 0, 0, 0);
+          }
+          double2* const cur = rowp + 16 * cb;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) cur[(int64_t)4 * reg * n] = make_double2(cre[reg], cim[reg]);
         }
-        double2* const cur = rowp + 16 * cb;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) cur[(int64_t)4 * reg * n] = make_double2(cre[reg], cim[reg]);
         // Z_J += C^H V'_I
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {

@@ -123,7 +123,8 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
     tp.j = k;
     panel();
     const int org = (kSbB * (k + 1)) & ~15;
-    if (tp.sb_lower) hipLaunchKernelGGL(k_sb_sweep_lo, dim3(nmat, (n - org + 63) / 64), dim3(kThreads), 0, st, tp);
+    if (tp.sb_lower && k == 0) hipLaunchKernelGGL(k_sb_sweep_lo<false>, dim3(nmat, (n - org + 63) / 64), dim3(kThreads), 0, st, tp);
+    else if (tp.sb_lower) hipLaunchKernelGGL(k_sb_sweep_lo<true>, dim3(nmat, (n - org + 63) / 64), dim3(kThreads), 0, st, tp);
     else hipLaunchKernelGGL(k_sb_sweep, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
   }
   tp.j = K;
@@ -800,7 +801,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     double by = 0.0;
     for (int k = 0; k < n / 8 - 1; ++k) {
       const double t = (n - ((8 * (k + 1)) & ~15)) / 16;
-      by += t * (t + 1) / 2 * 8.5 * 1024;
+      by += t * (t + 1) / 2 * (k == 0 ? 4.5 : 8.5) * 1024;  // (sweep 0 only reads)
     }
     ctx->ml_band_bytes += (int64_t)(by * nmat);
   };
