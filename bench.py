@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, help="SURVEY 8d config number (metric is quoted on 3)")
     ap.add_argument("--maker", default="dirty", choices=["dirty", "ml", "wiener"], help="map-maker of the timed day (the headline metric is quoted on dirty; cfg 3 of BASELINE.json names ml)")
     ap.add_argument("--tiles", default=None, choices=["random", "screen"], help="B tile source: counter-hash tiles (SyntheticProvider) or physically structured ones (BeamScreenProvider); default: random for dirty, screen for ml / wiener")
+    ap.add_argument("--band", default="spread", choices=["spread", "low"], help="ml / wiener on structured tiles: the resident pool's frequencies span the config's band (default: a telescope reaches higher m and its Gram matrices have higher rank at the top of the band) or are its lowest channels (the sample of rounds 3-4's earlier records)")
     ap.add_argument("--freqs", type=int, default=0, help="ml / wiener: frequencies of the timed day (0 = all of the config's; fewer = a stated sample, scaled)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: 'strong' (default) splits the metric's 256 frequencies over the ranks -- the job BASELINE.json names; 'weak' gives every rank its own 256")
     ap.add_argument("--b-dtype", default="complex128", choices=["complex128", "complex64"])
@@ -434,7 +435,16 @@ def dense_day(args, kind):
     pool_freqs = min(pool_freqs, nfreq)
     while nfreq % pool_freqs:
         pool_freqs -= 1
-    tel = TransitTelescope(wl.frequencies(nfreq_cfg)[:nfreq], lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
+    # The pool's distinct tiles are those of the telescope's first `pool_freqs` channels (the provider aliases f -> f % pool_freqs).
+    # Structured tiles depend on the wavelength -- at 800 MHz the telescope reaches twice the m it reaches at 400 MHz and
+    # its Gram matrices have twice the numerical rank -- so the pool's channels span the band ("spread"): every
+    # (nfreq_cfg / pool_freqs)-th channel of the config, cycled over the day's frequencies.
+    band = getattr(args, "band", "spread") if tiles == "screen" else "low"
+    if band == "spread":
+        tel_freqs = np.resize(wl.frequencies(nfreq_cfg)[:: nfreq_cfg // pool_freqs][:pool_freqs], nfreq)
+    else:
+        tel_freqs = wl.frequencies(nfreq_cfg)[:nfreq]
+    tel = TransitTelescope(tel_freqs, lmax=lmax, ncyl=cfg["ncyl"], nfeed_cyl=cfg["nfeed_cyl"])
     npairs = tel.npairs
     es = 16 if args.b_dtype == "complex128" else 8
     per_freq = sum(2 * npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * es
@@ -545,7 +555,7 @@ def dense_day(args, kind):
         "config": {
             "workload": f"cfg{args.config}: {tel.nfeed}-feed ({npairs} stacked baselines), {nfreq} of {nfreq_cfg} freq timed" + (f" (scaled x{scale:g} to the day)" if scale != 1 else "") + f", {nra} RA, lmax=mmax={lmax}: MModeTransform.process + {cls.__name__}.process through the task classes ({(lmax+1)*nfreq} (m,f) solves + alm2map to nside={nside})",
             "tiles": ("physically structured (BeamScreenProvider: per-polarisation Jones screens, narrow east-west primary beam; ill-conditioned Gram matrices like real products)" if tiles == "screen" else "counter-hash (SyntheticProvider: best-conditioned tiles possible)"),
-            "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}; generated on the GPU in {t_fill:.1f} s before the clock starts",
+            "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}" + (f"; the pool's channels span the band ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz, every {nfreq_cfg // pool_freqs}th channel of the config)" if band == "spread" else f"; the pool's channels are the config's lowest ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz)") + f"; generated on the GPU in {t_fill:.1f} s before the clock starts",
             "solves_per_s": (lmax + 1) * nfreq / day_s,
             "ms_per_solve": day_s * 1e3 / ((lmax + 1) * nfreq),
             "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "null_certificate": (c1[b"ml_tiles_null"] - c0[b"ml_tiles_null"]) // max(args.steps, 1),
