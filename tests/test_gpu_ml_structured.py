@@ -30,7 +30,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def _setup(nfreq=2, zero_frac=0.02, seed=11, **screen):
+def _setup(nfreq=2, zero_frac=0.02, seed=11, chan0=0, **screen):
     import torch
 
     from draco_amd.core import containers
@@ -39,7 +39,7 @@ def _setup(nfreq=2, zero_frac=0.02, seed=11, **screen):
 
     ctx = Context.get()
     c = osyn.CONFIGS[3]
-    tel = TransitTelescope(osyn.frequencies(c["nfreq"])[:nfreq], lmax=c["lmax"], ncyl=c["ncyl"], nfeed_cyl=c["nfeed_cyl"])
+    tel = TransitTelescope(osyn.frequencies(c["nfreq"])[chan0:chan0 + nfreq], lmax=c["lmax"], ncyl=c["ncyl"], nfeed_cyl=c["nfeed_cyl"])
     assert tel.npairs == 379 and tel.lmax == 512
     bt = BeamScreenProvider(tel, seed=3003, **screen)  # bench.py --maker ml's tile source and seed
     gen = torch.Generator(device=ctx.device).manual_seed(seed)
@@ -61,6 +61,9 @@ def _setup(nfreq=2, zero_frac=0.02, seed=11, **screen):
 @pytest.mark.parametrize("name,screen,sample", [
     ("bench", {}, [(0, 0), (0, 40), (0, 120), (0, 180), (0, 240), (0, 280), (0, 300), (0, 324), (0, 505), (1, 7), (1, 200), (1, 262)]),
     ("wide", {"cyl_sep": 44.0}, [(0, 10), (0, 250), (0, 322), (0, 330), (0, 380), (0, 430), (0, 470), (1, 325), (1, 400), (1, 455)]),
+    # (c) the TOP of the band (channels 254, 255: 797-798 MHz): the telescope reaches m ~ 600 > lmax -- no tile is null, the
+    #     Gram matrices have twice the numerical rank they have at 400 MHz, and the sky-side systems (m > 323) truncate too
+    ("top", {"chan0": 254}, [(0, 0), (0, 60), (0, 150), (0, 250), (0, 322), (0, 330), (0, 420), (0, 500), (1, 100), (1, 380)]),
 ])
 def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, screen, sample):
     import ctypes as C
@@ -72,7 +75,9 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
     from draco_amd.device import ptr
 
     nfreq = 2
-    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, **screen)
+    screen = dict(screen)
+    chan0 = screen.pop("chan0", 0)
+    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, chan0=chan0, **screen)
     lmax, n_m = tel.lmax, tel.lmax + 1
     task = MaximumLikelihoodMapMaker(nside=64, pool_bytes=nfreq * per_f + (1 << 20))
     task.setup(bt)
