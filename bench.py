@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--maker", default="dirty", choices=["dirty", "ml", "wiener"], help="map-maker of the timed day (the headline metric is quoted on dirty; cfg 3 of BASELINE.json names ml)")
     ap.add_argument("--tiles", default=None, choices=["random", "screen"], help="B tile source: counter-hash tiles (SyntheticProvider) or physically structured ones (BeamScreenProvider); default: random for dirty, screen for ml / wiener")
     ap.add_argument("--band", default="spread", choices=["spread", "low"], help="ml / wiener on structured tiles: the resident pool's frequencies span the config's band (default: a telescope reaches higher m and its Gram matrices have higher rank at the top of the band) or are its lowest channels (the sample of rounds 3-4's earlier records)")
+    ap.add_argument("--gram-resident", action="store_true", help="ml: keep the beam Gram products B B^H of the resident telescope-side tiles beside the B block (MaximumLikelihoodMapMaker.cache_beam_gram: multi-day processing; the warm-up day fills them) -- a labelled mode, not the default")
     ap.add_argument("--freqs", type=int, default=0, help="ml / wiener: frequencies of the timed day (0 = all of the config's; fewer = a stated sample, scaled)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: 'strong' (default) splits the metric's 256 frequencies over the ranks -- the job BASELINE.json names; 'weak' gives every rank its own 256")
     ap.add_argument("--b-dtype", default="complex128", choices=["complex128", "complex64"])
@@ -460,7 +461,8 @@ def dense_day(args, kind):
     mt = MModeTransform()
     mt.setup(bt)
     cls = MaximumLikelihoodMapMaker if kind == "ml" else WienerMapMaker
-    task = cls(nside=nside, b_dtype=args.b_dtype, pool_bytes=pool_freqs * per_freq + (1 << 20))
+    gram_resident = kind == "ml" and bool(getattr(args, "gram_resident", False))
+    task = cls(nside=nside, b_dtype=args.b_dtype, pool_bytes=pool_freqs * per_freq + (1 << 20), **({"cache_beam_gram": True} if gram_resident else {}))
     task.setup(bt)
 
     def counter(name):
@@ -483,7 +485,7 @@ def dense_day(args, kind):
     eng = task._get_engine()
     fills_before = eng.fills
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
-    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed", b"ml_tiles_null", b"ml_gram_flops", b"ml_band_bytes", b"ml_tiles_stopped", b"ml_stop_cols")}
+    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed", b"ml_tiles_null", b"ml_gram_flops", b"ml_band_bytes", b"ml_tiles_stopped", b"ml_stop_cols", b"ml_gram_cached")}
     mem0 = torch.cuda.memory_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -537,6 +539,14 @@ def dense_day(args, kind):
     roofline = {"kernel": "k_nt<GRAM/GRAMX> (Hermitian products D B B^H D / B^H N B on v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma", "achieved": gram_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": gram_tf / 78.6 if gram_tf else None, "traffic": None,
                 "flops_per_day": (gram_done * scale if kind == "ml" else gram_fl * nfreq_cfg), "ms_per_day_timed": prof["gram"]["ms"], "note": gram_note}
+    if gram_resident and secondary:
+        # the day's telescope-side Gram matrices come from the resident products (k_gram_scale: one read of the slot, one
+        # write of the matrix's lower blocks; no product computed); what is left of the Gram class are the sky-side
+        # products.  Stage 1 of the reduction is the pass's dominant kernel: its roofline leads.
+        n_c = (c1[b"ml_gram_cached"] - c0[b"ml_gram_cached"]) / max(args.steps, 1)
+        gram_rec = dict(roofline, note=gram_note + f"; --gram-resident: {n_c:.0f} of the timed day's telescope-side Gram matrices were formed from the resident products B B^H (computed by the warm-up day); the flops counted here are the sky-side products', the class time includes k_gram_scale")
+        roofline = dict(secondary[0], traffic=None, tiles_from_resident_products_per_day_timed=n_c)
+        secondary = [gram_rec] + secondary[1:]
     if kind == "wiener" and prof["solve"]["ms"] > 0:
         # dmm_wiener_run keeps two batches in flight on two streams (one's factorisation beside the other's Gram products):
         # the class sums overlap in time, the span of the whole pass is the time the matrix cores were asked for
@@ -555,7 +565,7 @@ def dense_day(args, kind):
         "config": {
             "workload": f"cfg{args.config}: {tel.nfeed}-feed ({npairs} stacked baselines), {nfreq} of {nfreq_cfg} freq timed" + (f" (scaled x{scale:g} to the day)" if scale != 1 else "") + f", {nra} RA, lmax=mmax={lmax}: MModeTransform.process + {cls.__name__}.process through the task classes ({(lmax+1)*nfreq} (m,f) solves + alm2map to nside={nside})",
             "tiles": ("physically structured (BeamScreenProvider: per-polarisation Jones screens, narrow east-west primary beam; ill-conditioned Gram matrices like real products)" if tiles == "screen" else "counter-hash (SyntheticProvider: best-conditioned tiles possible)"),
-            "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}" + (f"; the pool's channels span the band ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz, every {nfreq_cfg // pool_freqs}th channel of the config)" if band == "spread" else f"; the pool's channels are the config's lowest ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz)") + f"; generated on the GPU in {t_fill:.1f} s before the clock starts",
+            "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}" + (f"; the pool's channels span the band ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz, every {nfreq_cfg // pool_freqs}th channel of the config)" if band == "spread" else f"; the pool's channels are the config's lowest ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz)") + f"; generated on the GPU in {t_fill:.1f} s before the clock starts" + ("; beam Gram products B B^H of the resident telescope-side tiles kept beside them (%.1f GB, filled by the warm-up day)" % (sum(1 for m in range(lmax + 1) if 4 * (lmax + 1 - m) >= 2 * npairs) * pool_freqs * ((2 * npairs + 63) // 64) * ((2 * npairs + 63) // 64 + 1) // 2 * 65536 / 1e9) if gram_resident else ""),
             "solves_per_s": (lmax + 1) * nfreq / day_s,
             "ms_per_solve": day_s * 1e3 / ((lmax + 1) * nfreq),
             "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "null_certificate": (c1[b"ml_tiles_null"] - c0[b"ml_tiles_null"]) // max(args.steps, 1),
@@ -1079,14 +1089,17 @@ def extras(args, cfg, job):
         # counters (none of these tiles passes the full-rank certificate: every one is eigen-decomposed)
         import copy
 
-        for kind in ("wiener", "ml"):
+        # ("ml_day_gram_resident": the ML day again with the beam Gram products B B^H of the resident tiles kept beside the B
+        # block -- multi-day processing, `MaximumLikelihoodMapMaker.cache_beam_gram`; a labelled mode: the warm-up day fills them)
+        for kind, key, resident in (("wiener", "wiener_day", False), ("ml", "ml_day", False), ("ml", "ml_day_gram_resident", True)):
             try:
                 a2 = copy.copy(args)
                 a2.maker, a2.tiles, a2.freqs, a2.pool_freqs, a2.steps, a2.warmup, a2.b_dtype = kind, "screen", min(32, nfreq), 16, 1, 1, "complex128"
+                a2.gram_resident = resident
                 rec = dense_day(a2, kind)
-                extra[kind + "_day"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "roofline_secondary", "kernel_classes_ms_per_day_timed", "allocator")}
+                extra[key] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "roofline_secondary", "kernel_classes_ms_per_day_timed", "allocator")}
             except Exception as e:  # noqa: BLE001
-                extra[kind + "_day"] = {"error": repr(e)[:300]}
+                extra[key] = {"error": repr(e)[:300]}
             _solve.release_pools()
         # (4) B = host-stream (SURVEY 8d's second residency policy) THROUGH DirtyMapMaker.process: the tiles of a few
         # frequencies live in pinned host memory in the pool's wire format, nothing is resident on the GPU beforehand;

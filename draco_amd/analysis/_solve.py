@@ -37,6 +37,11 @@ class _Buffer:
         self.content = None  # key of the tiles it holds (None: garbage)
         self.filled = None  # event: the fill that produced `content` has finished (on the fill stream)
         self.last_use = None  # event: the last solve that read it has finished (on the caller's stream)
+        # resident beam Gram products of the buffer's telescope-side tiles (ML with `cache_beam_gram`): the arrays, and the
+        # buffer content they were computed from (anything else: stale, the library is told to start over)
+        self.gram = None
+        self.gram_valid = None
+        self.gram_content = None
 
 
 _BUFFERS: dict[int, list[_Buffer]] = {}
@@ -153,8 +158,9 @@ class SolveEngine:
 
     _MAX_PLAN_KEYS = 4
 
-    def __init__(self, provider, ctx=None, b_dtype=_lib.DMM_C128, b_layout=_lib.DMM_B_PACKED, pool_bytes=None, cache=True):
+    def __init__(self, provider, ctx=None, b_dtype=_lib.DMM_C128, b_layout=_lib.DMM_B_PACKED, pool_bytes=None, cache=True, gram_cache=False):
         self.provider = provider
+        self.gram_cache = bool(gram_cache)  # ML: keep B B^H of the resident telescope-side tiles beside the B block (multi-day processing)
         self.ctx = ctx or Context.get()
         self.b_dtype = b_dtype
         self.b_layout = b_layout
@@ -293,14 +299,39 @@ class SolveEngine:
             if buf.filled is not None and fill_stream != main:
                 main.wait_event(buf.filled)
             s.pool = buf.mem.view(_TORCH[self.b_dtype])
+            s.buf = buf
             try:
                 yield s
             finally:
                 s.pool = None  # plans outlive the pass; they must not keep the device's B block alive (release_pools)
+                s.buf = None
                 # also when the consumer raised or closed the generator after launching: whatever it did enqueue on
                 # `main` reads the buffer, and a later pass must not refill it underneath (recording is free)
                 buf.last_use = torch.cuda.Event()
                 buf.last_use.record(main)
+
+    def _gram_cache_on(self, slab):
+        """Hand the library the resident beam Gram products of the slab's buffer (``gram_cache``): the arrays live with
+        the buffer and are started over whenever it holds other tiles than the ones they were computed from."""
+        buf = getattr(slab, "buf", None)
+        if not self.gram_cache or buf is None or buf.content is None:
+            return False
+        lib = _lib.lib
+        nslots = int(lib.dmm_ml_gram_cache_slots(slab.plan))
+        nbytes = int(lib.dmm_ml_gram_cache_bytes(slab.plan))
+        if nslots == 0:
+            return False
+        reset = 0
+        if buf.gram is None or buf.gram.numel() < nbytes or buf.gram_valid.numel() < nslots:
+            buf.gram = buf.gram_valid = None
+            buf.gram = torch.empty(nbytes, dtype=torch.uint8, device=self.ctx.device)
+            buf.gram_valid = torch.zeros(nslots, dtype=torch.int32, device=self.ctx.device)
+            buf.gram_content = None
+        if buf.gram_content != buf.content:
+            reset = 1
+            buf.gram_content = buf.content
+        _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, ptr(buf.gram), ptr(buf.gram_valid), nslots, reset))
+        return True
 
     # ---- the four batched operations
     def solve(self, kind, mvis_d, mweight_d, freq_ind, mmax, on_freqs_done=None, **params):
@@ -342,11 +373,16 @@ class SolveEngine:
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
-                _lib.check(
-                    lib.dmm_ml_run(
-                        slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(mweight_d), float(params.get("acond", 1e-4)), float(params.get("rcond", 1e-3)), ptr(ws), ptr(alm)
+                cached = self._gram_cache_on(slab)
+                try:
+                    _lib.check(
+                        lib.dmm_ml_run(
+                            slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(mweight_d), float(params.get("acond", 1e-4)), float(params.get("rcond", 1e-3)), ptr(ws), ptr(alm)
+                        )
                     )
-                )
+                finally:
+                    if cached:
+                        _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, None, None, 0, 0))
             else:
                 raise ValueError(kind)
             issued += slab.ntile  # slabs are consecutive ranges of the f-major, m-minor tile list
@@ -409,9 +445,14 @@ class SolveEngine:
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
-                for d in range(D):
-                    _lib.check(lib.dmm_ml_run(slab.plan, ptr(slab.pool), ptr(mvis_l[d]), ptr(mweight_l[d]), float(params.get("acond", 1e-4)),
-                                              float(params.get("rcond", 1e-3)), ptr(ws), ptr(alms[d])))
+                cached = self._gram_cache_on(slab)
+                try:
+                    for d in range(D):
+                        _lib.check(lib.dmm_ml_run(slab.plan, ptr(slab.pool), ptr(mvis_l[d]), ptr(mweight_l[d]), float(params.get("acond", 1e-4)),
+                                                  float(params.get("rcond", 1e-3)), ptr(ws), ptr(alms[d])))
+                finally:
+                    if cached:
+                        _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, None, None, 0, 0))
             else:
                 raise ValueError(kind)
             issued += slab.ntile

@@ -95,7 +95,8 @@ class BaseMapMaker(ContainerTask):
     def _get_engine(self):
         if self._engine is None:
             dt = {"complex128": _lib.DMM_C128, "complex64": _lib.DMM_C64}[str(self.b_dtype)]
-            self._engine = _solve.SolveEngine(self.beamtransfer, Context.get(), dt, _lib.DMM_B_PACKED, self.pool_bytes)
+            self._engine = _solve.SolveEngine(self.beamtransfer, Context.get(), dt, _lib.DMM_B_PACKED, self.pool_bytes,
+                                              gram_cache=bool(getattr(self, "cache_beam_gram", False)))
         return self._engine
 
     def _solve_params(self):
@@ -316,6 +317,11 @@ class MaximumLikelihoodMapMaker(BaseMapMaker):
     """
 
     _kind = "ml"
+    # Multi-day processing: keep the products B B^H of the resident telescope-side tiles beside the B block.  The day's Gram
+    # matrix is D (B B^H) D with the day's weights in D only, so from the second day on it is formed by scaling the kept
+    # product -- bit-identical to computing it (`dmm_ctx_set_ml_gram_cache`).  Costs 5 MB of HBM per resident tile at cfg 3.
+    cache_beam_gram = False
+    _config_names = ("cache_beam_gram",)
 
     def _solve_params(self):
         return {"acond": 1e-4, "rcond": 1e-3}

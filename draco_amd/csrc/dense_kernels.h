@@ -60,6 +60,11 @@ struct DenseParams {
   const int* msel;         // Jacobi kernels: matrix index of the k-th selected matrix (nullptr: identity)
   double* theta;           // [nmat] upper bound of the largest eigenvalue
   double* diag;            // dmm_ctx_set_ml_diag: [nfreq][n_m][4] validation record of the rank decision, or nullptr
+  // resident beam Gram products (dmm_ctx_set_ml_gram_cache): B B^H of matrix `mat` lives in slot gslot[mat] (< 0: none),
+  // T (T + 1) / 2 blocks of 64 x 64; gvalid[slot] != 0: it is there (k_gram_scale forms G from it), else k_nt<MODE_GRAM> leaves it there
+  double2* gcache;
+  const int* gslot;
+  const int32_t* gvalid;
 };
 
 // Validation record of pinv_svd's rank decision for one tile (dmm_ctx_set_ml_diag): every thread of the 256-thread
@@ -157,6 +162,11 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
   __shared__ __align__(16) double xs[TB * LP];
   __shared__ __align__(16) double ys[TB * LP];
   const int mat = blockIdx.y;
+  int gs = -1;  // slot of the resident product this block leaves behind (MODE_GRAM with a cache)
+  if (MODE == MODE_GRAM && p.gcache) {
+    gs = p.gslot[mat];
+    if (gs >= 0 && p.gvalid[gs]) return;  // the product is resident: k_gram_scale forms this matrix
+  }
   const dmm_tile tile = p.tiles[p.tile0 + mat];
   int bi, bj;
   if (MODE == MODE_GRAM || MODE == MODE_GRAMX) {
@@ -364,6 +374,7 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
         double2* dst = p.A + ((int64_t)mat * p.Np + i) * p.Np + j;
         double re = cre[ti][tj][reg], im = cim[ti][tj][reg];
         if (MODE == MODE_GRAM) {
+          if (gs >= 0) p.gcache[((int64_t)gs * gridDim.x + blockIdx.x) * (TB * TB) + (i - I0) * TB + (j - J0)] = make_double2(re, im);  // B B^H, unscaled
           double di = 0.0, dj = 0.0;
           if (i < p.N) {
             const int s = i >= p.npairs, pp = i - s * p.npairs;
@@ -531,6 +542,51 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
       }
 }
 // the beam Gram launch: the DMA form where the tile layout allows it
+// The day's Gram matrix from the resident product: exactly the epilogue of k_nt<MODE_GRAM> (same expressions, same
+// masks: bit-identical matrices), on the entries that kernel writes -- the lower-triangle blocks, and of a diagonal block
+// the 16 x 16 tiles on and below its diagonal.
+__global__ __launch_bounds__(kThreads) void k_gram_scale(DenseParams p) {
+  const int mat = blockIdx.y;
+  const int gs = p.gslot[mat];
+  if (gs < 0 || !p.gvalid[gs]) return;
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  const int tt = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * tt + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= tt) ++bi;
+  while (bi * (bi + 1) / 2 > tt) --bi;
+  const int bj = tt - bi * (bi + 1) / 2;
+  const int I0 = bi * TB, J0 = bj * TB;
+  const double2* src = p.gcache + ((int64_t)gs * gridDim.x + tt) * (TB * TB);
+  for (int e = threadIdx.x; e < TB * TB; e += kThreads) {
+    const int li = e >> 6, lj = e & 63;
+    if (bi == bj && (lj >> 4) > (li >> 4)) continue;
+    const int i = I0 + li, j = J0 + lj;
+    const double2 raw = src[e];
+    double re = raw.x, im = raw.y;
+    double di = 0.0, dj = 0.0;
+    if (i < p.N) {
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      di = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+    }
+    if (j < p.N) {
+      const int s = j >= p.npairs, pp = j - s * p.npairs;
+      dj = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+    }
+    re *= di * dj;
+    im *= di * dj;
+    if (i >= p.N || j >= p.N) re = im = 0.0;
+    if (i == j) {
+      im = 0.0;
+      if (p.add_identity) re += 1.0;
+    }
+    p.A[((int64_t)mat * p.Np + i) * p.Np + j] = make_double2(re, im);
+  }
+}
+__global__ void k_gram_mark(const int* gslot, int32_t* gvalid, int nmat) {
+  const int mat = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mat < nmat && gslot[mat] >= 0) gvalid[gslot[mat]] = 1;
+}
+
 inline void launch_gram(const DenseParams& p, int nmat, hipStream_t st) {
   const bool dma = p.gram_dma && p.b_c128 && !p.full_layout && (int64_t)p.N * p.npol * (p.lmax + 1) < 0x7fffffff;
   if (dma) hipLaunchKernelGGL(k_gram_dma, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, st, p);

@@ -156,6 +156,7 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   else if (!strcmp(name, "ml_tiles_eigen")) *value = c->ml_tiles_eigen;
   else if (!strcmp(name, "ml_tiles_null")) *value = c->ml_tiles_null;
   else if (!strcmp(name, "ml_tiles_stopped")) *value = c->ml_tiles_stopped;
+  else if (!strcmp(name, "ml_gram_cached")) *value = c->ml_gram_cached;
   else if (!strcmp(name, "ml_stop_cols")) *value = c->ml_stop_cols;
   else if (!strcmp(name, "ml_gram_flops")) *value = c->ml_gram_flops;
   else if (!strcmp(name, "ml_band_bytes")) *value = c->ml_band_bytes;
@@ -175,6 +176,19 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
     *value = want_n ? c->prof_n[slot] : (int64_t)(c->prof_us[slot] + 0.5);
   }
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_get_counter: unknown counter '%s'", name);
+  return DMM_OK;
+}
+
+int dmm_ctx_set_ml_gram_cache(dmm_ctx* c, void* cache, int32_t* valid, int64_t nslots, int reset) {
+  DMM_REQUIRE(c != nullptr, "dmm_ctx_set_ml_gram_cache: ctx is NULL");
+  DMM_REQUIRE(cache == nullptr || (valid != nullptr && nslots > 0), "dmm_ctx_set_ml_gram_cache: a cache needs its valid flags and a slot count");
+  c->ml_gcache = (double2*)cache;
+  c->ml_gvalid = cache ? valid : nullptr;
+  c->ml_gslots = cache ? nslots : 0;
+  if (cache && (reset || (int64_t)c->ml_gvalid_h.size() != nslots)) {
+    DMM_HIP(hipMemsetAsync(valid, 0, (size_t)nslots * sizeof(int32_t), c->stream));
+    c->ml_gvalid_h.assign((size_t)nslots, 0);
+  }
   return DMM_OK;
 }
 

@@ -65,6 +65,11 @@ struct dmm_ctx {
   int opt_wiener_overlap = 1;              // 1: the batches of dmm_wiener_run alternate between two streams (half the workspace each); 0: one stream
   int opt_gram_stage = 0;                  // operand staging of the beam Gram kernel: 0 = through registers (k_nt), 1 = LDS-DMA (k_gram_dma, complex128 packed tiles)
   int opt_ml_reduce = 0;                   // tridiagonal reduction of the ML eigen path: 0 = two-stage (dense -> band -> tridiagonal) where the band fits the LDS, 1 = one-stage Householder
+  double2* ml_gcache = nullptr;            // dmm_ctx_set_ml_gram_cache: resident B B^H of the telescope-side tiles (caller-owned), or nullptr
+  int32_t* ml_gvalid = nullptr;            //   [ml_gslots] which slots hold a product
+  int64_t ml_gslots = 0;
+  std::vector<char> ml_gvalid_h;           //   host mirror of `ml_gvalid` in launch order (bookkeeping of the flop counter only)
+  int64_t ml_gram_cached = 0;              // counter: Gram matrices formed from a resident product
   double* ml_diag = nullptr;               // dmm_ctx_set_ml_diag: [nfreq][n_m][4] rank / sigma record of the eigen-decomposed ML tiles (validation)
   int opt_profile = 0;                     // 1: dmm_prof_scope records event pairs (bench.py's live kernel timing)
   std::vector<dmm_prof_span> prof_open;    // spans whose events have not been read yet

@@ -535,6 +535,9 @@ DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, cons
   p.msel = nullptr;
   p.theta = nullptr;
   p.diag = pl->ctx->ml_diag;
+  p.gcache = nullptr;
+  p.gslot = nullptr;
+  p.gvalid = nullptr;
   return p;
 }
 
@@ -583,6 +586,18 @@ extern "C" {
 // (the Wiener solve stages the sky-side operand like ML does: same workspace layout)
 int64_t dmm_wiener_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, 1); }
 int64_t dmm_ml_workspace_bytes(const dmm_plan* pl) { return workspace_bytes(pl, 2); }
+// resident beam Gram products (dmm_ctx_set_ml_gram_cache): one slot per telescope-side tile of the plan, in plan order
+int64_t dmm_ml_gram_cache_slots(const dmm_plan* pl) {
+  if (!pl) return 0;
+  int64_t n = 0;
+  for (const dmm_tile& t : pl->tiles_h) n += pl->npol * (pl->lmax + 1 - t.m) >= 2 * pl->npairs;
+  return n;
+}
+int64_t dmm_ml_gram_cache_bytes(const dmm_plan* pl) {
+  if (!pl) return 0;
+  const int64_t T = (2 * pl->npairs + TB - 1) / TB;
+  return dmm_ml_gram_cache_slots(pl) * (T * (T + 1) / 2) * TB * TB * (int64_t)sizeof(double2);
+}
 
 int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, double prior_amp,
                    double prior_tilt, void* workspace, void* alm) {
@@ -797,6 +812,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       ctx->ml_gram_flops += (int64_t)(4.0 * k * k * K);
     }
   };
+  auto uncount_gram = [&](const dmm_tile& tl) {  // (a Gram matrix formed from a resident product: no product computed)
+    const double nsky = (double)pl->npol * (pl->lmax + 1 - tl.m);
+    const double k = std::min<double>(ntel, nsky), K = std::max<double>(ntel, nsky);
+    ctx->ml_gram_flops -= (int64_t)(4.0 * k * k * K);
+  };
   auto count_band = [&](int n, int nmat) {
     double by = 0.0;
     for (int k = 0; k < n / 8 - 1; ++k) {
@@ -901,6 +921,15 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const int nsky = pl->npol * (pl->lmax + 1 - m);
     if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);  // 3: telescope side only
     else sky_lists[(nsky + TB - 1) / TB * TB].push_back(t);  // tiles of one padded order share batches
+  }
+  // resident beam Gram products: slot of a telescope-side tile = its rank among them in plan order
+  std::vector<int32_t> gslot_of;
+  const bool gcache_on = ctx->ml_gcache && ctx->opt_gram_stage != 1 && ctx->opt_ml_shortcut != 3 && dmm_ml_gram_cache_slots(pl) <= ctx->ml_gslots;
+  if (gcache_on) {
+    gslot_of.assign((size_t)pl->ntile, -1);
+    int32_t s = 0;
+    for (int64_t t = 0; t < pl->ntile; ++t)
+      if (pl->npol * (pl->lmax + 1 - pl->tiles_h[t].m) >= ntel) gslot_of[(size_t)t] = s++;
   }
   if (!sky_lists.empty()) {
     int rc = sky_rhs(pl, B, mvis, mweight, alm, sky_lists, tiles_d, work_d, cap);
@@ -1167,6 +1196,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     std::vector<dmm_tile> tiles;
     std::vector<int32_t> work;
     std::vector<int64_t> ids;
+    std::vector<int> slots;
     int nmat = 0, off = 0, np = 0;
     bool busy = false;
   } half[2];
@@ -1248,6 +1278,27 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         p.X = Vb;
         hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, S1, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+      } else if (gcache_on) {
+        // slots of the chunk's matrices -> device (the int array of the Jacobi flags is free on this path); the Gram
+        // kernel skips the matrices whose product is resident, k_gram_scale forms those from the slot
+        H.slots.resize(nmat);
+        int fresh = 0;
+        for (int i = 0; i < nmat; ++i) {
+          H.slots[i] = gslot_of[(size_t)list[i0 + i]];
+          if (H.slots[i] >= 0 && ctx->ml_gvalid_h[(size_t)H.slots[i]]) ++ctx->ml_gram_cached, uncount_gram(H.tiles[i]);
+          else ++fresh;
+        }
+        int* const slots_d = flag_d + off;
+        DMM_HIP(hipMemcpyAsync(slots_d, H.slots.data(), nmat * sizeof(int), hipMemcpyHostToDevice, S1));
+        p.gcache = ctx->ml_gcache;
+        p.gslot = slots_d;
+        p.gvalid = ctx->ml_gvalid;
+        if (fresh) hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+        if (fresh < nmat) hipLaunchKernelGGL(k_gram_scale, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+        hipLaunchKernelGGL(k_gram_mark, dim3((nmat + 255) / 256), dim3(256), 0, S1, slots_d, ctx->ml_gvalid, nmat);
+        for (int i = 0; i < nmat; ++i)
+          if (H.slots[i] >= 0) ctx->ml_gvalid_h[(size_t)H.slots[i]] = 1;
+        p.gcache = nullptr;  // (nothing downstream looks at the cache)
       } else {
         launch_gram(p, nmat, S1);
       }

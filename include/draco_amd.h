@@ -124,6 +124,18 @@ int dmm_ctx_get_counter(dmm_ctx* ctx, const char* name, int64_t* value);
  * l < m -- count as cut with sigma 0).  Tiles solved by the certified full-rank shortcut write nothing (initialise
  * the buffer to -1 to tell them apart).  f, m as in dmm_tile; n_m = the plan's.  NULL switches it off. */
 int dmm_ctx_set_ml_diag(dmm_ctx* ctx, double* diag);
+/* Resident beam Gram products for dmm_ml_run (multi-day processing: the beam transfers are the telescope's, the weights
+ * the day's).  The telescope-side Gram matrix of a tile is D (B B^H) D with D = sqrt(N^-1) of the day (mapmaker.py:190-198
+ * whitens B with it): B B^H does not change from day to day.  While `cache` [dev] is non-NULL, dmm_ml_run keeps the
+ * products B B^H of the plan's telescope-side tiles there -- slot s = the s-th such tile in plan order, T (T + 1) / 2
+ * lower-triangle blocks of 64 x 64 complex128 each (T = ceil(2 npairs / 64)): dmm_ml_gram_cache_bytes(plan) bytes --
+ * computing a slot the first time it meets it (`valid` [dev, one int32 per slot] says which are there) and forming the
+ * day's Gram matrix from the slot by the same scaling its Gram kernel applies (bit-identical matrices) ever after.
+ * The caller owns both arrays, keeps them with the B block they were computed from and passes reset = 1 whenever that
+ * block's contents change (the library then clears `valid`).  cache = NULL: off (default). */
+int dmm_ctx_set_ml_gram_cache(dmm_ctx* ctx, void* cache, int32_t* valid, int64_t nslots, int reset);
+int64_t dmm_ml_gram_cache_slots(const dmm_plan* plan);
+int64_t dmm_ml_gram_cache_bytes(const dmm_plan* plan);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
 int dmm_timer_start(dmm_ctx* ctx);
 int dmm_timer_stop(dmm_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */

@@ -259,3 +259,59 @@ def test_rank_stop_of_the_band_reduction_changes_no_rank_and_no_solution():
     assert ns_on == 0 or cols_s / ns_on > 0.8 * (cols_on / n_on) * 3  # (mean effective order: most of the matrix, not a third of it)
     assert np.array_equal(ds_on[..., 0], ds_off[..., 0])
     assert np.abs(s_on - s_off).max() < 1e-11 * np.abs(s_off).max(), np.abs(s_on - s_off).max() / np.abs(s_off).max()
+
+
+def test_resident_beam_gram_products_give_bit_identical_days():
+    """``cache_beam_gram``: the telescope-side Gram matrix of a day is D (B B^H) D with the day's weights in D only
+    (mapmaker.py:190-198 whitens B with them); with the products B B^H kept beside the resident B block the second day's
+    matrices are formed by the Gram kernel's own scaling -- every a_lm must equal the uncached pass bit for bit, on the day
+    that fills the cache and on the days that use it, also after the B block changed hands."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis import _solve
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+
+    nfreq = 2
+    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, seed=15)
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    gen = torch.Generator(device=ctx.device).manual_seed(99)
+    days = [mm]
+    for _ in range(2):  # two more days: other visibilities, other weights (other zero-weight baselines too)
+        v = torch.randn(mv.shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+        w = (torch.rand(mw.shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5) * 20.0 * 1024
+        w[torch.rand(mw.shape, dtype=torch.float64, device=ctx.device, generator=gen) < 0.02] = 0.0
+        d = containers.MModes(mmax=tel.lmax, freq=tel.frequencies, stack=tel.npairs, allocate=False)
+        d.attach("vis", v)
+        d.attach("vis_weight", w)
+        days.append(d)
+    plain = MaximumLikelihoodMapMaker(nside=64, pool_bytes=nfreq * per_f + (1 << 20))
+    plain.setup(bt)
+    ref = [plain.make_alm(d).cpu().numpy() for d in days]
+    cached = MaximumLikelihoodMapMaker(nside=64, pool_bytes=nfreq * per_f + (1 << 20), cache_beam_gram=True)
+    cached.setup(bt)
+    c0, e0 = counter(b"ml_gram_cached"), counter(b"ml_tiles_eigen")
+    a0 = cached.make_alm(days[0]).cpu().numpy()  # fills the cache
+    assert counter(b"ml_gram_cached") == c0
+    n_eig = counter(b"ml_tiles_eigen") - e0
+    a1 = cached.make_alm(days[1]).cpu().numpy()  # every telescope-side Gram matrix from its resident product
+    n_cached = counter(b"ml_gram_cached") - c0
+    n_tel = sum(1 for m in range(tel.lmax + 1) if 4 * (tel.lmax + 1 - m) >= 2 * tel.npairs) * nfreq
+    assert 0 < n_cached <= n_tel and n_cached > 0.5 * min(n_eig, n_tel)
+    assert np.array_equal(a0, ref[0]) and np.array_equal(a1, ref[1])
+    # the B block is given back and filled again: the engine starts the cache over (no stale product survives)
+    _solve.release_pools()
+    c1 = counter(b"ml_gram_cached")
+    a2 = cached.make_alm(days[2]).cpu().numpy()
+    assert counter(b"ml_gram_cached") == c1
+    assert np.array_equal(a2, ref[2])
+    a2b = cached.make_alm(days[2]).cpu().numpy()
+    assert counter(b"ml_gram_cached") > c1 and np.array_equal(a2b, ref[2])
