@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--maker", default="dirty", choices=["dirty", "ml", "wiener"], help="map-maker of the timed day (the headline metric is quoted on dirty; cfg 3 of BASELINE.json names ml)")
     ap.add_argument("--tiles", default=None, choices=["random", "screen"], help="B tile source: counter-hash tiles (SyntheticProvider) or physically structured ones (BeamScreenProvider); default: random for dirty, screen for ml / wiener")
     ap.add_argument("--band", default="spread", choices=["spread", "low"], help="ml / wiener on structured tiles: the resident pool's frequencies span the config's band (default: a telescope reaches higher m and its Gram matrices have higher rank at the top of the band) or are its lowest channels (the sample of rounds 3-4's earlier records)")
-    ap.add_argument("--gram-resident", action="store_true", help="ml: keep the beam Gram products B B^H of the resident telescope-side tiles beside the B block (MaximumLikelihoodMapMaker.cache_beam_gram: multi-day processing; the warm-up day fills them) -- a labelled mode, not the default")
+    ap.add_argument("--gram-resident", action="store_true", help="ml / wiener: keep the beam Gram products (B B^H, for Wiener B S B^H) of the resident telescope-side tiles beside the B block (task attribute cache_beam_gram: multi-day processing; the warm-up day fills them) -- a labelled mode, not the default")
     ap.add_argument("--freqs", type=int, default=0, help="ml / wiener: frequencies of the timed day (0 = all of the config's; fewer = a stated sample, scaled)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: 'strong' (default) splits the metric's 256 frequencies over the ranks -- the job BASELINE.json names; 'weak' gives every rank its own 256")
     ap.add_argument("--b-dtype", default="complex128", choices=["complex128", "complex64"])
@@ -461,7 +461,7 @@ def dense_day(args, kind):
     mt = MModeTransform()
     mt.setup(bt)
     cls = MaximumLikelihoodMapMaker if kind == "ml" else WienerMapMaker
-    gram_resident = kind == "ml" and bool(getattr(args, "gram_resident", False))
+    gram_resident = bool(getattr(args, "gram_resident", False))
     task = cls(nside=nside, b_dtype=args.b_dtype, pool_bytes=pool_freqs * per_freq + (1 << 20), **({"cache_beam_gram": True} if gram_resident else {}))
     task.setup(bt)
 
@@ -505,6 +505,8 @@ def dense_day(args, kind):
     scale = nfreq_cfg / nfreq  # a frequency sample is scaled to the config's day (frequencies are independent)
     value = (lmax + 1) / (day_s * scale)
     gram_fl, chol_fl = dense_flops(cfg, npairs)
+    if gram_resident and kind == "wiener":  # only the sky-side products are computed on a timed day (the telescope-side ones are resident)
+        gram_fl = sum(4.0 * (4 * (lmax + 1 - m)) ** 2 * (2 * npairs) for m in range(lmax + 1) if 4 * (lmax + 1 - m) < 2 * npairs)
     gram_tf = gram_fl * nfreq / (prof["gram"]["ms"] * 1e-3) / 1e12 if prof["gram"]["ms"] > 0 else None
     if kind == "ml":  # the library's own count of what it formed (tiles answered by the null certificate never get a Gram matrix)
         gram_done = (c1[b"ml_gram_flops"] - c0[b"ml_gram_flops"]) / max(args.steps, 1)
@@ -539,7 +541,7 @@ def dense_day(args, kind):
     roofline = {"kernel": "k_nt<GRAM/GRAMX> (Hermitian products D B B^H D / B^H N B on v_mfma_f64_16x16x4_f64)",
                 "bound": "mfma", "achieved": gram_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": gram_tf / 78.6 if gram_tf else None, "traffic": None,
                 "flops_per_day": (gram_done * scale if kind == "ml" else gram_fl * nfreq_cfg), "ms_per_day_timed": prof["gram"]["ms"], "note": gram_note}
-    if gram_resident and secondary:
+    if gram_resident and kind == "ml" and secondary:
         # the day's telescope-side Gram matrices come from the resident products (k_gram_scale: one read of the slot, one
         # write of the matrix's lower blocks; no product computed); what is left of the Gram class are the sky-side
         # products.  Stage 1 of the reduction is the pass's dominant kernel: its roofline leads.
@@ -555,7 +557,7 @@ def dense_day(args, kind):
         roofline = {"kernel": "dmm_wiener_run: Gram products + blocked Cholesky, all of it k_nt on v_mfma_f64_16x16x4_f64 (two batches in flight on two streams)",
                     "bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
                     "flops_per_day": (gram_fl + chol_fl) * nfreq_cfg, "ms_per_day_timed": prof["solve"]["ms"],
-                    "note": "useful flops (Hermitian half of the smaller Gram matrix 8 k^2 K / 2 + factorisation (8/3) k^3 per tile) / HIP-event span of every dmm_wiener_run of the timed day on the caller's stream"}
+                    "note": "useful flops (Hermitian half of the smaller Gram matrix 8 k^2 K / 2 + factorisation (8/3) k^3 per tile) / HIP-event span of every dmm_wiener_run of the timed day on the caller's stream" + ("; --gram-resident: the telescope-side products B S B^H are resident (computed by the warm-up day) and NOT counted: the flops are the factorisations and the sky-side products" if gram_resident else "")}
     out = {
         "metric": f"m-modes/sec through MModeTransform+{cls.__name__} (128-feed, 256-freq)",
         "value": value, "unit": "m-modes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -1091,7 +1093,7 @@ def extras(args, cfg, job):
 
         # ("ml_day_gram_resident": the ML day again with the beam Gram products B B^H of the resident tiles kept beside the B
         # block -- multi-day processing, `MaximumLikelihoodMapMaker.cache_beam_gram`; a labelled mode: the warm-up day fills them)
-        for kind, key, resident in (("wiener", "wiener_day", False), ("ml", "ml_day", False), ("ml", "ml_day_gram_resident", True)):
+        for kind, key, resident in (("wiener", "wiener_day", False), ("ml", "ml_day", False), ("ml", "ml_day_gram_resident", True), ("wiener", "wiener_day_gram_resident", True)):
             try:
                 a2 = copy.copy(args)
                 a2.maker, a2.tiles, a2.freqs, a2.pool_freqs, a2.steps, a2.warmup, a2.b_dtype = kind, "screen", min(32, nfreq), 16, 1, 1, "complex128"

@@ -310,9 +310,10 @@ class SolveEngine:
                 buf.last_use = torch.cuda.Event()
                 buf.last_use.record(main)
 
-    def _gram_cache_on(self, slab):
+    def _gram_cache_on(self, slab, tag=("ml",)):
         """Hand the library the resident beam Gram products of the slab's buffer (``gram_cache``): the arrays live with
-        the buffer and are started over whenever it holds other tiles than the ones they were computed from."""
+        the buffer and are started over whenever it holds other tiles than the ones they were computed from -- or the
+        products of another maker / prior (``tag``: ML keeps B B^H, Wiener B S B^H)."""
         buf = getattr(slab, "buf", None)
         if not self.gram_cache or buf is None or buf.content is None:
             return False
@@ -327,9 +328,9 @@ class SolveEngine:
             buf.gram = torch.empty(nbytes, dtype=torch.uint8, device=self.ctx.device)
             buf.gram_valid = torch.zeros(nslots, dtype=torch.int32, device=self.ctx.device)
             buf.gram_content = None
-        if buf.gram_content != buf.content:
+        if buf.gram_content != (tag, buf.content):
             reset = 1
-            buf.gram_content = buf.content
+            buf.gram_content = (tag, buf.content)
         _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, ptr(buf.gram), ptr(buf.gram_valid), nslots, reset))
         return True
 
@@ -365,11 +366,16 @@ class SolveEngine:
             elif kind == "wiener":
                 self._offer_workspace(b"wiener_workspace_mib", 24 << 10)  # 0.0649 -> 0.0620 ms per cfg-3 solve against 6 GiB
                 ws = self._workspace(int(lib.dmm_wiener_workspace_bytes(slab.plan)))
-                _lib.check(
-                    lib.dmm_wiener_run(
-                        slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(mweight_d), float(params["prior_amp"]), float(params["prior_tilt"]), ptr(ws), ptr(alm)
+                cached = self._gram_cache_on(slab, ("wiener", float(params["prior_amp"]), float(params["prior_tilt"])))
+                try:
+                    _lib.check(
+                        lib.dmm_wiener_run(
+                            slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(mweight_d), float(params["prior_amp"]), float(params["prior_tilt"]), ptr(ws), ptr(alm)
+                        )
                     )
-                )
+                finally:
+                    if cached:
+                        _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, None, None, 0, 0))
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
@@ -439,9 +445,14 @@ class SolveEngine:
             elif kind == "wiener":
                 self._offer_workspace(b"wiener_workspace_mib", 24 << 10)
                 ws = self._workspace(int(lib.dmm_wiener_workspace_bytes(slab.plan)))
-                for d in range(D):
-                    _lib.check(lib.dmm_wiener_run(slab.plan, ptr(slab.pool), ptr(mvis_l[d]), ptr(mweight_l[d]), float(params["prior_amp"]),
-                                                  float(params["prior_tilt"]), ptr(ws), ptr(alms[d])))
+                cached = self._gram_cache_on(slab, ("wiener", float(params["prior_amp"]), float(params["prior_tilt"])))
+                try:
+                    for d in range(D):
+                        _lib.check(lib.dmm_wiener_run(slab.plan, ptr(slab.pool), ptr(mvis_l[d]), ptr(mweight_l[d]), float(params["prior_amp"]),
+                                                      float(params["prior_tilt"]), ptr(ws), ptr(alms[d])))
+                finally:
+                    if cached:
+                        _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, None, None, 0, 0))
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))

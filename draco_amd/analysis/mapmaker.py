@@ -348,7 +348,10 @@ class WienerMapMaker(BaseMapMaker):
 
     prior_amp = 1.0
     prior_tilt = 0.5
-    _config_names = ("prior_amp", "prior_tilt")
+    # multi-day processing, as for MaximumLikelihoodMapMaker: the telescope-side system is I + D (B S B^H) D (mapmaker.py:267-272)
+    # with the day's weights in D only -- B S B^H is kept beside the resident B block (per prior) and scaled: bit-identical maps
+    cache_beam_gram = False
+    _config_names = ("prior_amp", "prior_tilt", "cache_beam_gram")
     _kind = "wiener"
 
     def _solve_params(self):

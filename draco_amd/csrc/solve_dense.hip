@@ -623,6 +623,7 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   dmm_tile* const tiles_d = (dmm_tile*)q;
   q += (size_t)cap * sizeof(dmm_tile);
   int32_t* const work_d = (int32_t*)q;
+  int* const slots_d = (int*)(work_d + (((size_t)cap + 8) & ~(size_t)1));  // [cap] slots of the resident products (the per-matrix extras leave room: layout_of)
 
   // Both of the reference's branches (mapmaker.py:267-278) are the same estimator; the smaller system is
   // solved: telescope side G = I + D B S B^H D while nsky_m >= ntel, sky side C^-1 = S^-1 + B^H Ni B at high m
@@ -638,6 +639,17 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
     int rc = sky_rhs(pl, B, mvis, mweight, alm, sky_lists, tiles_d, work_d, cap);
     if (rc) return rc;
   }
+  // resident beam Gram products (dmm_ctx_set_ml_gram_cache; here B S B^H: the cache belongs to this maker and this prior):
+  // slot of a telescope-side tile = its rank among them in plan order
+  std::vector<int32_t> gslot_of;
+  const bool gcache_on = ctx->ml_gcache && ctx->opt_gram_stage != 1 && ctx->opt_ml_shortcut != 3 && dmm_ml_gram_cache_slots(pl) <= ctx->ml_gslots;
+  if (gcache_on) {
+    gslot_of.assign((size_t)pl->ntile, -1);
+    int32_t s = 0;
+    for (int64_t t = 0; t < pl->ntile; ++t)
+      if (pl->npol * (pl->lmax + 1 - pl->tiles_h[t].m) >= ntel) gslot_of[(size_t)t] = s++;
+  }
+  std::vector<int> slots_c[2];
   const size_t solve_lds = ((size_t)L.Np + TB + 4 * TB) * sizeof(double2);
   DMM_HIP(hipFuncSetAttribute((const void*)k_chol_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
   const size_t diag_lds = (size_t)TB * (TB + 1) * sizeof(double2);
@@ -720,7 +732,29 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
       p.Sk = Sk;
       p.sk_pitch = L.sk_pitch;
       p.add_identity = 1;
-      launch_gram(p, nmat, S);
+      if (gcache_on) {  // (as in dmm_ml_run: the Gram kernel skips the matrices whose product is resident, k_gram_scale forms those)
+        std::vector<int>& sc = slots_c[h];
+        sc.resize(nmat);
+        int fresh = 0;
+        for (int i = 0; i < nmat; ++i) {
+          sc[i] = gslot_of[(size_t)list[i0 + i]];
+          if (sc[i] >= 0 && ctx->ml_gvalid_h[(size_t)sc[i]]) ++ctx->ml_gram_cached;
+          else ++fresh;
+        }
+        int* const sd = slots_d + off;
+        DMM_HIP(hipMemcpyAsync(sd, sc.data(), nmat * sizeof(int), hipMemcpyHostToDevice, S));
+        p.gcache = ctx->ml_gcache;
+        p.gslot = sd;
+        p.gvalid = ctx->ml_gvalid;
+        if (fresh) hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S, p);
+        if (fresh < nmat) hipLaunchKernelGGL(k_gram_scale, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S, p);
+        hipLaunchKernelGGL(k_gram_mark, dim3((nmat + 255) / 256), dim3(256), 0, S, sd, ctx->ml_gvalid, nmat);
+        for (int i = 0; i < nmat; ++i)
+          if (sc[i] >= 0) ctx->ml_gvalid_h[(size_t)sc[i]] = 1;
+        p.gcache = nullptr;
+      } else {
+        launch_gram(p, nmat, S);
+      }
     }
     {
       dmm_prof_scope prof(ctx, DMM_PROF_CHOL, S);

@@ -132,7 +132,9 @@ int dmm_ctx_set_ml_diag(dmm_ctx* ctx, double* diag);
  * computing a slot the first time it meets it (`valid` [dev, one int32 per slot] says which are there) and forming the
  * day's Gram matrix from the slot by the same scaling its Gram kernel applies (bit-identical matrices) ever after.
  * The caller owns both arrays, keeps them with the B block they were computed from and passes reset = 1 whenever that
- * block's contents change (the library then clears `valid`).  cache = NULL: off (default). */
+ * block's contents change (the library then clears `valid`).  cache = NULL: off (default).
+ * dmm_wiener_run honours the same arrays for its telescope-side systems I + D (B S B^H) D (mapmaker.py:267-272): the
+ * products are then B S B^H -- a cache belongs to ONE maker and ONE prior; hand each its own. */
 int dmm_ctx_set_ml_gram_cache(dmm_ctx* ctx, void* cache, int32_t* valid, int64_t nslots, int reset);
 int64_t dmm_ml_gram_cache_slots(const dmm_plan* plan);
 int64_t dmm_ml_gram_cache_bytes(const dmm_plan* plan);

@@ -315,3 +315,52 @@ def test_resident_beam_gram_products_give_bit_identical_days():
     assert np.array_equal(a2, ref[2])
     a2b = cached.make_alm(days[2]).cpu().numpy()
     assert counter(b"ml_gram_cached") > c1 and np.array_equal(a2b, ref[2])
+
+
+def test_resident_beam_gram_products_for_wiener_too():
+    """The Wiener maker's telescope-side systems ``I + D (B S B^H) D`` (mapmaker.py:267-272) from resident products
+    ``B S B^H``: bit-identical a_lm on the filling day and after; another prior starts the cache over."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import WienerMapMaker
+    from draco_amd.core import containers
+
+    nfreq = 2
+    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, seed=16)
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    gen = torch.Generator(device=ctx.device).manual_seed(7)
+    v = torch.randn(mv.shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    w = (torch.rand(mw.shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5) * 20.0 * 1024
+    w[torch.rand(mw.shape, dtype=torch.float64, device=ctx.device, generator=gen) < 0.02] = 0.0
+    day2 = containers.MModes(mmax=tel.lmax, freq=tel.frequencies, stack=tel.npairs, allocate=False)
+    day2.attach("vis", v)
+    day2.attach("vis_weight", w)
+    pool = nfreq * per_f + (1 << 20)
+    plain = WienerMapMaker(nside=64, pool_bytes=pool)
+    plain.setup(bt)
+    ref = [plain.make_alm(d).cpu().numpy() for d in (mm, day2)]
+    cached = WienerMapMaker(nside=64, pool_bytes=pool, cache_beam_gram=True)
+    cached.setup(bt)
+    c0 = counter(b"ml_gram_cached")
+    a0 = cached.make_alm(mm).cpu().numpy()
+    assert counter(b"ml_gram_cached") == c0
+    a1 = cached.make_alm(day2).cpu().numpy()
+    n_tel = sum(1 for m in range(tel.lmax + 1) if 4 * (tel.lmax + 1 - m) >= 2 * tel.npairs) * nfreq
+    assert counter(b"ml_gram_cached") - c0 == n_tel
+    assert np.array_equal(a0, ref[0]) and np.array_equal(a1, ref[1])
+    # another prior: other products -- the cache starts over, and the answer is that prior's
+    other = WienerMapMaker(nside=64, pool_bytes=pool, prior_tilt=1.0)
+    other.setup(bt)
+    ref_o = other.make_alm(day2).cpu().numpy()
+    cached.prior_tilt = 1.0
+    c1 = counter(b"ml_gram_cached")
+    a2 = cached.make_alm(day2).cpu().numpy()
+    assert counter(b"ml_gram_cached") == c1 and np.array_equal(a2, ref_o)
