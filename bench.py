@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--maker", default="dirty", choices=["dirty", "ml", "wiener"], help="map-maker of the timed day (the headline metric is quoted on dirty; cfg 3 of BASELINE.json names ml)")
     ap.add_argument("--tiles", default=None, choices=["random", "screen"], help="B tile source: counter-hash tiles (SyntheticProvider) or physically structured ones (BeamScreenProvider); default: random for dirty, screen for ml / wiener")
     ap.add_argument("--band", default="spread", choices=["spread", "low"], help="ml / wiener on structured tiles: the resident pool's frequencies span the config's band (default: a telescope reaches higher m and its Gram matrices have higher rank at the top of the band) or are its lowest channels (the sample of rounds 3-4's earlier records)")
+    ap.add_argument("--basis-resident", action="store_true", help="ml: keep the singular bases (U, Sigma) of the resident telescope-side beam transfers beside the B block (MaximumLikelihoodMapMaker.cache_beam_basis: the day's eigenproblem has the order of the beam transfer's numerical rank; the warm-up day builds them) -- a labelled mode, not the default")
     ap.add_argument("--gram-resident", action="store_true", help="ml / wiener: keep the beam Gram products (B B^H, for Wiener B S B^H) of the resident telescope-side tiles beside the B block (task attribute cache_beam_gram: multi-day processing; the warm-up day fills them) -- a labelled mode, not the default")
     ap.add_argument("--freqs", type=int, default=0, help="ml / wiener: frequencies of the timed day (0 = all of the config's; fewer = a stated sample, scaled)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: 'strong' (default) splits the metric's 256 frequencies over the ranks -- the job BASELINE.json names; 'weak' gives every rank its own 256")
@@ -462,7 +463,9 @@ def dense_day(args, kind):
     mt.setup(bt)
     cls = MaximumLikelihoodMapMaker if kind == "ml" else WienerMapMaker
     gram_resident = bool(getattr(args, "gram_resident", False))
-    task = cls(nside=nside, b_dtype=args.b_dtype, pool_bytes=pool_freqs * per_freq + (1 << 20), **({"cache_beam_gram": True} if gram_resident else {}))
+    basis_resident = kind == "ml" and bool(getattr(args, "basis_resident", False))
+    task = cls(nside=nside, b_dtype=args.b_dtype, pool_bytes=pool_freqs * per_freq + (1 << 20), **({"cache_beam_gram": True} if gram_resident else {}),
+               **({"cache_beam_basis": True} if basis_resident else {}))
     task.setup(bt)
 
     def counter(name):
@@ -485,7 +488,7 @@ def dense_day(args, kind):
     eng = task._get_engine()
     fills_before = eng.fills
     _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
-    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed", b"ml_tiles_null", b"ml_gram_flops", b"ml_band_bytes", b"ml_tiles_stopped", b"ml_stop_cols", b"ml_gram_cached")}
+    c0 = {k: counter(k) for k in (b"ml_tiles_direct", b"ml_tiles_eigen", b"ml_tiles_ql_failed", b"ml_tiles_null", b"ml_gram_flops", b"ml_band_bytes", b"ml_tiles_stopped", b"ml_stop_cols", b"ml_gram_cached", b"ml_tiles_basis")}
     mem0 = torch.cuda.memory_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -567,11 +570,13 @@ def dense_day(args, kind):
         "config": {
             "workload": f"cfg{args.config}: {tel.nfeed}-feed ({npairs} stacked baselines), {nfreq} of {nfreq_cfg} freq timed" + (f" (scaled x{scale:g} to the day)" if scale != 1 else "") + f", {nra} RA, lmax=mmax={lmax}: MModeTransform.process + {cls.__name__}.process through the task classes ({(lmax+1)*nfreq} (m,f) solves + alm2map to nside={nside})",
             "tiles": ("physically structured (BeamScreenProvider: per-polarisation Jones screens, narrow east-west primary beam; ill-conditioned Gram matrices like real products)" if tiles == "screen" else "counter-hash (SyntheticProvider: best-conditioned tiles possible)"),
-            "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}" + (f"; the pool's channels span the band ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz, every {nfreq_cfg // pool_freqs}th channel of the config)" if band == "spread" else f"; the pool's channels are the config's lowest ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz)") + f"; generated on the GPU in {t_fill:.1f} s before the clock starts" + ("; beam Gram products B B^H of the resident telescope-side tiles kept beside them (%.1f GB, filled by the warm-up day)" % (sum(1 for m in range(lmax + 1) if 4 * (lmax + 1 - m) >= 2 * npairs) * pool_freqs * ((2 * npairs + 63) // 64) * ((2 * npairs + 63) // 64 + 1) // 2 * 65536 / 1e9) if gram_resident else ""),
+            "b_residency": f"hbm-pool: {pool_freqs} frequencies' B tiles resident ({pool_freqs*per_freq/1e9:.1f} GB distinct, {args.b_dtype}, l>=m packed), provider aliases f -> f % {pool_freqs}" + (f"; the pool's channels span the band ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz, every {nfreq_cfg // pool_freqs}th channel of the config)" if band == "spread" else f"; the pool's channels are the config's lowest ({tel_freqs[0]:.1f} ... {tel_freqs[pool_freqs - 1]:.1f} MHz)") + f"; generated on the GPU in {t_fill:.1f} s before the clock starts" + ("; beam Gram products B B^H of the resident telescope-side tiles kept beside them (%.1f GB, filled by the warm-up day)" % (sum(1 for m in range(lmax + 1) if 4 * (lmax + 1 - m) >= 2 * npairs) * pool_freqs * ((2 * npairs + 63) // 64) * ((2 * npairs + 63) // 64 + 1) // 2 * 65536 / 1e9) if gram_resident else "")
+                           + ("; singular bases (U, Sigma; up to 448 vectors per tile) of the resident telescope-side tiles kept beside them (%.1f GB, built by the warm-up day)" % (sum(1 for m in range(lmax + 1) if 4 * (lmax + 1 - m) >= 2 * npairs) * pool_freqs * 448 * 2 * npairs * 16 / 1e9) if basis_resident else ""),
             "solves_per_s": (lmax + 1) * nfreq / day_s,
             "ms_per_solve": day_s * 1e3 / ((lmax + 1) * nfreq),
             "ml_tiles": {"certified_direct": n_direct, "eigen_decomposed": n_eigen, "null_certificate": (c1[b"ml_tiles_null"] - c0[b"ml_tiles_null"]) // max(args.steps, 1),
                          "ql_failed": c1[b"ml_tiles_ql_failed"] - c0[b"ml_tiles_ql_failed"],
+                         "basis_route": (c1[b"ml_tiles_basis"] - c0[b"ml_tiles_basis"]) // max(args.steps, 1),
                          "rank_stopped": (c1[b"ml_tiles_stopped"] - c0[b"ml_tiles_stopped"]) // max(args.steps, 1),
                          "rank_stop_mean_order": (c1[b"ml_stop_cols"] - c0[b"ml_stop_cols"]) / max(c1[b"ml_tiles_stopped"] - c0[b"ml_tiles_stopped"], 1)} if kind == "ml" else None,
         },
@@ -1093,11 +1098,14 @@ def extras(args, cfg, job):
 
         # ("ml_day_gram_resident": the ML day again with the beam Gram products B B^H of the resident tiles kept beside the B
         # block -- multi-day processing, `MaximumLikelihoodMapMaker.cache_beam_gram`; a labelled mode: the warm-up day fills them)
-        for kind, key, resident in (("wiener", "wiener_day", False), ("ml", "ml_day", False), ("ml", "ml_day_gram_resident", True), ("wiener", "wiener_day_gram_resident", True)):
+        # ("ml_day_basis_resident": with the singular bases of the resident beam transfers kept instead -- `cache_beam_basis`)
+        for kind, key, resident in (("wiener", "wiener_day", 0), ("ml", "ml_day", 0), ("ml", "ml_day_gram_resident", 1), ("wiener", "wiener_day_gram_resident", 1),
+                                    ("ml", "ml_day_basis_resident", 2)):
             try:
                 a2 = copy.copy(args)
                 a2.maker, a2.tiles, a2.freqs, a2.pool_freqs, a2.steps, a2.warmup, a2.b_dtype = kind, "screen", min(32, nfreq), 16, 1, 1, "complex128"
-                a2.gram_resident = resident
+                a2.gram_resident = resident == 1
+                a2.basis_resident = resident == 2
                 rec = dense_day(a2, kind)
                 extra[key] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "roofline_secondary", "kernel_classes_ms_per_day_timed", "allocator")}
             except Exception as e:  # noqa: BLE001

@@ -65,6 +65,7 @@ _SIGS = {
     "dmm_ctx_get_counter": (_i, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "dmm_ctx_set_ml_diag": (_i, [_vp, _vp]),
     "dmm_ctx_set_ml_gram_cache": (_i, [_vp, _vp, _vp, _i64, _i]),
+    "dmm_ctx_set_ml_basis": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i]),
     "dmm_ml_gram_cache_slots": (_i64, [_vp]),
     "dmm_ml_gram_cache_bytes": (_i64, [_vp]),
     "dmm_mmode_svd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp]),

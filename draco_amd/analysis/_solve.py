@@ -42,6 +42,9 @@ class _Buffer:
         self.gram = None
         self.gram_valid = None
         self.gram_content = None
+        # resident singular bases of the buffer's telescope-side tiles (ML with `cache_beam_basis`): U^H, sigma, rank per slot
+        self.basis = None
+        self.basis_content = None
 
 
 _BUFFERS: dict[int, list[_Buffer]] = {}
@@ -161,6 +164,8 @@ class SolveEngine:
     def __init__(self, provider, ctx=None, b_dtype=_lib.DMM_C128, b_layout=_lib.DMM_B_PACKED, pool_bytes=None, cache=True, gram_cache=False):
         self.provider = provider
         self.gram_cache = bool(gram_cache)  # ML: keep B B^H of the resident telescope-side tiles beside the B block (multi-day processing)
+        self.basis_cache = False            # ML: keep their singular bases instead (`cache_beam_basis`)
+        self.basis_rmax = 448
         self.ctx = ctx or Context.get()
         self.b_dtype = b_dtype
         self.b_layout = b_layout
@@ -310,6 +315,41 @@ class SolveEngine:
                 buf.last_use = torch.cuda.Event()
                 buf.last_use.record(main)
 
+    def _basis_on(self, slab, mvis_d, mweight_d, params, ws, alm):
+        """Hand the library the resident singular bases of the slab's buffer (``basis_cache``), building them first -- one
+        decomposition of B B^H per telescope-side tile, with unit weights -- when the buffer holds other tiles than the
+        ones they were computed from."""
+        buf = getattr(slab, "buf", None)
+        if not self.basis_cache or buf is None or buf.content is None:
+            return False
+        lib = _lib.lib
+        nslots = int(lib.dmm_ml_gram_cache_slots(slab.plan))
+        if nslots == 0:
+            return False
+        ntel = 2 * self.provider.telescope.npairs
+        rmax = int(self.basis_rmax)
+        if buf.basis is None or buf.basis[2].numel() < nslots or buf.basis[3] != (rmax, ntel):
+            buf.basis = None
+            U = torch.empty(nslots * rmax * ntel, dtype=torch.complex128, device=self.ctx.device)
+            sg = torch.empty(nslots * rmax, dtype=torch.float64, device=self.ctx.device)
+            rk = torch.empty(nslots, dtype=torch.int32, device=self.ctx.device)
+            buf.basis = (U, sg, rk, (rmax, ntel))
+            buf.basis_content = None
+        U, sg, rk, _ = buf.basis
+        if buf.basis_content != buf.content:
+            _lib.check(lib.dmm_ctx_set_ml_basis(self.ctx.handle, ptr(U), ptr(sg), ptr(rk), nslots, rmax, 1))
+            try:
+                ones = torch.ones_like(mweight_d)
+                _lib.check(lib.dmm_ml_run(slab.plan, ptr(slab.pool), ptr(mvis_d), ptr(ones), float(params.get("acond", 1e-4)),
+                                          float(params.get("rcond", 1e-3)), ptr(ws), ptr(alm)))
+                torch.cuda.current_stream(self.ctx.device).synchronize()  # (`ones` dies here)
+            finally:
+                _lib.check(lib.dmm_ctx_set_ml_basis(self.ctx.handle, None, None, None, 0, 0, 0))
+            buf.basis_content = buf.content
+            self.basis_builds = getattr(self, "basis_builds", 0) + 1
+        _lib.check(lib.dmm_ctx_set_ml_basis(self.ctx.handle, ptr(U), ptr(sg), ptr(rk), nslots, rmax, 0))
+        return True
+
     def _gram_cache_on(self, slab, tag=("ml",)):
         """Hand the library the resident beam Gram products of the slab's buffer (``gram_cache``): the arrays live with
         the buffer and are started over whenever it holds other tiles than the ones they were computed from -- or the
@@ -379,6 +419,7 @@ class SolveEngine:
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
+                based = self._basis_on(slab, mvis_d, mweight_d, params, ws, alm)
                 cached = self._gram_cache_on(slab)
                 try:
                     _lib.check(
@@ -389,6 +430,8 @@ class SolveEngine:
                 finally:
                     if cached:
                         _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, None, None, 0, 0))
+                    if based:
+                        _lib.check(lib.dmm_ctx_set_ml_basis(self.ctx.handle, None, None, None, 0, 0, 0))
             else:
                 raise ValueError(kind)
             issued += slab.ntile  # slabs are consecutive ranges of the f-major, m-minor tile list
@@ -456,6 +499,7 @@ class SolveEngine:
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
+                based = self._basis_on(slab, mvis_l[0], mweight_l[0], params, ws, alms[0])
                 cached = self._gram_cache_on(slab)
                 try:
                     for d in range(D):
@@ -464,6 +508,8 @@ class SolveEngine:
                 finally:
                     if cached:
                         _lib.check(lib.dmm_ctx_set_ml_gram_cache(self.ctx.handle, None, None, 0, 0))
+                    if based:
+                        _lib.check(lib.dmm_ctx_set_ml_basis(self.ctx.handle, None, None, None, 0, 0, 0))
             else:
                 raise ValueError(kind)
             issued += slab.ntile

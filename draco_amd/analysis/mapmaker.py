@@ -321,7 +321,18 @@ class MaximumLikelihoodMapMaker(BaseMapMaker):
     # matrix is D (B B^H) D with the day's weights in D only, so from the second day on it is formed by scaling the kept
     # product -- bit-identical to computing it (`dmm_ctx_set_ml_gram_cache`).  Costs 5 MB of HBM per resident tile at cfg 3.
     cache_beam_gram = False
-    _config_names = ("cache_beam_gram",)
+    # One step further: keep the singular bases B = U Sigma V^H of the resident telescope-side tiles (U, Sigma: what driftscan's
+    # SVD-compressed products hold).  The day's problem is then the r x r matrix Sigma U^H N^-1 U Sigma, r the beam transfer's
+    # numerical rank (150-400 of 758 at cfg 3): no Gram product of B, an eigenproblem of a third of the order.  Same modes
+    # kept, a_lm within the solver's own resolution of the full-order pass (not bit-identical: another, equally valid,
+    # rounding).  The first pass over a B block builds the bases (one decomposition per tile).
+    cache_beam_basis = False
+    _config_names = ("cache_beam_gram", "cache_beam_basis")
+
+    def _get_engine(self):
+        eng = super()._get_engine()
+        eng.basis_cache = bool(self.cache_beam_basis)
+        return eng
 
     def _solve_params(self):
         return {"acond": 1e-4, "rcond": 1e-3}

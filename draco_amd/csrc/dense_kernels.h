@@ -65,7 +65,15 @@ struct DenseParams {
   double2* gcache;
   const int* gslot;
   const int32_t* gvalid;
+  int64_t xstride;         // double2 units between the X arrays of consecutive matrices (0: Np * ldx, packed)
+  // basis route of the ML eigen path (solve_dense.hip, "resident beam bases"): the matrices are M = X X^H of order N with
+  // X = Sigma U^H D [N][ldx] (U, Sigma: the resident singular basis of the tile's beam transfer, D the day's weights)
+  int lr_n;                // > 0: order of the ORIGINAL system (right-hand side and solution have this length)
+  const int* lr_rank;      // [nmat] rows of X that are not zero
 };
+__device__ __forceinline__ const double2* x_of(const DenseParams& p, int mat) {
+  return p.X + (p.xstride ? (int64_t)mat * p.xstride : (int64_t)mat * p.Np * p.ldx);
+}
 
 // Validation record of pinv_svd's rank decision for one tile (dmm_ctx_set_ml_diag): every thread of the 256-thread
 // block brings what it saw of the spectrum -- kept count, smallest kept sigma, largest cut sigma.
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(kThreads) void k_nt(DenseParams p) {
       if (p.Sk) sk = p.Sk + (int64_t)tile.m * p.sk_pitch + c0;
     } else if (MODE == MODE_GRAMX) {
       const int n = order_of(p, tile);
-      xp = p.X + ((int64_t)mat * p.Np + min(I0 + r, n - 1)) * p.ldx + c0;
-      yp = p.X + ((int64_t)mat * p.Np + min(J0 + r, n - 1)) * p.ldx + c0;
+      xp = x_of(p, mat) + (int64_t)min(I0 + r, n - 1) * p.ldx + c0;
+      yp = x_of(p, mat) + (int64_t)min(J0 + r, n - 1) * p.ldx + c0;
     } else if (MODE == MODE_UPDATE) {
       xp = p.A + ((int64_t)mat * p.Np + I0 + r) * p.Np + c0;
       yp = p.A + ((int64_t)mat * p.Np + J0 + r) * p.Np + c0;

@@ -157,6 +157,7 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   else if (!strcmp(name, "ml_tiles_null")) *value = c->ml_tiles_null;
   else if (!strcmp(name, "ml_tiles_stopped")) *value = c->ml_tiles_stopped;
   else if (!strcmp(name, "ml_gram_cached")) *value = c->ml_gram_cached;
+  else if (!strcmp(name, "ml_tiles_basis")) *value = c->ml_tiles_basis;
   else if (!strcmp(name, "ml_stop_cols")) *value = c->ml_stop_cols;
   else if (!strcmp(name, "ml_gram_flops")) *value = c->ml_gram_flops;
   else if (!strcmp(name, "ml_band_bytes")) *value = c->ml_band_bytes;
@@ -176,6 +177,26 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
     *value = want_n ? c->prof_n[slot] : (int64_t)(c->prof_us[slot] + 0.5);
   }
   else return dmm_set_error(DMM_E_ARG, "dmm_ctx_get_counter: unknown counter '%s'", name);
+  return DMM_OK;
+}
+
+int dmm_ctx_set_ml_basis(dmm_ctx* c, void* U, double* sigma, int32_t* rank, int64_t nslots, int rmax, int build) {
+  DMM_REQUIRE(c != nullptr, "dmm_ctx_set_ml_basis: ctx is NULL");
+  DMM_REQUIRE(U == nullptr || (sigma != nullptr && rank != nullptr && nslots > 0 && rmax >= 64 && rmax % 64 == 0),
+              "dmm_ctx_set_ml_basis: a basis needs sigma, rank, a slot count and rmax a multiple of 64");
+  c->ml_bs_U = (double2*)U;
+  c->ml_bs_sigma = U ? sigma : nullptr;
+  c->ml_bs_rank = U ? rank : nullptr;
+  c->ml_bs_slots = U ? nslots : 0;
+  c->ml_bs_rmax = U ? rmax : 0;
+  c->ml_bs_build = U ? (build != 0) : 0;
+  c->ml_bs_rank_h.clear();
+  if (U && build) DMM_HIP(hipMemsetAsync(rank, 0xFF, (size_t)nslots * sizeof(int32_t), c->stream));  // -1: nothing there yet
+  if (U && !build) {  // the ranks size the chunks' small problems: host copy
+    c->ml_bs_rank_h.resize((size_t)nslots);
+    DMM_HIP(hipMemcpyAsync(c->ml_bs_rank_h.data(), rank, (size_t)nslots * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    DMM_HIP(hipStreamSynchronize(c->stream));
+  }
   return DMM_OK;
 }
 

@@ -65,6 +65,13 @@ struct dmm_ctx {
   int opt_wiener_overlap = 1;              // 1: the batches of dmm_wiener_run alternate between two streams (half the workspace each); 0: one stream
   int opt_gram_stage = 0;                  // operand staging of the beam Gram kernel: 0 = through registers (k_nt), 1 = LDS-DMA (k_gram_dma, complex128 packed tiles)
   int opt_ml_reduce = 0;                   // tridiagonal reduction of the ML eigen path: 0 = two-stage (dense -> band -> tridiagonal) where the band fits the LDS, 1 = one-stage Householder
+  double2* ml_bs_U = nullptr;              // dmm_ctx_set_ml_basis: resident singular bases of the telescope-side tiles (caller-owned), or nullptr
+  double* ml_bs_sigma = nullptr;
+  int32_t* ml_bs_rank = nullptr;
+  int64_t ml_bs_slots = 0;
+  int ml_bs_rmax = 0, ml_bs_build = 0;
+  std::vector<int32_t> ml_bs_rank_h;       //   host copy of the ranks (use mode: sizes the chunks' small problems)
+  int64_t ml_tiles_basis = 0;              // counter: tiles decomposed through the basis route
   double2* ml_gcache = nullptr;            // dmm_ctx_set_ml_gram_cache: resident B B^H of the telescope-side tiles (caller-owned), or nullptr
   int32_t* ml_gvalid = nullptr;            //   [ml_gslots] which slots hold a product
   int64_t ml_gslots = 0;

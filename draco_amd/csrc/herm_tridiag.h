@@ -50,6 +50,13 @@ struct TdParams {
                        // Q = Q1 Q2 from the block reflectors in A's upper triangle and the reflector log instead
   int sb_lower;        // 1: stage 1 sweeps the lower triangle only (k_sb_sweep_lo)
   int chase_layout;    // LDS layout of the bulge chase's band image: 0 = round 3's, 1 = the bank-spread one (herm_band.h)
+  // basis build (dmm_ctx_set_ml_basis, build = 1): PH 3 writes the eigenvectors of the kept eigenvalues instead of solving
+  double2* bs_U;       // [slot][bs_rmax][bs_ld]: row j = conj of the j-th kept eigenvector (nullptr: normal solve)
+  double* bs_sigma;    // [slot][bs_rmax] sqrt(lambda_j)
+  int32_t* bs_rank;    // [slot] kept count, -1: more than bs_rmax
+  const int* bs_slot;  // [nmat] slot of each matrix
+  int bs_rmax, bs_ld;
+  double bs_tol;       // kept: lambda > bs_tol * lambda_max
   double stop_tol;     // > 0: rank stop of the band reduction (herm_band.h) -- a matrix whose trailing trace has fallen to
                        // stop_tol * (lower bound of lambda_max) is cut off there: its effective order (sb_order) is what the
                        // chase, QL and the back-transformation work on
@@ -553,6 +560,10 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   // effective order: where the band reduction's rank stop cut the matrix off (herm_band.h); everything beyond is an
   // eigenvalue 0 -- below the cut
   const int ne = tp.two_stage ? sb_order(tp, mat) : n;
+  // basis route: the matrix is M = X X^H, X = Sigma U^H D; right-hand side z = X (D v), solution
+  // x = X^H W diag(keep / lambda^2) W^H z, output w = D x ("resident beam bases")
+  const bool lowrank = p.lr_n > 0;
+  const int lrk = lowrank ? p.lr_rank[mat] : 0;
 
   if (PH == 2) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -568,6 +579,30 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
     if (threadIdx.x == 0) {
       s_nrot = *nrun_g;
       s_fail = 0;
+    }
+  } else if (lowrank) {
+    double2* dvec = b + n;  // [lr_n] D v
+    for (int i = threadIdx.x; i < p.lr_n; i += kThreads) {
+      const int s = i >= p.npairs, pp = i - s * p.npairs;
+      const int64_t o = (((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp;
+      const double d = sqrt(p.mweight[o]);
+      const double2 x = p.mvis[o];
+      dvec[i] = make_double2(d * x.x, d * x.y);
+    }
+    __syncthreads();
+    const double2* Xm = x_of(p, mat);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = wv; i < n; i += kThreads / 64) {  // z_i = sum_row X[i][row] (D v)_row: a wave per row of X
+      double2 a = make_double2(0.0, 0.0);
+      if (i < lrk)
+        for (int r = lane; r < p.lr_n; r += 64) {
+          const double2 x = Xm[(int64_t)i * p.ldx + r], dv = dvec[r];
+          a.x += x.x * dv.x - x.y * dv.y;
+          a.y += x.x * dv.y + x.y * dv.x;
+        }
+      a.x = wave_sum(a.x);
+      a.y = wave_sum(a.y);
+      if (lane == 0) b[i] = a;
     }
   } else
   for (int i = threadIdx.x; i < n; i += kThreads) {
@@ -745,6 +780,48 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
   td_replay<false>(b, lcs, lrun, s_nrot);
   __syncthreads();
   TD_T(3);
+  // ---- basis build (dmm_ctx_set_ml_basis, build = 1): no solve -- the eigenvectors of the kept eigenvalues, one at a time:
+  // e_i through the logged chases backwards and through Q = Q1 Q2, conjugated into row j of the tile's slot
+  if ((PH == 3 || PH == 0) && tp.bs_U) {
+    __shared__ int s_r;
+    __shared__ double red_bs[5 * 16];
+    int* idx = reinterpret_cast<int*>(el);  // kept eigen-indices (el is free in this phase)
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) mx = fmax(mx, dl[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    const double lmx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (threadIdx.x == 0) {
+      int r = 0;
+      for (int i = 0; i < ne; ++i)
+        if (dl[i] > tp.bs_tol * lmx && dl[i] > 0.0) idx[r++] = i;
+      s_r = r;
+    }
+    __syncthreads();
+    const int r = s_r, slot = tp.bs_slot[mat];
+    const bool over = r > tp.bs_rmax;
+    if (threadIdx.x == 0) tp.bs_rank[slot] = over ? -1 : r;
+    if (over) return;
+    double2* Us = tp.bs_U + (int64_t)slot * tp.bs_rmax * tp.bs_ld;
+    const double2 *Tq, *rl;
+    sb_solve_ptrs(tp, mat, &Tq, &rl);
+    for (int j = 0; j < r; ++j) {
+      const int ii = idx[j];
+      for (int i = threadIdx.x; i < n; i += kThreads) b[i] = make_double2(i == ii ? 1.0 : 0.0, 0.0);
+      __syncthreads();
+      td_replay<true>(b, lcs, lrun, s_nrot);
+      __syncthreads();
+      sb_apply_q2<false>(b, rl, ne);
+      sb_apply_q1<false>(b, A, Tq, n, ne, red_bs);
+      for (int row = threadIdx.x; row < N; row += kThreads) Us[(int64_t)j * tp.bs_ld + row] = make_double2(b[row].x, -b[row].y);
+      if (threadIdx.x == 0) tp.bs_sigma[(int64_t)slot * tp.bs_rmax + j] = sqrt(dl[ii]);
+      __syncthreads();
+    }
+    return;
+  }
   // ---- the reference's cut on sigma = sqrt(lambda) (mapmaker.py:296), g = f(L) S^T z
   {
     double mx = 0.0;
@@ -760,7 +837,10 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
       const double lam = dl[i], sig = sqrt(fmax(lam, 0.0));
       double2 v = make_double2(0.0, 0.0);
       const bool keep = sig > tp.rcond * smax && sig > tp.acond;
-      if (keep) v = make_double2(b[i].x / lam, b[i].y / lam);
+      if (keep) {
+        const double dv = lowrank ? lam * lam : lam;
+        v = make_double2(b[i].x / dv, b[i].y / dv);
+      }
       b[i] = v;
       cnt += keep ? 1.0 : 0.0;
       mnk = keep ? fmin(mnk, sig) : mnk;
@@ -808,6 +888,22 @@ __global__ __launch_bounds__(kThreads) void k_td_solve(TdParams tp) {
            (td_t[2] - td_t[1]) * 1e-5, (td_t[3] - td_t[2]) * 1e-5, (td_t[4] - td_t[3]) * 1e-5, (td_t[5] - td_t[4]) * 1e-5);
 #endif
   if (threadIdx.x == 0 && ne < n) tp.fail[blockIdx.x] = ne << 8;  // (bit 0 = "QL gave up" stays clear: the host counts the stops)
+  if (lowrank) {  // w = D X^H y:  w_row = d_row sum_i conj(X[i][row]) y_i
+    __syncthreads();
+    const double2* Xm = x_of(p, mat);
+    for (int r = threadIdx.x; r < p.lr_n; r += kThreads) {
+      double2 a = make_double2(0.0, 0.0);
+      for (int i = 0; i < lrk; ++i) {
+        const double2 x = Xm[(int64_t)i * p.ldx + r], y = b[i];
+        a.x += x.x * y.x + x.y * y.y;
+        a.y += x.x * y.y - x.y * y.x;
+      }
+      const int s = r >= p.npairs, pp = r - s * p.npairs;
+      const double d = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+      p.wbuf[(int64_t)mat * p.lr_n + r] = make_double2(d * a.x, d * a.y);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < N; i += kThreads) {
     const double2 acc = b[i];
     if (p.sky) {

@@ -163,7 +163,7 @@ void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, 
 void td_solve(const TdParams& tp, int nmat, hipStream_t st) {
   const size_t n = tp.d.Np;
   // three launches: the long serial QL phase runs as ONE 64-thread wave per matrix (see k_td_solve)
-  hipLaunchKernelGGL(k_td_solve<1>, dim3(nmat), dim3(kThreads), n * sizeof(double2), st, tp);
+  hipLaunchKernelGGL(k_td_solve<1>, dim3(nmat), dim3(kThreads), (n + (size_t)tp.d.lr_n) * sizeof(double2), st, tp);  // (basis route: + D v)
   hipLaunchKernelGGL(k_td_solve<2>, dim3(nmat), dim3(64), n * 2 * sizeof(double), st, tp);
   hipLaunchKernelGGL(k_td_solve<3>, dim3(nmat), dim3(kThreads), n * (sizeof(double2) + 2 * sizeof(double)), st, tp);
 }
@@ -171,6 +171,35 @@ void td_solve(const TdParams& tp, int nmat, hipStream_t st) {
 }  // namespace
 
 namespace {
+
+// ---------------------------------------------------------------- ML: basis route (resident beam bases)
+// X = Sigma U^H D of every matrix of a chunk from its resident basis: row j = sigma_j conj(U[:, j]) (the slot's row j)
+// times the day's d_row; rows from the tile's rank up to the chunk's order nr are zero.  Also the rank per matrix.
+__global__ __launch_bounds__(kThreads) void k_basis_x(DenseParams p, const double2* U, const double* sigma, const int32_t* rank, const int* slots,
+                                                     int rmax, double2* X, int64_t xstride, int nr, int* rank_out) {
+  __shared__ double s_d[kSbRows * kThreads];
+  const int mat = blockIdx.x, slot = slots[mat], n = p.N, r = rank[slot];
+  const dmm_tile tile = p.tiles[p.tile0 + mat];
+  for (int i = threadIdx.x; i < n; i += kThreads) {
+    const int s = i >= p.npairs, pp = i - s * p.npairs;
+    s_d[i] = sqrt(p.mweight[(((int64_t)tile.m * 2 + s) * p.nfreq + tile.f) * p.npairs + pp]);
+  }
+  if (threadIdx.x == 0) rank_out[mat] = r;
+  __syncthreads();
+  const double2* Us = U + (int64_t)slot * rmax * n;
+  const double* sg = sigma + (int64_t)slot * rmax;
+  double2* Xm = X + (int64_t)mat * xstride;
+  for (int64_t e = threadIdx.x; e < (int64_t)nr * n; e += kThreads) {
+    const int j = (int)(e / n), row = (int)(e - (int64_t)j * n);
+    double2 v = make_double2(0.0, 0.0);
+    if (j < r) {
+      const double2 u = Us[(int64_t)j * n + row];
+      const double f = sg[j] * s_d[row];
+      v = make_double2(f * u.x, f * u.y);
+    }
+    Xm[e] = v;
+  }
+}
 
 // ---------------------------------------------------------------- ML: certificate of "nothing cut"
 // X[mat][k][i] = d_i conj(B[i][k]): the rows of (D B)^H, so that the NT tile product gives B^H Ni B
@@ -538,6 +567,9 @@ DenseParams make_params(const dmm_plan* pl, const Layout& L, const void* B, cons
   p.gcache = nullptr;
   p.gslot = nullptr;
   p.gvalid = nullptr;
+  p.xstride = 0;
+  p.lr_n = 0;
+  p.lr_rank = nullptr;
   return p;
 }
 
@@ -872,7 +904,13 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     ++ctx->ml_tiles_stopped;
     ctx->ml_stop_cols += ne;
   };
-  const bool shortcut = ctx->opt_ml_shortcut != 2;  // 2: always take the eigen path (tests, timing)
+  // resident beam bases (dmm_ctx_set_ml_basis): build = this call decomposes B B^H of the telescope-side tiles and leaves the bases
+  const bool bs_have = ctx->ml_bs_U != nullptr && ctx->opt_ml_shortcut != 3 && ctx->opt_ml_reduce == 0 && sb_stop_tol(ctx) > 0.0 &&
+                       ntel <= kSbRows * kThreads && dmm_ml_gram_cache_slots(pl) <= ctx->ml_bs_slots;
+  const bool bs_build = bs_have && ctx->ml_bs_build;
+  const bool bs_use = bs_have && !ctx->ml_bs_build && (int64_t)ctx->ml_bs_rank_h.size() >= dmm_ml_gram_cache_slots(pl);
+  DMM_REQUIRE(!ctx->ml_bs_build || bs_build, "dmm_ml_run: the basis build needs the two-stage reduction with its rank stop and enough slots");
+  const bool shortcut = ctx->opt_ml_shortcut != 2 && !bs_build;  // 2: always take the eigen path (tests, timing)
   const int max_sweeps = ctx->opt_ml_outer_sweeps > 0 ? ctx->opt_ml_outer_sweeps : 60;
   const int inner_sweeps = ctx->opt_ml_inner_sweeps > 0 ? ctx->opt_ml_inner_sweeps : 1;  // tools/ml_tune.py
 
@@ -883,7 +921,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   // one (a tile is never called null unseen; a null tile below that m is simply decomposed like any other).  The scratch
   // is the workspace header (the prior tables of the Wiener solve: unused here).  "ml_null" = 1 switches it off.
   std::vector<char> is_null(pl->ntile, 0);
-  if (ctx->opt_ml_null != 1 && acond > 0.0 && (size_t)pl->ntile * (sizeof(double) + sizeof(int32_t)) <= L.header) {
+  if (ctx->opt_ml_null != 1 && !bs_build && acond > 0.0 && (size_t)pl->ntile * (sizeof(double) + sizeof(int32_t)) <= L.header) {
     double* const trace_d = (double*)ws;
     int32_t* const list_d = (int32_t*)(trace_d + pl->ntile);
     // (the sum is exact to a few ulp; the margin keeps a tile AT the threshold on the decomposing side, where the cut
@@ -956,10 +994,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     if (nsky >= ntel || ctx->opt_ml_shortcut == 3) tel_list.push_back(t);  // 3: telescope side only
     else sky_lists[(nsky + TB - 1) / TB * TB].push_back(t);  // tiles of one padded order share batches
   }
+  if (bs_build) sky_lists.clear();  // (a basis belongs to a telescope-side tile)
   // resident beam Gram products: slot of a telescope-side tile = its rank among them in plan order
   std::vector<int32_t> gslot_of;
-  const bool gcache_on = ctx->ml_gcache && ctx->opt_gram_stage != 1 && ctx->opt_ml_shortcut != 3 && dmm_ml_gram_cache_slots(pl) <= ctx->ml_gslots;
-  if (gcache_on) {
+  const bool gcache_on = !bs_build && ctx->ml_gcache && ctx->opt_gram_stage != 1 && ctx->opt_ml_shortcut != 3 && dmm_ml_gram_cache_slots(pl) <= ctx->ml_gslots;
+  if (gcache_on || bs_build || bs_use) {
     gslot_of.assign((size_t)pl->ntile, -1);
     int32_t s = 0;
     for (int64_t t = 0; t < pl->ntile; ++t)
@@ -1124,6 +1163,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
         tp.chase_layout = sb_chase_layout(ctx, n);
         tp.stop_tol = sb_stop_tol(ctx);
+        tp.bs_U = nullptr;
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
         DMM_HIP(hipMemsetAsync(fail_b, 0, nsel * sizeof(int), ctx->stream));
         if (tp.two_stage) {
@@ -1260,7 +1300,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       if (fl[k] & 1) {
         (redo_is_sky[h] ? redo_sky[redo_np[h]] : redo_tel).push_back(H.ids[k]);
         ++ctx->ml_tiles_ql_failed;
-      } else {  // the rank stop's effective order (0: none)
+      } else if (!bs_build) {  // the rank stop's effective order (0: none)
         count_stop(H.np, fl[k] >> 8);
       }
     H.busy = false;
@@ -1303,8 +1343,50 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     redo_np[h] = np_sky;
     DMM_HIP(hipMemcpyAsync(tiles_h, H.tiles.data(), nmat * sizeof(dmm_tile), hipMemcpyHostToDevice, S1));
     DMM_HIP(hipMemcpyAsync(work_h, H.work.data(), (nmat + 1) * sizeof(int32_t), hipMemcpyHostToDevice, S1));
-    const int T = p.T, n = p.Np;
-    {
+    const int T = p.T;
+    int n = p.Np;
+    // slots of the chunk's telescope-side matrices (resident Gram products / bases) -> device (the int array of the Jacobi
+    // flags is free on this path)
+    int* const slots_d = flag_d + off;
+    if (!sky && (gcache_on || bs_build || bs_use)) {
+      H.slots.resize(nmat);
+      for (int i = 0; i < nmat; ++i) H.slots[i] = gslot_of[(size_t)list[i0 + i]];
+      DMM_HIP(hipMemcpyAsync(slots_d, H.slots.data(), nmat * sizeof(int), hipMemcpyHostToDevice, S1));
+    }
+    // Basis route (dmm_ctx_set_ml_basis): every tile of the chunk has its singular basis resident -- the day's problem is
+    // M = X X^H with X = Sigma U^H D, of the order of the chunk's largest rank; no Gram product of B
+    int nr = 0;
+    if (!sky && bs_use) {
+      int rmx = 0;
+      bool all = true;
+      for (int i = 0; i < nmat; ++i) {
+        const int r = H.slots[i] >= 0 ? ctx->ml_bs_rank_h[(size_t)H.slots[i]] : -1;
+        all = all && r >= 0;
+        rmx = std::max(rmx, r);
+      }
+      nr = std::max((rmx + TB - 1) / TB * TB, 2 * TB);
+      if (!all || nr + 128 > n || !sb_usable(ctx, nr)) nr = 0;
+    }
+    if (nr > 0) {
+      dmm_prof_scope prof(ctx, DMM_PROF_GRAM, S1);
+      double2* const Xb = Vb + (int64_t)L.Np * L.Np;  // second half of every matrix's log region (the QL log is capped below it)
+      const int64_t xs = (int64_t)2 * L.Np * L.Np;
+      int* const rank_d = msel_d + off;                // (the selection list of the synchronous batches: free here)
+      hipLaunchKernelGGL(k_basis_x, dim3(nmat), dim3(kThreads), 0, S1, p, (const double2*)ctx->ml_bs_U, (const double*)ctx->ml_bs_sigma,
+                         (const int32_t*)ctx->ml_bs_rank, (const int*)slots_d, ctx->ml_bs_rmax, Xb, xs, nr, rank_d);
+      p.X = Xb;
+      p.xstride = xs;
+      p.ldx = ntel;
+      p.lr_n = ntel;
+      p.lr_rank = rank_d;
+      p.N = p.Np = nr;
+      p.T = nr / TB;
+      hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);  // M = X X^H
+      ctx->ml_gram_flops += (int64_t)(4.0 * nr * (double)nr * ntel) * nmat;
+      n = nr;
+      H.np = nr;
+      ctx->ml_tiles_basis += nmat;
+    } else {
       dmm_prof_scope prof(ctx, DMM_PROF_GRAM, S1);
       count_gram(H.tiles.data(), nmat);
       if (sky) {
@@ -1313,17 +1395,12 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         hipLaunchKernelGGL(k_xpose, dim3((p.N + 31) / 32, (ntel + 31) / 32, nmat), dim3(kThreads), 0, S1, p, Vb);
         hipLaunchKernelGGL(k_nt<MODE_GRAMX>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
       } else if (gcache_on) {
-        // slots of the chunk's matrices -> device (the int array of the Jacobi flags is free on this path); the Gram
-        // kernel skips the matrices whose product is resident, k_gram_scale forms those from the slot
-        H.slots.resize(nmat);
+        // the Gram kernel skips the matrices whose product is resident, k_gram_scale forms those from the slot
         int fresh = 0;
         for (int i = 0; i < nmat; ++i) {
-          H.slots[i] = gslot_of[(size_t)list[i0 + i]];
           if (H.slots[i] >= 0 && ctx->ml_gvalid_h[(size_t)H.slots[i]]) ++ctx->ml_gram_cached, uncount_gram(H.tiles[i]);
           else ++fresh;
         }
-        int* const slots_d = flag_d + off;
-        DMM_HIP(hipMemcpyAsync(slots_d, H.slots.data(), nmat * sizeof(int), hipMemcpyHostToDevice, S1));
         p.gcache = ctx->ml_gcache;
         p.gslot = slots_d;
         p.gvalid = ctx->ml_gvalid;
@@ -1356,8 +1433,20 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
     tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
     tp.chase_layout = sb_chase_layout(ctx, n);
-    tp.stop_tol = sb_stop_tol(ctx);
+    tp.stop_tol = bs_build ? 1e-16 : sb_stop_tol(ctx);  // (a basis must hold B B^H to 1e-15: its truncation enters the day's Gram matrix in first order)
     if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
+    if (nr > 0) tp.log_cap = (int)std::min<int64_t>(tp.log_cap, (int64_t)L.Np * L.Np - ((int64_t)3 * runs * sizeof(int) + 15) / 16);  // (QL's log and its chase headers end where X begins)
+    tp.bs_U = nullptr;
+    if (bs_build && !sky) {
+      DMM_REQUIRE(tp.two_stage, "dmm_ml_run: the basis build needs the two-stage reduction (order %d)", n);
+      tp.bs_U = ctx->ml_bs_U;
+      tp.bs_sigma = ctx->ml_bs_sigma;
+      tp.bs_rank = ctx->ml_bs_rank;
+      tp.bs_slot = slots_d;
+      tp.bs_rmax = ctx->ml_bs_rmax;
+      tp.bs_ld = ntel;
+      tp.bs_tol = 1e-15;
+    }
     DMM_HIP(hipMemsetAsync(fail_hd, 0, nmat * sizeof(int), S1));
     if (tp.two_stage) {
       dmm_prof_scope prof(ctx, DMM_PROF_BAND, S1);
@@ -1379,7 +1468,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       td_solve(tp, nmat, S2);
     }
     DMM_HIP(hipGetLastError());
-    if (!sky) {  // back-projection a = B^H w of the half's tiles, behind its solve on the second stream
+    if (!sky && !bs_build) {  // back-projection a = B^H w of the half's tiles, behind its solve on the second stream
       dmm_prof_scope prof(ctx, DMM_PROF_BACKPROJ, S2);
       ctx->stream = S2;
       rc = dmm_dirty_w_launch_list(pl, B, p.wbuf, nullptr, tiles_h, work_h, nmat, H.work[nmat], alm);
@@ -1399,7 +1488,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     if (list.empty()) return DMM_OK;
     const int np = ((sky ? np_sky : ntel) + TB - 1) / TB * TB;
     const int eig = ctx->opt_ml_eigen;
-    const bool pipelined = capE >= 1 && (eig == 4 || eig == 3 || (eig == 0 && (double)std::min<size_t>(capE, list.size()) * np >= 12000.0));
+    const bool pipelined = capE >= 1 && (eig == 4 || eig == 3 || bs_build || (eig == 0 && (double)std::min<size_t>(capE, list.size()) * np >= 12000.0));
     if (!pipelined) {
       // the synchronous batches use the whole workspace: nothing of the pipeline may still be in flight in it
       int rc = retire(0);

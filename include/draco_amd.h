@@ -136,6 +136,20 @@ int dmm_ctx_set_ml_diag(dmm_ctx* ctx, double* diag);
  * dmm_wiener_run honours the same arrays for its telescope-side systems I + D (B S B^H) D (mapmaker.py:267-272): the
  * products are then B S B^H -- a cache belongs to ONE maker and ONE prior; hand each its own. */
 int dmm_ctx_set_ml_gram_cache(dmm_ctx* ctx, void* cache, int32_t* valid, int64_t nslots, int reset);
+/* Resident singular bases of the beam transfers for dmm_ml_run (multi-day processing, one step further than the Gram
+ * products).  B B^H = U Sigma^2 U^H does not change from day to day: with U and Sigma of a telescope-side tile resident
+ * (numerical rank r = 150 ... 400 of 758 at cfg 3) the day's Gram matrix D B B^H D = A A^H, A = D U Sigma, has the non-zero
+ * spectrum of the r x r matrix M = A^H A = Sigma U^H D^2 U Sigma, and pinv_svd's solution (mapmaker.py:190-201, 287-300) is
+ * A W diag(keep / lambda^2) W^H A^H (D v) with M = W Lambda W^H -- an order-r eigenproblem per tile and day instead of
+ * an order-758 one, and no Gram product of B at all.
+ *   build = 1: the next dmm_ml_run calls do NOT solve: they decompose B B^H of every telescope-side tile of their plan (pass
+ *              unit weights) and leave, per slot (= the tile's rank among the plan's telescope-side tiles, as for the Gram
+ *              cache): U^H as rmax rows of 2 npairs complex128 (`U`), the singular values (`sigma`, rmax doubles) and
+ *              their count (`rank`, -1: more than rmax above 1e-15 of the largest eigenvalue -- the tile keeps the
+ *              full-order path).  alm is not written.
+ *   build = 0: dmm_ml_run takes the basis route for every chunk whose tiles all have a basis.
+ * U = NULL: off.  The arrays are the caller's and live with the B block they were computed from. */
+int dmm_ctx_set_ml_basis(dmm_ctx* ctx, void* U, double* sigma, int32_t* rank, int64_t nslots, int rmax, int build);
 int64_t dmm_ml_gram_cache_slots(const dmm_plan* plan);
 int64_t dmm_ml_gram_cache_bytes(const dmm_plan* plan);
 /* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */

@@ -364,3 +364,76 @@ def test_resident_beam_gram_products_for_wiener_too():
     c1 = counter(b"ml_gram_cached")
     a2 = cached.make_alm(day2).cpu().numpy()
     assert counter(b"ml_gram_cached") == c1 and np.array_equal(a2, ref_o)
+
+
+@pytest.mark.parametrize("chan0", [0, 254])
+def test_resident_beam_bases_keep_the_same_modes_and_agree_with_the_oracle_svd(chan0):
+    """``cache_beam_basis``: with the singular basis ``B = U Sigma V^H`` of a telescope-side tile resident, the day's
+    pseudo-inverse (mapmaker.py:190-201, 287-300) is that of the r x r matrix ``Sigma U^H N^-1 U Sigma``.  Against the
+    full-order pass on the same structured tiles: the same modes kept on every tile, a_lm within the solver's resolution;
+    sampled tiles against the oracle's SVD; a second day (other weights) through the same resident bases."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.device import ptr
+
+    nfreq = 1
+    ctx, tel, bt, mm, mv, mw, per_f = _setup(nfreq, seed=17, chan0=chan0)
+    n_m = tel.lmax + 1
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    gen = torch.Generator(device=ctx.device).manual_seed(5)
+    v2 = torch.randn(mv.shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    w2 = (torch.rand(mw.shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5) * 20.0 * 1024
+    w2[torch.rand(mw.shape, dtype=torch.float64, device=ctx.device, generator=gen) < 0.02] = 0.0
+    day2 = containers.MModes(mmax=tel.lmax, freq=tel.frequencies, stack=tel.npairs, allocate=False)
+    day2.attach("vis", v2)
+    day2.attach("vis_weight", w2)
+
+    def run(task, day):
+        diag = torch.full((nfreq, n_m, 4), -1.0, dtype=torch.float64, device=ctx.device)
+        _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, ptr(diag)))
+        try:
+            alm = task.make_alm(day)
+            ctx.sync()
+        finally:
+            _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, None))
+        return alm.cpu().numpy(), diag.cpu().numpy()
+
+    pool = nfreq * per_f + (1 << 20)
+    plain = MaximumLikelihoodMapMaker(nside=64, pool_bytes=pool)
+    plain.setup(bt)
+    based = MaximumLikelihoodMapMaker(nside=64, pool_bytes=pool, cache_beam_basis=True)
+    based.setup(bt)
+    worst = 0.0
+    for day, vh, wh in ((mm, mv, mw), (day2, v2, w2)):
+        a_ref, d_ref = run(plain, day)
+        b0 = counter(b"ml_tiles_basis")
+        a_bs, d_bs = run(based, day)
+        n_bs = counter(b"ml_tiles_basis") - b0
+        dec = d_ref[..., 0] >= 0
+        n_tel_dec = int(dec[0, : sum(1 for m in range(n_m) if 4 * (n_m - m) >= 2 * tel.npairs)].sum())
+        assert n_bs >= 0.9 * n_tel_dec > 0, (n_bs, n_tel_dec)
+        assert np.array_equal(d_bs[..., 0], d_ref[..., 0])  # the same modes kept on every tile
+        scale = np.abs(a_ref).max()
+        assert np.abs(a_bs - a_ref).max() < 2e-8 * scale, np.abs(a_bs - a_ref).max() / scale
+        kept = dec & (d_ref[..., 0] > 0)
+        assert np.abs(d_bs[..., 2][kept] / d_ref[..., 2][kept] - 1.0).max() < 1e-8  # the smallest kept sigma of every tile
+        vh_h, wh_h = vh.cpu().numpy(), wh.cpu().numpy()
+        for m in (0, 15, 60, 113, 200, 280):
+            bm = bt.beam_m(m, fi=0)
+            ref = omm.ml_solve(bm, vh_h[m, :, 0], wh_h[m, :, 0])
+            rank_o, _ = omm.ml_spectrum(bm, wh_h[m, :, 0])
+            assert int(d_bs[0, m, 0]) == rank_o, (m, d_bs[0, m, 0], rank_o)
+            worst = max(worst, _rel(a_bs[0, :, m, :], ref))
+    assert based._engine.basis_builds == 1  # built once, used by both days
+    assert worst < 1e-7, worst
+    print("basis route against the oracle's SVD, worst over two days:", worst)
