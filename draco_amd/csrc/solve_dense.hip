@@ -1484,8 +1484,16 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   // one list of same-order matrices through the eigen path: pipelined tridiagonal chunks, or (few matrices, or the
   // Jacobi / full-matrix variants asked for) the synchronous batches above
   int chunk_no = 0;
-  auto eigen_list = [&](const std::vector<int64_t>& list, bool sky, int np_sky) -> int {
-    if (list.empty()) return DMM_OK;
+  auto eigen_list = [&](const std::vector<int64_t>& list_in, bool sky, int np_sky) -> int {
+    if (list_in.empty()) return DMM_OK;
+    // basis route: the chunks' small problems have the order of their LARGEST rank -- tiles of like rank share chunks
+    std::vector<int64_t> by_rank;
+    if (!sky && bs_use) {
+      by_rank = list_in;
+      auto rk = [&](int64_t t) { const int32_t sl = gslot_of[(size_t)t]; return sl >= 0 ? ctx->ml_bs_rank_h[(size_t)sl] : -1; };
+      std::stable_sort(by_rank.begin(), by_rank.end(), [&](int64_t a, int64_t b) { return rk(a) > rk(b); });
+    }
+    const std::vector<int64_t>& list = by_rank.empty() ? list_in : by_rank;
     const int np = ((sky ? np_sky : ntel) + TB - 1) / TB * TB;
     const int eig = ctx->opt_ml_eigen;
     const bool pipelined = capE >= 1 && (eig == 4 || eig == 3 || bs_build || (eig == 0 && (double)std::min<size_t>(capE, list.size()) * np >= 12000.0));
