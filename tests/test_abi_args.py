@@ -144,3 +144,12 @@ def test_round4_entries_check_their_arguments():
     _arg_error(lib.dmm_ctx_set_ml_diag(None, BUF), "ctx is NULL")
     _arg_error(lib.dmm_ctx_set_option(None, b"ml_null", 1), "NULL")
     assert _lib.DMM_E_COMM == -5
+
+
+def test_resident_product_entries_check_their_arguments():
+    """`dmm_ctx_set_ml_gram_cache`, `dmm_ctx_set_ml_basis` and their sizing functions: NULL handles and inconsistent
+    arrays are refused before anything is dereferenced; a NULL plan has no slots."""
+    lib = _lib.lib
+    _arg_error(lib.dmm_ctx_set_ml_gram_cache(None, BUF, BUF, 4, 0), "ctx is NULL")
+    _arg_error(lib.dmm_ctx_set_ml_basis(None, BUF, BUF, BUF, 4, 448, 0), "ctx is NULL")
+    assert lib.dmm_ml_gram_cache_slots(None) == 0 and lib.dmm_ml_gram_cache_bytes(None) == 0
