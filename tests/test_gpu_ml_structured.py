@@ -315,6 +315,21 @@ def test_resident_beam_gram_products_give_bit_identical_days():
     assert np.array_equal(a2, ref[2])
     a2b = cached.make_alm(days[2]).cpu().numpy()
     assert counter(b"ml_gram_cached") > c1 and np.array_equal(a2b, ref[2])
+    # D days from one pass over B (`make_alm_many`): the products computed for the first day of a group serve the others
+    _solve.release_pools()
+    c2 = counter(b"ml_gram_cached")
+    many = [a.cpu().numpy() for a in cached.make_alm_many(days)]
+    assert counter(b"ml_gram_cached") > c2
+    for a, r in zip(many, ref):
+        assert np.array_equal(a, r)
+    # ... and with the singular bases instead (`cache_beam_basis`): the solver's own resolution, not bit for bit
+    based = MaximumLikelihoodMapMaker(nside=64, pool_bytes=nfreq * per_f + (1 << 20), cache_beam_basis=True)
+    based.setup(bt)
+    b0 = counter(b"ml_tiles_basis")
+    many_b = [a.cpu().numpy() for a in based.make_alm_many(days)]
+    assert counter(b"ml_tiles_basis") > b0 and based._engine.basis_builds == 1
+    for a, r in zip(many_b, ref):
+        assert np.abs(a - r).max() < 2e-8 * np.abs(r).max()
 
 
 def test_resident_beam_gram_products_for_wiener_too():
