@@ -443,7 +443,7 @@ def test_resident_beam_bases_keep_the_same_modes_and_agree_with_the_oracle_svd(c
         kept = dec & (d_ref[..., 0] > 0)
         assert np.abs(d_bs[..., 2][kept] / d_ref[..., 2][kept] - 1.0).max() < 1e-8  # the smallest kept sigma of every tile
         vh_h, wh_h = vh.cpu().numpy(), wh.cpu().numpy()
-        for m in (0, 15, 60, 113, 200, 280):
+        for m in ((0, 15, 113, 280) if day is mm else (60, 200)):  # (the oracle's SVD of a 758 x 2052 tile takes seconds)
             bm = bt.beam_m(m, fi=0)
             ref = omm.ml_solve(bm, vh_h[m, :, 0], wh_h[m, :, 0])
             rank_o, _ = omm.ml_spectrum(bm, wh_h[m, :, 0])
