@@ -206,10 +206,11 @@ int dmm_ctx_set_ml_gram_cache(dmm_ctx* c, void* cache, int32_t* valid, int64_t n
   c->ml_gcache = (double2*)cache;
   c->ml_gvalid = cache ? valid : nullptr;
   c->ml_gslots = cache ? nslots : 0;
-  if (cache && (reset || (int64_t)c->ml_gvalid_h.size() != nslots)) {
-    DMM_HIP(hipMemsetAsync(valid, 0, (size_t)nslots * sizeof(int32_t), c->stream));
-    c->ml_gvalid_h.assign((size_t)nslots, 0);
-  }
+  if (cache && reset) DMM_HIP(hipMemsetAsync(valid, 0, (size_t)nslots * sizeof(int32_t), c->stream));
+  // the host's mirror of `valid` feeds the counters only (the kernels read the device flags): started over with every
+  // reset and whenever another cache is handed in
+  if (cache && (reset || cache != c->ml_gcache_last || (int64_t)c->ml_gvalid_h.size() != nslots)) c->ml_gvalid_h.assign((size_t)nslots, 0);
+  if (cache) c->ml_gcache_last = cache;
   return DMM_OK;
 }
 

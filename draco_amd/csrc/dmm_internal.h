@@ -75,6 +75,7 @@ struct dmm_ctx {
   double2* ml_gcache = nullptr;            // dmm_ctx_set_ml_gram_cache: resident B B^H of the telescope-side tiles (caller-owned), or nullptr
   int32_t* ml_gvalid = nullptr;            //   [ml_gslots] which slots hold a product
   int64_t ml_gslots = 0;
+  const void* ml_gcache_last = nullptr;    //   the cache the mirror below belongs to
   std::vector<char> ml_gvalid_h;           //   host mirror of `ml_gvalid` in launch order (bookkeeping of the flop counter only)
   int64_t ml_gram_cached = 0;              // counter: Gram matrices formed from a resident product
   double* ml_diag = nullptr;               // dmm_ctx_set_ml_diag: [nfreq][n_m][4] rank / sigma record of the eigen-decomposed ML tiles (validation)

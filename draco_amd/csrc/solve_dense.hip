@@ -778,8 +778,9 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
         p.gcache = ctx->ml_gcache;
         p.gslot = sd;
         p.gvalid = ctx->ml_gvalid;
-        if (fresh) hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S, p);
-        if (fresh < nmat) hipLaunchKernelGGL(k_gram_scale, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S, p);
+        (void)fresh;  // (both kernels always: the DEVICE flags decide, see dmm_ml_run)
+        hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S, p);
+        hipLaunchKernelGGL(k_gram_scale, dim3(T * (T + 1) / 2, nmat), dim3(kThreads), 0, S, p);
         hipLaunchKernelGGL(k_gram_mark, dim3((nmat + 255) / 256), dim3(256), 0, S, sd, ctx->ml_gvalid, nmat);
         for (int i = 0; i < nmat; ++i)
           if (sc[i] >= 0) ctx->ml_gvalid_h[(size_t)sc[i]] = 1;
@@ -1404,8 +1405,11 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         p.gcache = ctx->ml_gcache;
         p.gslot = slots_d;
         p.gvalid = ctx->ml_gvalid;
-        if (fresh) hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
-        if (fresh < nmat) hipLaunchKernelGGL(k_gram_scale, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+        // (both kernels always: which matrices each of them takes is decided by the DEVICE flags -- the host's mirror of
+        // them only feeds the counters, and may lag when a caller alternates between caches)
+        (void)fresh;
+        hipLaunchKernelGGL(k_nt<MODE_GRAM>, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
+        hipLaunchKernelGGL(k_gram_scale, dim3(p.T * (p.T + 1) / 2, nmat), dim3(kThreads), 0, S1, p);
         hipLaunchKernelGGL(k_gram_mark, dim3((nmat + 255) / 256), dim3(256), 0, S1, slots_d, ctx->ml_gvalid, nmat);
         for (int i = 0; i < nmat; ++i)
           if (H.slots[i] >= 0) ctx->ml_gvalid_h[(size_t)H.slots[i]] = 1;
