@@ -108,6 +108,8 @@ struct dmm_plan {
   int cols_per_block = 0;
   int pair_ok = 0;                   // packed complex64 rows are 16-byte aligned: 2 columns per lane
   int64_t b_bytes = 0;
+  std::vector<int16_t> ml_ne;        // dmm_ml_run: effective order of each tile's last decomposition (0: not known) -- a property
+                                     // of the tile's beam transfer far more than of the day: the next pass sorts its chunks by it
 };
 
 // ---- Buffer rule of the library's second stream (`aux_stream`).

@@ -130,7 +130,7 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   tp.j = K;
   panel();
 }
-void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0) {
+void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0, int cap_hint = 0) {
   // grid_cap > 0 ("ml_chase_grid"): at most that many blocks, each working through several matrices -- the chase keeps a
   // CU's whole LDS, so a capped grid confines it to that many CUs instead of letting it take every CU in turn
   const int grid = grid_cap > 0 && grid_cap < nmat ? grid_cap : nmat;
@@ -142,7 +142,9 @@ void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, 
   // its blocks start beside the next chunk's sweep / Gram blocks instead of waiting for a CU whose LDS is empty --; a
   // matrix above that goes through a second, small persistent launch with the full image.
   int cap = n;
-  if (tp.stop_tol > 0.0 && ctx->opt_ml_chase_split != 1) {
+  if (tp.stop_tol > 0.0 && ctx->opt_ml_chase_split != 1 && cap_hint > 0) {
+    cap = std::max(cap_hint, 128);  // the chunk's own tiles were decomposed before (dmm_plan::ml_ne): their largest order + 64
+  } else if (tp.stop_tol > 0.0 && ctx->opt_ml_chase_split != 1) {
     int64_t total = 0;
     int top = 0;
     for (int b = 0; b < 17; ++b) {
@@ -1303,6 +1305,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         ++ctx->ml_tiles_ql_failed;
       } else if (!bs_build) {  // the rank stop's effective order (0: none)
         count_stop(H.np, fl[k] >> 8);
+        if (!redo_is_sky[h] && !pl->ml_ne.empty()) pl->ml_ne[(size_t)H.ids[k]] = (int16_t)((fl[k] >> 8) ? (fl[k] >> 8) : H.np);
       }
     H.busy = false;
     return DMM_OK;
@@ -1465,7 +1468,18 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipStreamWaitEvent(S2, ctx->aux_ev[h], 0));
     if (tp.two_stage) {  // the chase is one wave per matrix, as latency bound as QL: it runs beside the next chunk's sweeps too
       dmm_prof_scope prof(ctx, DMM_PROF_CHASE, S2);
-      sb_chase(ctx, tp, nmat, S2, ctx->opt_ml_chase_grid);
+      int hint = 0;  // the chunk's largest known effective order + 64 columns, if every tile of it has one (full-order chunks)
+      if (!sky && nr == 0 && !pl->ml_ne.empty()) {
+        int mx = 0;
+        bool all = true;
+        for (int i = 0; i < nmat; ++i) {
+          const int v = pl->ml_ne[(size_t)list[i0 + i]];
+          all = all && v > 0;
+          mx = std::max(mx, v);
+        }
+        if (all) hint = (mx + TB - 1) / TB * TB + TB;
+      }
+      sb_chase(ctx, tp, nmat, S2, ctx->opt_ml_chase_grid, hint);
     }
     {
       dmm_prof_scope prof(ctx, DMM_PROF_QL, S2);
@@ -1496,6 +1510,18 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       by_rank = list_in;
       auto rk = [&](int64_t t) { const int32_t sl = gslot_of[(size_t)t]; return sl >= 0 ? ctx->ml_bs_rank_h[(size_t)sl] : -1; };
       std::stable_sort(by_rank.begin(), by_rank.end(), [&](int64_t a, int64_t b) { return rk(a) > rk(b); });
+    }
+    // full-order path: by the effective order of the tiles' last decomposition, where the plan knows it (dmm_plan::ml_ne) --
+    // chunks of like rank end their stage 1 together, and their bulge chase gets an LDS image sized for the chunk
+    if (!sky && !bs_use && !bs_build && ctx->opt_ml_chase_split != 1) {
+      if (pl->ml_ne.empty()) pl->ml_ne.assign((size_t)pl->ntile, 0);
+      size_t known = 0;
+      for (int64_t t : list_in) known += pl->ml_ne[(size_t)t] > 0;
+      if (known * 10 >= list_in.size() * 9) {
+        by_rank = list_in;
+        auto rk = [&](int64_t t) { const int v = pl->ml_ne[(size_t)t]; return v > 0 ? v : 32767; };
+        std::stable_sort(by_rank.begin(), by_rank.end(), [&](int64_t a, int64_t b) { return rk(a) > rk(b); });
+      }
     }
     const std::vector<int64_t>& list = by_rank.empty() ? list_in : by_rank;
     const int np = ((sky ? np_sky : ntel) + TB - 1) / TB * TB;
