@@ -141,8 +141,7 @@ def test_cfg3_ml_batched_pass_on_structured_tiles_against_the_oracle_svd(name, s
     for f, m in sample:
         bm = bt.beam_m(m, fi=f)
         v, Ni = mv_h[m, :, f], mw_h[m, :, f]
-        ref = omm.ml_solve(bm, v, Ni)
-        rank_o, sig = omm.ml_spectrum(bm, Ni)
+        ref, rank_o, sig = omm.ml_solve_with_spectrum(bm, v, Ni)  # (one SVD for both)
         cut_o = max(RCOND * sig[0], ACOND)
         gap_o = float(min(sig[rank_o - 1] / cut_o - 1.0 if rank_o > 0 else np.inf, 1.0 - (sig[rank_o] / cut_o if rank_o < len(sig) else 0.0)))
         err = _rel(alm[f, :, m, :], ref)
@@ -445,8 +444,7 @@ def test_resident_beam_bases_keep_the_same_modes_and_agree_with_the_oracle_svd(c
         vh_h, wh_h = vh.cpu().numpy(), wh.cpu().numpy()
         for m in ((0, 15, 113, 280) if day is mm else (60, 200)):  # (the oracle's SVD of a 758 x 2052 tile takes seconds)
             bm = bt.beam_m(m, fi=0)
-            ref = omm.ml_solve(bm, vh_h[m, :, 0], wh_h[m, :, 0])
-            rank_o, _ = omm.ml_spectrum(bm, wh_h[m, :, 0])
+            ref, rank_o, _ = omm.ml_solve_with_spectrum(bm, vh_h[m, :, 0], wh_h[m, :, 0])
             assert int(d_bs[0, m, 0]) == rank_o, (m, d_bs[0, m, 0], rank_o)
             worst = max(worst, _rel(a_bs[0, :, m, :], ref))
     assert based._engine.basis_builds == 1  # built once, used by both days

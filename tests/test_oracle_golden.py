@@ -116,6 +116,12 @@ def test_solve_m(golden_dir):
     assert n == 18
     for i in range(n):
         bm, m, v, Ni = g[f"c{i}_bm"], int(g[f"c{i}_m"]), g[f"c{i}_v"], g[f"c{i}_Ni"]
+        # the one-decomposition helper of the GPU tests IS ml_solve + ml_spectrum
+        a1, r1, s1 = omm.ml_solve_with_spectrum(bm, v, Ni)
+        r0, s0 = omm.ml_spectrum(bm, Ni)
+        np.testing.assert_array_equal(a1, omm.ml_solve(bm, v, Ni))
+        assert r1 == r0
+        np.testing.assert_allclose(s1, s0, rtol=1e-12, atol=1e-14 * s0.max())
         for name, got in (
             ("dirty", omm.dirty_solve(bm, v, Ni)),
             ("ml", omm.ml_solve(bm, v, Ni)),
