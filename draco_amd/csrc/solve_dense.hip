@@ -1370,6 +1370,10 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       }
       nr = std::max((rmx + TB - 1) / TB * TB, 2 * TB);
       if (!all || nr + 128 > n || !sb_usable(ctx, nr)) nr = 0;
+      // X (nr x ntel) sits in the second half of the matrix's log region, the T factors and the chase's reflector log
+      // of the order-nr reduction at the region's tail: the route is taken only where the two do not meet (otherwise the
+      // full-order path; ADVICE r4: Np 576 at nr 448, Np 768 at nr >= 576, Np 1024 at nr >= 768 would overlap)
+      if (nr > 0 && (int64_t)L.Np * L.Np + (int64_t)nr * ntel + sb_tail(nr) > (int64_t)2 * L.Np * L.Np) nr = 0;
     }
     if (nr > 0) {
       dmm_prof_scope prof(ctx, DMM_PROF_GRAM, S1);
