@@ -234,7 +234,29 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   lp.m_identity = (ctx->opt_sht_variant & 32) ? 1 : 0;
   if (NPOL == 4 && !(ctx->opt_sht_variant & 8)) {  // bit 3: force the vector-ALU kernel
     const int npair = (g.nring + 1) / 2;
-    hipLaunchKernelGGL(k_leg_synth_mfma, dim3(g.mmax + 1, (npair + kThreads - 1) / kThreads, (nf + kLegF - 1) / kLegF), dim3(kThreads), 0, ctx->stream, lp);
+    const int nrc = (npair + kThreads - 1) / kThreads;
+#ifdef LEG_STAMPS  // diagnostic build (-DLEG_STAMPS): every wave of the synthesis kernel leaves its phase clocks
+    static unsigned long long* stamps_d = nullptr;
+    const size_t nst = (size_t)(g.mmax + 1) * nrc * ((nf + 2 * kLegF - 1) / (2 * kLegF)) * 4 * 8;
+    if (!stamps_d) (void)hipMalloc((void**)&stamps_d, 64 << 20);
+    (void)hipMemsetAsync(stamps_d, 0, nst * 8, ctx->stream);
+    lp.stamps = stamps_d;
+#endif
+    if (ctx->opt_sht_variant & 64)  // bit 6: the first MFMA form (rounds 1-4), the A/B of the pipelined one
+      hipLaunchKernelGGL(k_leg_synth_mfma, dim3(g.mmax + 1, nrc, (nf + kLegF - 1) / kLegF), dim3(kThreads), 0, ctx->stream, lp);
+    else if (ctx->opt_sht_variant & 128)  // bit 7: one frequency group per block, two waves per SIMD
+      hipLaunchKernelGGL(k_leg_synth_mfma2<1>, dim3(g.mmax + 1, nrc, (nf + kLegF - 1) / kLegF), dim3(kThreads), 0, ctx->stream, lp);
+    else
+      hipLaunchKernelGGL(k_leg_synth_mfma2<2>, dim3(g.mmax + 1, nrc, (nf + 2 * kLegF - 1) / (2 * kLegF)), dim3(kThreads), 0, ctx->stream, lp);
+#ifdef LEG_STAMPS
+    {
+      std::vector<unsigned long long> h(nst);
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipMemcpy(h.data(), stamps_d, nst * 8, hipMemcpyDeviceToHost);
+      FILE* fo = fopen("gpurun_out/leg_blocks.bin", "wb");
+      if (fo) { fwrite(h.data(), 8, nst, fo); fclose(fo); }
+    }
+#endif
   } else
   switch (ctx->opt_sht_variant & 3) {
     case 1: hipLaunchKernelGGL((k_leg_synth<NPOL, 1, 1>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;

@@ -48,6 +48,9 @@ struct LegParams {
   const double2* alm;     // [nf, npol, n_m, lmax+1]
   double2* b;             // [nf, npol, nring, mmax+1]
   int m_identity;         // 1: block b takes m = b (sht_variant bit 5, the A/B of leg_m_of_block)
+#ifdef LEG_STAMPS
+  unsigned long long* stamps;  // diagnostic build only
+#endif
 };
 
 // LDS image of one (f, m): coefficient rows + npol a_lm columns

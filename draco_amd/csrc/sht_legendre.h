@@ -315,6 +315,311 @@ __global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) {
     }
 }
 
+// ---- synthesis on the matrix cores, second form (round 5; default, `sht_variant` bit 6 restores the one above).
+// What the counters and in-kernel stamps of the first form say (profiles/r01_sht_cfg3_pmc.txt, profiles/r05_sht_*): 17 vector
+// instructions per MFMA, the matrix pipe busy 0.30 of the kernel -- and on this part an f64 VALU operation runs on the SAME
+// double-precision pipe as the f64 MFMA (profiles/r01_mfma_f64_probe.txt: 4 cycles each, never hidden, with one wave or four
+// per SIMD), so every f64 operation of the recurrence is matrix-pipe time, everything else is issue slots, and a second
+// wave per SIMD overlaps next to nothing (measured: the same kernel time with one wave per SIMD and twice the products per
+// wave).  Here
+//  * a block owns NFG = 2 frequency groups (8 frequencies, 512 registers, one wave per SIMD): the recurrence, the operand
+//    formation and every load of a chunk serve 48 products instead of 24;
+//  * the recurrence lane (one ring pair) computes lambda ONLY (3 f64 operations per l) and parks it in a DOUBLE-BUFFERED
+//    wave-private slab; F1 / F2 are formed where the MFMA A operands are built -- from lambda_l, lambda_{l-1} of the slab,
+//    the lane's own two l (coefficient rows fetched by vector loads a chunk ahead) and its ring's 1/sin^2, x/sin^2;
+//    the per-l broadcasts shrink from 14 v_readlane to 4 (ra, rb);
+//  * the recurrence of chunk c + 1 is interleaved, step by step, with the products of chunk c (other buffer), and the LDS
+//    reads of a group's operands are issued BEFORE the previous group's products, so their round trip runs under them;
+//  * ring tiles go round robin over the waves of all blocks of an (m, frequency group) and a tile none of whose rings has
+//    reached the scale of its values is skipped (wave-uniform): no operands, no products;
+//  * the loads of a chunk use one uniform base and 32-bit lane offsets; signs and the zeros beyond lmax are applied to the
+//    B values once per chunk, the masks only where a chunk is ragged.
+// Same products, same summation order per accumulator as the first form; lambda_{l-1} of the step at which a ring's scale
+// reaches 1 is read as 0 (it is < 2^-60 of the ring's values there), as the analysis kernel has always done.
+constexpr int kLeg2Rows = kLegL + 1;  // row 0: lambda of the step before the chunk
+#ifndef PIPE_HINT
+#define PIPE_HINT 1
+#endif
+
+template <int NFG>
+__global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2(LegParams p) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  __shared__ double slab[kThreads / 64][2][kLeg2Rows][kLegPitch];
+  __shared__ double ringf[kThreads / 64][2][64];
+  const int m = leg_m_of_block(blockIdx.x, p.g.mmax + 1, p.m_identity), rc = blockIdx.y, f0 = blockIdx.z * (kLegF * NFG);
+  const int lmax = p.g.lmax, nl = lmax - m + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nring = p.g.nring, npair = (nring + 1) / 2;
+  const int64_t mstride = p.g.mmax + 1;
+  double(*sl)[kLeg2Rows][kLegPitch] = slab[wave];
+#ifdef LEG_STAMPS
+  unsigned long long st[6];
+  auto stamp = [&](int i) {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    st[i] = t;
+  };
+  stamp(0);
+#define LEG_STAMP(i) stamp(i)
+#else
+#define LEG_STAMP(i)
+#endif
+
+  // Ring tiles (16 consecutive ring pairs) go round robin over the waves of ALL the blocks of this (m, frequency group):
+  // wave W = 4 rc + wave owns the tiles W, W + NW, W + 2 NW, W + 3 NW, so every wave holds polar and equatorial rings alike
+  const int NW = gridDim.y * (kThreads / 64), W = rc * (kThreads / 64) + wave;
+  // generation state of this thread's ring pair
+  const int r = 16 * (W + (lane >> 4) * NW) + (lane & 15);
+  double x = 0.0, lam = 0.0, lam_prev = 0.0;
+  int nsc = -1;
+  {
+    double inv_s2 = 0.0, xs2 = 0.0;
+    if (r < npair) {
+      const double sth = p.g.sth[r];
+      x = p.g.z[r];
+      inv_s2 = 1.0 / (sth * sth);
+      xs2 = x * inv_s2;
+      if (!ring_skips_m(m, lmax, sth)) lam_start(p.g.lfac[m], m, sth, lam, nsc);
+    }
+    ringf[wave][0][lane] = xs2;
+    ringf[wave][1][lane] = inv_s2;
+  }
+  const bool wave_live = __any(nsc >= 0);
+
+  // MFMA operand coordinates of this lane
+  const int li = lane & 15, kq = lane >> 4;
+  const int col = li, fi = col >> 2, c = col & 3;
+  int fq[NFG];
+  bool fok[NFG];
+#pragma unroll
+  for (int h = 0; h < NFG; ++h) {
+    fq[h] = f0 + kLegF * h + fi;
+    fok[h] = fq[h] < p.nf;
+  }
+
+  v4d acc[NFG][4][4];  // [frequency group][ring tile][TV sym, TV anti, QU sym, QU anti]
+#pragma unroll
+  for (int h = 0; h < NFG; ++h)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[h][t][q] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  if (wave_live) {
+    // One uniform base per table and 32-bit lane offsets (bytes): a_lm of (f0, pol 0, m, l = m) + the lane's three columns
+    // (a frequency beyond nf reads the last valid one: its columns are computed and never stored)
+    const char* abase = reinterpret_cast<const char*>(p.alm + (((int64_t)f0 * 4) * p.n_m + m) * (lmax + 1) + m);
+    const char* cbase = reinterpret_cast<const char*>(p.g.coef) + 64 * coef_row0(m, lmax);
+    unsigned oTV[NFG], o1[NFG], o2[NFG];
+#pragma unroll
+    for (int h = 0; h < NFG; ++h) {
+      const int fr = (fok[h] ? fq[h] : p.nf - 1) - f0;
+      auto colofs = [&](int pol, int comp) { return (unsigned)((((int64_t)fr * 4 + pol) * p.n_m * (lmax + 1)) * 16 + comp * 8); };
+      oTV[h] = colofs(c < 2 ? 0 : 3, c & 1);
+      o1[h] = colofs(c < 2 ? 1 : 2, c & 1);
+      o2[h] = colofs(c < 2 ? 2 : 1, (c & 1) ^ 1);
+    }
+    const unsigned s2x = (c == 0 || c == 3) ? 0u : 0x80000000u;  // sign of the F2 data column: xor on the high word
+    const int nchunk = (nl + kLegL - 1) / kLegL;
+    auto fetch_rr = [&](int c0) {  // (ra, rb) of a chunk's 8 rows: lanes 0..15, one double each
+      const int row = c0 + ((lane >> 1) & 7);
+      return *reinterpret_cast<const double*>(cbase + 64u * (unsigned)(row < nl ? row : nl - 1) + 8u * (lane & 1));
+    };
+    auto bcast = [&](double v, int src) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+      return __hiloint2double(hi, lo);
+    };
+    // operands of the MFMA lanes for one chunk: the spin-2 factors of this lane's two l and its B values
+    struct LaneOps {
+      double2 c12[2], cd3[2];
+      double c4[2], rTV[NFG][2], r1[NFG][2], r2[NFG][2];
+    };
+    auto fetch_ops = [&](int c0, bool ragged) {
+      LaneOps o;
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int k = c0 + 2 * kq + par;
+        const unsigned kc = (unsigned)(ragged && k >= nl ? nl - 1 : k);
+        const char* cr = cbase + 64u * kc;
+        o.c12[par] = *reinterpret_cast<const double2*>(cr + 16);
+        o.cd3[par] = *reinterpret_cast<const double2*>(cr + 32);
+        o.c4[par] = *reinterpret_cast<const double*>(cr + 48);
+#pragma unroll
+        for (int h = 0; h < NFG; ++h) {
+          o.rTV[h][par] = *reinterpret_cast<const double*>(abase + (oTV[h] + 16u * kc));
+          o.r1[h][par] = *reinterpret_cast<const double*>(abase + (o1[h] + 16u * kc));
+          o.r2[h][par] = *reinterpret_cast<const double*>(abase + (o2[h] + 16u * kc));
+        }
+      }
+      return o;
+    };
+    // a chunk's B values in their final form: the sign of the F2 column (the minus of the F1 column is carried by the A
+    // operand), and -- only where the chunk is ragged -- zeros beyond lmax
+    auto finish_ops = [&](LaneOps& o, int c0, bool ragged) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int h = 0; h < NFG; ++h) {
+          o.r2[h][par] = __hiloint2double(__double2hiint(o.r2[h][par]) ^ (int)s2x, __double2loint(o.r2[h][par]));
+          if (ragged && c0 + 2 * kq + par >= nl) o.rTV[h][par] = o.r1[h][par] = o.r2[h][par] = 0.0;
+        }
+    };
+    double le_prev = 0.0;
+    // one step of the recurrence of a chunk -> row kk + 1 of buffer nb.  PEND: some lane of the wave still carries 2^-800
+    // blocks (wave-uniform, decided per chunk): the rescale test and the mask of the parked value, written WITHOUT branches
+    // -- the chunk body is one scheduling region, so that the compiler can place its non-f64 instructions under the MFMAs
+    auto rec_step = [&](int nb, int kk, double cvr, bool first, bool PEND) {
+      const double ra = bcast(cvr, 2 * kk), rb = bcast(cvr, 2 * kk + 1);
+      // (no lane mask: a ring that takes no part carries lam = lam_prev = 0 and stays there; steps beyond lmax run on the
+      // last coefficient row and stay finite -- their B operands are zero)
+      if (!(first && kk == 0)) {
+        const double nxt = x * lam * ra - lam_prev * rb;
+        lam_prev = lam;
+        lam = nxt;
+      }
+      double le = lam;
+      if (PEND) {
+        const bool big = nsc > 0 && fabs(lam) > kBig;
+        const double sc = __hiloint2double(big ? __double2hiint(kSmallStep) : 0x3ff00000, 0);  // 2^-800 or 1
+        lam *= sc;
+        lam_prev *= sc;
+        nsc -= big ? 1 : 0;
+        le = nsc == 0 ? lam : 0.0;
+      }
+      sl[nb][kk + 1][lane] = le;
+      le_prev = le;
+    };
+    // A operands of ring tile t, parity par of the chunk in buffer b, prepared ONE GROUP AHEAD of the products that take
+    // them.  The f64 MFMA and the f64 VALU operations share one pipe: what can run UNDER a group's products is everything
+    // that is not f64 arithmetic -- so the LDS reads of the next group's operands go out BEFORE the products (their round
+    // trip is over when the pipe is free again); the recurrence step and the eight operations that build the operands follow.
+    double pl1 = 0.0, pa1 = 0.0, pa2 = 0.0, ql0 = 0.0, ql1 = 0.0, qfx = 0.0, qfs = 0.0;
+    auto prep_load = [&](int b, int t, int par) {
+      ql0 = sl[b][2 * kq + par][16 * t + li];
+      ql1 = sl[b][2 * kq + par + 1][16 * t + li];
+      qfx = ringf[wave][0][16 * t + li];  // x / sin^2, 1 / sin^2 of the lane's ring
+      qfs = ringf[wave][1][16 * t + li];
+    };
+    auto prep_build = [&](int par, const LaneOps& o) {
+      pl1 = ql1;
+      // (-F1, F2): the F1 data column enters with a minus
+      pa1 = fma(fma(o.c12[par].x, qfs, o.c12[par].y), ql1, -(o.cd3[par].x * qfx * ql0));
+      pa2 = fma(o.c4[par] * qfs, ql0, -(o.cd3[par].y * qfx * ql1));
+    };
+    auto issue = [&](int t, int par, const LaneOps& o) {
+#pragma unroll
+      for (int h = 0; h < NFG; ++h) {
+        acc[h][t][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(pl1, o.rTV[h][par], acc[h][t][par], 0, 0, 0);
+        acc[h][t][2 + par] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1, o.r1[h][par], acc[h][t][2 + par], 0, 0, 0);
+        acc[h][t][3 - par] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa2, o.r2[h][par], acc[h][t][3 - par], 0, 0, 0);
+      }
+    };
+    // the pipeline of one group, for the scheduler: every MFMA followed by a share of the group's other instructions
+    auto pipeline = [&]() {
+#pragma unroll
+      for (int i = 0; i < 3 * NFG; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // a DS read
+        __builtin_amdgcn_sched_group_barrier(0x002, NFG == 2 ? 6 : 12, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // a DS write
+      }
+    };
+
+    LEG_STAMP(1);
+    // prologue: chunk 0 into buffer 0
+    double cvr = fetch_rr(0);
+    double cvr_next = fetch_rr(kLegL < nl ? kLegL : 0);
+    LaneOps ops = fetch_ops(0, nchunk == 1);
+    sl[0][0][lane] = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < kLegL; ++kk) rec_step(0, kk, cvr, true, true);
+    cvr = cvr_next;
+    finish_ops(ops, 0, nchunk == 1);
+    prep_load(0, 0, 0);
+    // chunks 0 .. nchunk - 2: products of chunk ch (buffer ch & 1) beside the recurrence of chunk ch + 1
+    auto body = [&](int ch, bool PEND) __attribute__((always_inline)) {
+      const int b = ch & 1, nb = b ^ 1, c0n = (ch + 1) * kLegL;
+      const bool ragged = c0n + kLegL > nl;  // (only the last chunk can be)
+      cvr_next = fetch_rr(c0n + kLegL < nl ? c0n + kLegL : c0n);
+      LaneOps ops_next = fetch_ops(c0n, ragged);
+      sl[nb][0][lane] = le_prev;
+      prep_build(0, ops);
+#pragma unroll
+      for (int g = 0; g < kLegL; ++g) {
+        if (g + 1 < kLegL) prep_load(b, (g + 1) & 3, (g + 1) >> 2);
+        issue(g & 3, g >> 2, ops);
+        rec_step(nb, g, cvr, false, PEND);
+        if (g + 1 < kLegL) prep_build((g + 1) >> 2, ops);
+        if (PIPE_HINT) pipeline();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      prep_load(nb, 0, 0);
+      cvr = cvr_next;
+      finish_ops(ops_next, c0n, ragged);
+      ops = ops_next;
+    };
+    LEG_STAMP(2);
+    // (two loops, not a branch inside one: lanes only ever leave the pending state)
+    int ch = 0;
+    for (; ch + 1 < nchunk && __any(nsc > 0); ++ch) body(ch, true);
+    LEG_STAMP(3);
+    for (; ch + 1 < nchunk; ++ch) body(ch, false);
+    // last chunk: products only
+    {
+      const int b = ch & 1;
+      prep_build(0, ops);
+#pragma unroll
+      for (int g = 0; g < kLegL; ++g) {
+        if (g + 1 < kLegL) prep_load(b, (g + 1) & 3, (g + 1) >> 2);
+        issue(g & 3, g >> 2, ops);
+        if (g + 1 < kLegL) prep_build((g + 1) >> 2, ops);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  LEG_STAMP(4);
+  // ring coefficients: north = sym + anti, south = sym - anti; D rows = rings (kq + 4 reg), D columns = this lane's column
+  // (the Q | U accumulators hold MINUS the F1 terms' sign convention of the first form folded into the A operand: same sums)
+  double* bout = reinterpret_cast<double*>(p.b);
+  const int comp = c & 1;
+#pragma unroll
+  for (int h = 0; h < NFG; ++h) {
+    if (!fok[h]) continue;
+    const int f = fq[h];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int rr = 16 * (W + t * NW) + kq + 4 * reg;
+        if (rr >= npair) continue;
+        const int rs = nring - 1 - rr;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {  // g = 0: (T | V), g = 1: (Q | U)
+          const int pol = g == 0 ? (c < 2 ? 0 : 3) : (c < 2 ? 1 : 2);
+          const double sy = acc[h][t][2 * g][reg], an = acc[h][t][2 * g + 1][reg];
+          bout[((((int64_t)f * 4 + pol) * nring + rr) * mstride + m) * 2 + comp] = sy + an;
+          if (rs != rr) bout[((((int64_t)f * 4 + pol) * nring + rs) * mstride + m) * 2 + comp] = sy - an;
+        }
+      }
+  }
+#ifdef LEG_STAMPS
+  stamp(5);
+  if (p.stamps && lane == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* o = p.stamps + 8 * ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave);
+    for (int i = 0; i < 6; ++i) o[i] = wave_live ? st[i] : (i == 0 || i == 5 ? st[i] : st[0]);
+    o[6] = ((unsigned long long)xcc << 32) | hw;
+    o[7] = m;
+  }
+#endif
+}
+
 // ---------------------------------------------------------------- analysis, stage 2'
 struct LegAnalParams {
   ShtGeom g;

@@ -72,7 +72,7 @@ int dmm_ctx_set_stream(dmm_ctx* ctx, void* hip_stream);
 int dmm_ctx_sync(dmm_ctx* ctx);
 /* tuning knobs (performance only, never results): "dirty_variant" (0 = default), "grid_mult",
  * "project_variant", "project_grid_mult", "ml_inner_sweeps", "ml_outer_sweeps", "sht_variant",
- * (sht_variant: bits 0-1 synthesis form, bit 2 direct ring sums, bit 3 vector-ALU Legendre kernels, bit 4 the 8-wave analysis block, bit 5 m = blockIdx.x instead of the XCD-aware block -> m map),
+ * (sht_variant: bits 0-1 synthesis form, bit 2 direct ring sums, bit 3 vector-ALU Legendre kernels, bit 4 the 8-wave analysis block, bit 5 m = blockIdx.x instead of the XCD-aware block -> m map, bit 6 the first MFMA synthesis kernel (rounds 1-4) instead of the pipelined one, bit 7 the pipelined one with 4 instead of 8 frequencies per block),
  * "ml_shortcut" (0 = on; 2 = always eigen-decompose; 3 = telescope-side systems only),
  * "ml_eigen" (eigen path of the ML solve: 0 = chosen by batch size; 4 = Householder tridiagonalisation + QL kept
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give

@@ -450,3 +450,75 @@ def test_resident_beam_bases_keep_the_same_modes_and_agree_with_the_oracle_svd(c
     assert based._engine.basis_builds == 1  # built once, used by both days
     assert worst < 1e-7, worst
     print("basis route against the oracle's SVD, worst over two days:", worst)
+
+
+def test_resident_beam_bases_small_telescope_where_the_basis_would_meet_the_reduction_tail():
+    """on the basis route ``X = Sigma U^H D`` (nr x ntel) sits in the second half of a matrix's log region
+    and the order-nr reduction keeps its T factors and reflector log at that region's tail; for a telescope of padded order
+    576 (ntel 513..576) the two would overlap from nr = 448 on -- the default ``basis_rmax``.  A 2 x 24-feed telescope
+    (ntel = 566) whose ranks reach ~400 at the top of the band: the chunks whose largest rank lies above 384 must take the
+    full-order path (``solve_dense.hip``: the fit check), every tile keeps the modes of the plain pass, a_lm agrees, and the
+    tiles of highest rank agree with the oracle's SVD."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import BeamScreenProvider, TransitTelescope
+    from draco_amd.device import Context, ptr
+
+    ctx = Context.get()
+    lmax = 512
+    tel = TransitTelescope(np.array([798.0]), lmax=lmax, ncyl=2, nfeed_cyl=24)
+    assert 513 <= 2 * tel.npairs <= 576
+    bt = BeamScreenProvider(tel, seed=3003, feed_sep=1.0, sigma_n=1.2)
+    gen = torch.Generator(device=ctx.device).manual_seed(23)
+    shape = (lmax + 1, 2, 1, tel.npairs)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = (torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5) * 20.0 * 1024
+    mw[torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) < 0.02] = 0.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs, allocate=False)
+    mm.attach("vis", mv)
+    mm.attach("vis_weight", mw)
+    per_f = sum(2 * tel.npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * 16
+
+    def counter(name):
+        v = C.c_int64()
+        _lib.check(_lib.lib.dmm_ctx_get_counter(ctx.handle, name, C.byref(v)))
+        return int(v.value)
+
+    def run(task):
+        diag = torch.full((1, lmax + 1, 4), -1.0, dtype=torch.float64, device=ctx.device)
+        _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, ptr(diag)))
+        try:
+            alm = task.make_alm(mm)
+            ctx.sync()
+        finally:
+            _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, None))
+        return alm.cpu().numpy(), diag.cpu().numpy()
+
+    plain = MaximumLikelihoodMapMaker(nside=64, pool_bytes=per_f + (1 << 20))
+    plain.setup(bt)
+    a_ref, d_ref = run(plain)
+    ranks = d_ref[0, :, 0]
+    assert ranks.max() > 384, ranks.max()  # the regime the finding is about: a chunk whose basis order would be 448
+    based = MaximumLikelihoodMapMaker(nside=64, pool_bytes=per_f + (1 << 20), cache_beam_basis=True)
+    based.setup(bt)
+    assert based._get_engine().basis_rmax == 448
+    run(based)  # (builds the bases)
+    b0 = counter(b"ml_tiles_basis")
+    a_bs, d_bs = run(based)
+    n_bs = counter(b"ml_tiles_basis") - b0
+    n_tel = sum(1 for m in range(lmax + 1) if 4 * (lmax + 1 - m) >= 2 * tel.npairs and ranks[m] >= 0)
+    assert 0 < n_bs < n_tel, (n_bs, n_tel)  # some chunks on the basis route, the high-rank ones on the full-order path
+    assert np.array_equal(d_bs[..., 0], d_ref[..., 0])
+    scale = np.abs(a_ref).max()
+    assert np.abs(a_bs - a_ref).max() < 2e-8 * scale, np.abs(a_bs - a_ref).max() / scale
+    vh, wh = mv.cpu().numpy(), mw.cpu().numpy()
+    top = [int(i) for i in np.argsort(ranks)[-2:]] + [int(np.argmin(np.abs(ranks - 380)))]
+    for m in top:
+        ref, rank_o, _ = omm.ml_solve_with_spectrum(bt.beam_m(m, fi=0), vh[m, :, 0], wh[m, :, 0])
+        assert int(d_bs[0, m, 0]) == rank_o, (m, d_bs[0, m, 0], rank_o)
+        assert _rel(a_bs[0, :, m, :], ref) < 1e-7, (m, _rel(a_bs[0, :, m, :], ref))

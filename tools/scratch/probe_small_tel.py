@@ -9,7 +9,7 @@ from draco_amd.core.products import BeamScreenProvider, TransitTelescope
 from draco_amd.device import Context, ptr
 ctx = Context.get()
 out = {}
-for name, freq, lmax, kw in (("a", 798.0, 512, {}), ("b", 798.0, 512, {"feed_sep": 0.6}), ("c", 798.0, 512, {"feed_sep": 0.6, "cyl_sep": 44.0}), ("d", 798.0, 384, {"feed_sep": 0.9, "cyl_sep": 44.0})):
+for name, freq, lmax, kw in (("e", 798.0, 512, {"feed_sep": 0.8}), ("f", 798.0, 512, {"feed_sep": 1.0}), ("g", 798.0, 512, {"feed_sep": 1.3}), ("h", 798.0, 512, {"feed_sep": 1.0, "sigma_n": 1.2})):
     tel = TransitTelescope(np.array([freq]), lmax=lmax, ncyl=2, nfeed_cyl=24)
     bt = BeamScreenProvider(tel, seed=3003, **kw)
     gen = torch.Generator(device=ctx.device).manual_seed(3)
