@@ -315,12 +315,31 @@ class SolveEngine:
                 buf.last_use = torch.cuda.Event()
                 buf.last_use.record(main)
 
-    def _basis_on(self, slab, mvis_d, mweight_d, params, ws, alm):
+    #: largest ratio of a day's non-zero noise weights for which the resident bases are used (they are truncated at 1e-15
+    #: of lambda_max of the UNWEIGHTED B B^H: the dropped modes enter the day's Gram matrix at up to 1e-15 ratio^2 of its
+    #: lambda_max, and pinv_svd cuts at 1e-6 -- ADVICE r4); beyond it the day takes the full-order path
+    basis_max_weight_ratio = 1e6
+
+    def _basis_weights_ok(self, weights):
+        """One reduction and one host read per CALL of solve / solve_many (not per slab): the verdict is remembered for
+        the weight arrays it was taken on."""
+        key = tuple((int(w.data_ptr()), int(w._version), tuple(w.shape)) for w in weights)
+        if getattr(self, "_basis_wkey", None) != key:
+            hi = max(float(w.max()) for w in weights)
+            lo = min(float(torch.where(w > 0, w, torch.full_like(w, float("inf"))).min()) for w in weights)
+            # (D = sqrt(w): (d_max / d_min)^2 = w_max / w_min -> dropped modes at <= 1e-15 * 1e6 = 1e-9 of lambda_max)
+            self._basis_wok = bool(hi <= 0 or lo == float("inf") or hi / lo <= self.basis_max_weight_ratio)
+            self._basis_wkey = key
+        return self._basis_wok
+
+    def _basis_on(self, slab, mvis_d, mweight_d, params, ws, alm, weights=None):
         """Hand the library the resident singular bases of the slab's buffer (``basis_cache``), building them first -- one
         decomposition of B B^H per telescope-side tile, with unit weights -- when the buffer holds other tiles than the
-        ones they were computed from."""
+        ones they were computed from.  Not for days whose weights span too many decades (``basis_max_weight_ratio``)."""
         buf = getattr(slab, "buf", None)
         if not self.basis_cache or buf is None or buf.content is None:
+            return False
+        if not self._basis_weights_ok(weights if weights is not None else [mweight_d]):
             return False
         lib = _lib.lib
         nslots = int(lib.dmm_ml_gram_cache_slots(slab.plan))
@@ -499,7 +518,7 @@ class SolveEngine:
             elif kind == "ml":
                 self._offer_workspace(b"ml_workspace_mib", 64 << 10)
                 ws = self._workspace(int(lib.dmm_ml_workspace_bytes(slab.plan)))
-                based = self._basis_on(slab, mvis_l[0], mweight_l[0], params, ws, alms[0])
+                based = self._basis_on(slab, mvis_l[0], mweight_l[0], params, ws, alms[0], weights=mweight_l)
                 cached = self._gram_cache_on(slab)
                 try:
                     for d in range(D):

@@ -57,6 +57,45 @@ hipError_t dmm_ticket(dmm_ctx* ctx, unsigned long long** out) {
   return hipSuccess;
 }
 
+int dmm_make_cu_stream(dmm_ctx* ctx, hipStream_t* st, bool side, int K) {
+  if (K < 2) {
+    DMM_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    return DMM_OK;
+  }
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 256; ++i)
+    if (((i % K) == 0) == side) mask[i >> 5] |= 1u << (i & 31);
+  DMM_HIP(hipExtStreamCreateWithCUMask(st, 8, mask));
+  return DMM_OK;
+}
+
+int dmm_cu_scope::enter(int K) {
+  if (K < 2) return DMM_OK;
+  if (c->cu_main && c->cu_main_every != K) {
+    DMM_HIP(hipStreamSynchronize(c->cu_main));
+    DMM_HIP(hipStreamDestroy(c->cu_main));
+    c->cu_main = nullptr;
+  }
+  if (!c->cu_main) {
+    int rc = dmm_make_cu_stream(c, &c->cu_main, false, K);
+    if (rc) return rc;
+    c->cu_main_every = K;
+  }
+  if (!c->cu_ev) DMM_HIP(hipEventCreateWithFlags(&c->cu_ev, hipEventDisableTiming));
+  DMM_HIP(hipEventRecord(c->cu_ev, c->stream));
+  DMM_HIP(hipStreamWaitEvent(c->cu_main, c->cu_ev, 0));
+  caller = c->stream;
+  c->stream = c->cu_main;
+  return DMM_OK;
+}
+
+dmm_cu_scope::~dmm_cu_scope() {
+  if (!caller) return;
+  (void)hipEventRecord(c->cu_ev, c->cu_main);
+  (void)hipStreamWaitEvent(caller, c->cu_ev, 0);
+  c->stream = caller;
+}
+
 extern "C" {
 
 int dmm_version(void) { return DMM_VERSION; }
@@ -106,6 +145,8 @@ int dmm_ctx_destroy(dmm_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->aux_stream_b) (void)hipStreamDestroy(c->aux_stream_b);
+  if (c->cu_main) (void)hipStreamDestroy(c->cu_main);
+  if (c->cu_ev) (void)hipEventDestroy(c->cu_ev);
   if (c->aux_pinned) (void)hipHostFree(c->aux_pinned);
   delete c;
   return DMM_OK;
@@ -114,6 +155,31 @@ int dmm_ctx_destroy(dmm_ctx* c) {
 int dmm_ctx_set_stream(dmm_ctx* c, void* s) {
   DMM_REQUIRE(c != nullptr, "dmm_ctx_set_stream: ctx is NULL");
   c->stream = (hipStream_t)s;
+  return DMM_OK;
+}
+
+int dmm_stream_create_cu_subset(int device, int every, int phase, int priority, void** stream) {
+  DMM_REQUIRE(stream != nullptr && every >= 1 && every <= 64 && phase >= -every && phase < every, "dmm_stream_create_cu_subset: every in 1..64, phase in -every..every-1");
+  DMM_HIP(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  if (every == 1) {
+    DMM_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
+  } else {
+    // CU i belongs to the subset when i % every == phase (phase >= 0), or when i % every != -phase - 1 (phase < 0: the
+    // complement of subset -phase - 1): spread over the chip whatever the numbering behind the mask bits
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 256; ++i) {
+      const bool in = phase >= 0 ? (i % every) == phase : (i % every) != -phase - 1;
+      if (in) mask[i >> 5] |= 1u << (i & 31);
+    }
+    DMM_HIP(hipExtStreamCreateWithCUMask(&st, 8, mask));
+  }
+  *stream = (void*)st;
+  return DMM_OK;
+}
+
+int dmm_stream_destroy(void* stream) {
+  if (stream) DMM_HIP(hipStreamDestroy((hipStream_t)stream));
   return DMM_OK;
 }
 
@@ -130,6 +196,8 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
   else if (!strcmp(name, "ml_null")) c->opt_ml_null = (int)value;
   else if (!strcmp(name, "ml_rank_stop")) c->opt_ml_rank_stop = (int)value;
+  else if (!strcmp(name, "ml_cu_split")) c->opt_ml_cu_split = (int)value;
+  else if (!strcmp(name, "dirty_cu_split")) c->opt_dirty_cu_split = (int)value;
   else if (!strcmp(name, "ml_chase_split")) c->opt_ml_chase_split = (int)value;
   else if (!strcmp(name, "ml_chase_grid")) c->opt_ml_chase_grid = (int)value;
   else if (!strcmp(name, "ml_chase_layout")) c->opt_ml_chase_layout = (int)value;
@@ -189,13 +257,24 @@ int dmm_ctx_set_ml_basis(dmm_ctx* c, void* U, double* sigma, int32_t* rank, int6
   c->ml_bs_rank = U ? rank : nullptr;
   c->ml_bs_slots = U ? nslots : 0;
   c->ml_bs_rmax = U ? rmax : 0;
-  c->ml_bs_build = U ? (build != 0) : 0;
+  c->ml_bs_build = U ? (build == 1) : 0;
   c->ml_bs_rank_h.clear();
-  if (U && build) DMM_HIP(hipMemsetAsync(rank, 0xFF, (size_t)nslots * sizeof(int32_t), c->stream));  // -1: nothing there yet
-  if (U && !build) {  // the ranks size the chunks' small problems: host copy
-    c->ml_bs_rank_h.resize((size_t)nslots);
-    DMM_HIP(hipMemcpyAsync(c->ml_bs_rank_h.data(), rank, (size_t)nslots * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    DMM_HIP(hipStreamSynchronize(c->stream));
+  if (U && build == 1) {
+    DMM_HIP(hipMemsetAsync(rank, 0xFF, (size_t)nslots * sizeof(int32_t), c->stream));  // -1: nothing there yet
+    c->ml_bs_rank_cache_src = nullptr;
+  }
+  if (U && build != 1) {  // the ranks size the chunks' small problems: host copy
+    // (kept from the last use of the same array through this context -- a build through it, or build = 2, refreshes it:
+    // the copy is a D2H transfer and a drain of the caller's stream, once per slab of every day otherwise)
+    if (build == 0 && c->ml_bs_rank_cache_src == rank && (int64_t)c->ml_bs_rank_cache.size() == nslots) {
+      c->ml_bs_rank_h = c->ml_bs_rank_cache;
+    } else {
+      c->ml_bs_rank_h.resize((size_t)nslots);
+      DMM_HIP(hipMemcpyAsync(c->ml_bs_rank_h.data(), rank, (size_t)nslots * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      DMM_HIP(hipStreamSynchronize(c->stream));
+      c->ml_bs_rank_cache = c->ml_bs_rank_h;
+      c->ml_bs_rank_cache_src = rank;
+    }
   }
   return DMM_OK;
 }

@@ -30,6 +30,11 @@ struct dmm_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t aux_stream = nullptr;        // library-owned second stream (ML eigen path: QL of one half-batch under the reduction of the next)
   hipStream_t aux_stream_b = nullptr;      // and a third: the QL launches of the two chunk slots are latency bound and run side by side
+  hipStream_t cu_main = nullptr;           // "ml_cu_split" (A/B): the caller's queue of dmm_ml_run, confined to the CUs the side streams do not own
+  hipEvent_t cu_ev = nullptr;
+  int opt_ml_cu_split = 0;
+  int opt_dirty_cu_split = 0;
+  int cu_main_every = 0;                   // the split cu_main was created for
   hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int* aux_pinned = nullptr;               // pinned host words for flags read back on the second stream
   size_t aux_pinned_n = 0;
@@ -71,6 +76,8 @@ struct dmm_ctx {
   int64_t ml_bs_slots = 0;
   int ml_bs_rmax = 0, ml_bs_build = 0;
   std::vector<int32_t> ml_bs_rank_h;       //   host copy of the ranks (use mode: sizes the chunks' small problems)
+  std::vector<int32_t> ml_bs_rank_cache;  // host copy of the last rank array used through this context ...
+  const int32_t* ml_bs_rank_cache_src = nullptr;  // ... and which array it was (dmm_ctx_set_ml_basis)
   int64_t ml_tiles_basis = 0;              // counter: tiles decomposed through the basis route
   double2* ml_gcache = nullptr;            // dmm_ctx_set_ml_gram_cache: resident B B^H of the telescope-side tiles (caller-owned), or nullptr
   int32_t* ml_gvalid = nullptr;            //   [ml_gslots] which slots hold a product
@@ -172,3 +179,15 @@ int dmm_set_error(int code, const char* fmt, ...);
 int dmm_fft_tables_f64(dmm_ctx* ctx, int n, dmm_fft_tables** out);  // mfft.hip
 
 static inline bool dmm_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// ---- "ml_cu_split" / "dirty_cu_split" = K >= 2: for the length of a call the caller's queue is moved to a library-owned
+// stream confined to the CUs with i % K != 0 (the complement of dmm_stream_create_cu_subset(device, K, 0, ...), the side
+// stream's share), ordered with the caller's stream by events on both ends.
+int dmm_make_cu_stream(dmm_ctx* ctx, hipStream_t* st, bool side, int K);
+struct dmm_cu_scope {
+  dmm_ctx* c;
+  hipStream_t caller = nullptr;
+  explicit dmm_cu_scope(dmm_ctx* ctx) : c(ctx) {}
+  int enter(int K);
+  ~dmm_cu_scope();
+};

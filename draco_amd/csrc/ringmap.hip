@@ -788,12 +788,17 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
     const int ntile_el = (nel + kFuEl16 - 1) / kFuEl16;
     const int64_t ntile = (int64_t)ntile_el * npol * nfreq;
     const size_t lds16 = (size_t)8 * q.P * sizeof(double2) + tw_b;  // all sixteen elevations' image in the LDS?
+    // The parked half of the image is 131 KB per block at nra = 2048 and is indexed by TILE: it grows with nfreq npol nel, and
+    // the form only pays while it stays in the Infinity Cache (256 MiB) -- beyond that the 8-elevation form below takes the
+    // call (0.5 GB of scratch at 4096 tiles, kept by the context)
+    const size_t park_bytes = (size_t)ntile * 4 * nra * sizeof(double2);
+    if (lds16 > 150 * 1024 && park_bytes > ((size_t)192 << 20)) goto eight_elevations;
     if (lds16 <= 150 * 1024) {
       DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fused16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
       hipLaunchKernelGGL(k_rm_fused16<false>, dim3((unsigned)ntile), dim3(kFuThreads), lds16, ctx->stream, p, q, ntile_el, (double2*)nullptr);
     } else {
       void* park = nullptr;
-      rc = dmm_get_scratch(ctx, (size_t)ntile * 4 * nra * sizeof(double2) + 256, &park);
+      rc = dmm_get_scratch(ctx, park_bytes + 256, &park);
       if (rc) return rc;
       DMM_HIP(hipFuncSetAttribute((const void*)k_rm_fused16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
       hipLaunchKernelGGL(k_rm_fused16<true>, dim3((unsigned)ntile), dim3(kFuThreads), fused_lds, ctx->stream, p, q, ntile_el, (double2*)park);
@@ -801,6 +806,7 @@ extern "C" int dmm_ringmap_deconvolve(dmm_ctx* ctx, int nm, int nm_beam, int npo
     DMM_HIP(hipGetLastError());
     return DMM_OK;
   }
+eight_elevations:
   if (!dirty_beam && !skip_deconvolution && !q.blue && nra >= 8 && fused_lds <= 150 * 1024 && ctx->opt_ringmap_variant != 1) {
     const int ntile_el = (nel + kFuEl - 1) / kFuEl;
     const int64_t ntile = (int64_t)ntile_el * npol * nfreq;

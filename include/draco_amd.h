@@ -70,7 +70,22 @@ int dmm_ctx_destroy(dmm_ctx* ctx);
 /* run on the caller's HIP stream (hipStream_t passed as void*; NULL = default stream) */
 int dmm_ctx_set_stream(dmm_ctx* ctx, void* hip_stream);
 int dmm_ctx_sync(dmm_ctx* ctx);
-/* tuning knobs (performance only, never results): "dirty_variant" (0 = default), "grid_mult",
+/* A HIP stream (returned as void*) whose kernels run on a SUBSET of the GPU's compute units (hipExtStreamCreateWithCUMask):
+ * CU i is in the subset when i % every == phase; phase < 0 selects the complement of subset -phase - 1; every = 1: an
+ * ordinary stream of the given HIP priority.  For stages that run BESIDE the HBM-bound solves on a stream of their own --
+ * the reference has no counterpart (its stages run one after the other, mapmaker.py:62-118): confined to a few CUs the
+ * compute-bound alm2map of finished frequencies leaves the others' registers and LDS to the solve kernel.
+ * Hand it to dmm_ctx_set_stream / torch.cuda.ExternalStream; destroy with dmm_stream_destroy when nothing uses it. */
+int dmm_stream_create_cu_subset(int device, int every, int phase, int priority, void** hip_stream);
+int dmm_stream_destroy(void* hip_stream);
+/* Options.  Two kinds:
+ *  - performance only, never results (A/B switches and sizes): every name below EXCEPT the ones listed next;
+ *  - accuracy-affecting: "ml_rank_stop" (on by default: an approximation of the reference's pinv_svd validated at 1.7e-9 on
+ *    the structured tiles, exact for Gram matrices that are not numerically rank deficient; requires POSITIVE SEMI-DEFINITE
+ *    input -- the library applies it to the Gram matrices D B B^H D / B^H N B and X X^H only; values are clamped to
+ *    v >= 11, i.e. a stop no looser than 1e-11 of lambda_max, five decades under pinv_svd's relative cut of 1e-6),
+ *    "ml_inner_sweeps" / "ml_outer_sweeps" (iteration caps of the Jacobi fallback).
+ * "dirty_variant" (0 = default), "grid_mult",
  * "project_variant", "project_grid_mult", "ml_inner_sweeps", "ml_outer_sweeps", "sht_variant",
  * (sht_variant: bits 0-1 synthesis form, bit 2 direct ring sums, bit 3 vector-ALU Legendre kernels, bit 4 the 8-wave analysis block, bit 5 m = blockIdx.x instead of the XCD-aware block -> m map, bit 6 the first MFMA synthesis kernel (rounds 1-4) instead of the pipelined one, bit 7 the pipelined one with 4 instead of 8 frequencies per block),
  * "ml_shortcut" (0 = on; 2 = always eigen-decompose; 3 = telescope-side systems only),
@@ -85,9 +100,12 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * conflicts -- an A/B of DESIGN 5.5: the counted conflicts change, the run time does not),
  * "ml_rank_stop" (rank stop of the two-stage reduction, DESIGN 5.5: once the trace of a Gram matrix's trailing matrix has
  * fallen to 1e-13 of a lower bound of its largest eigenvalue -- seven decades below pinv_svd's relative cut -- the matrix is
- * cut off at that order and the bulge chase, QL and both back-transformations work on it; 0, default: on; 1: off; v >= 8:
- * on at 10^-v), "ml_chase_split" (0, default: the bulge chase's LDS is sized for the effective order 98 % of the
+ * cut off at that order and the bulge chase, QL and both back-transformations work on it; 0, default: on; 1: off; v >= 11:
+ * on at 10^-v, 2 <= v < 11 is taken as 11), "ml_chase_split" (0, default: the bulge chase's LDS is sized for the effective order 98 % of the
  * context's matrices so far stayed under, the few above go through a second small launch; 1: one launch, full band image),
+ * "ml_cu_split" (0, default: off; K >= 2: the library's side streams -- bulge chase, serial QL -- are created on every K-th CU
+ * (hipExtStreamCreateWithCUMask) and dmm_ml_run moves the caller's queue to a stream on the others for the length of the
+ * call: an A/B of DESIGN 5.5; set before the first dmm_ml_run of the context),
  * "ml_chase_grid" (0, default: one bulge-chase block per matrix; > 0: at most that many persistent blocks, each working
  * through several matrices -- an A/B of DESIGN 5.5),
  * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies; 2 = the
@@ -147,8 +165,15 @@ int dmm_ctx_set_ml_gram_cache(dmm_ctx* ctx, void* cache, int32_t* valid, int64_t
  *              cache): U^H as rmax rows of 2 npairs complex128 (`U`), the singular values (`sigma`, rmax doubles) and
  *              their count (`rank`, -1: more than rmax above 1e-15 of the largest eigenvalue -- the tile keeps the
  *              full-order path).  alm is not written.
- *   build = 0: dmm_ml_run takes the basis route for every chunk whose tiles all have a basis.
- * U = NULL: off.  The arrays are the caller's and live with the B block they were computed from. */
+ *   build = 0: dmm_ml_run takes the basis route for every chunk whose tiles all have a basis -- and whose small problem fits
+ *              the workspace beside the basis product (otherwise the chunk keeps the full-order path).  The library sizes the
+ *              chunks from a host copy of `rank`, taken when the array is first used through this context and kept until a
+ *              build through this context; build = 2: as 0, and take the copy again (the array was written by other means).
+ * U = NULL: off.  The arrays are the caller's and live with the B block they were computed from.
+ * Accuracy: the bases are truncated at 1e-15 of the largest eigenvalue of the UNWEIGHTED B B^H; a day whose non-zero noise
+ * weights span more than six decades should use the full-order path (the dropped modes enter the day's Gram matrix at up to
+ * 1e-15 (d_max / d_min)^2 of its lambda_max, pinv_svd's relative cut is 1e-6): MaximumLikelihoodMapMaker.cache_beam_basis
+ * checks the day's weights and falls back by itself. */
 int dmm_ctx_set_ml_basis(dmm_ctx* ctx, void* U, double* sigma, int32_t* rank, int64_t nslots, int rmax, int build);
 int64_t dmm_ml_gram_cache_slots(const dmm_plan* plan);
 int64_t dmm_ml_gram_cache_bytes(const dmm_plan* plan);

@@ -30,7 +30,7 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     assert d["ranks"]["ranks_seen_by_all_gather_into_tensor"] == 2 and d["launcher"]["ranks_started"] == 2
     nfreq_job = 64 if scaling == "strong" else 128
     assert d["allgather"]["frequencies_gathered"] == nfreq_job  # every rank ends with the whole map
-    assert d["allgather"]["gathered_GB"] == pytest.approx(2 * d["allgather"]["shard_GB"])
+    assert d["allgather"]["gathered_GB"] == pytest.approx(2 * d["allgather"]["shard_GB"], rel=1e-4)  # (the line carries 6 significant digits)
     assert d["roofline"]["launches"] >= 2 and 0 < d["roofline"]["frac"] < 1.0
     assert d["cpu_baseline"] is None  # (--no-cpu-baseline; otherwise the launcher times it before it starts the ranks)
 
