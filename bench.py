@@ -1004,6 +1004,8 @@ def main():
             k_, v_ = kv.split("=")
             for c_ in (Context.get(), Context.side(Context.get().device_index)):
                 _lib.check(_lib.lib.dmm_ctx_set_option(c_.handle, k_.strip().encode(), int(v_)))
+                if k_.strip() == "sht_variant":
+                    c_.sht_variant_pin = int(v_)  # (the map-makers then leave the Legendre form alone)
     job = Job(cfg, rank, world, args.scaling, args.b_dtype, args.pool_freqs, overlap_sht=False if args.no_overlap else None)
 
     def barrier():

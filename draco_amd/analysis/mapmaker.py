@@ -33,6 +33,26 @@ from .transform import _dev_dataset
 _IN_FLIGHT: dict = {}
 
 
+def _alm2map_neighbourly(c, alm, nfreq, lmax, mmax, nside, maps):
+    """``dmm_alm2map`` of a map-maker: always with the FIRST MFMA form of the Legendre synthesis (``sht_variant`` bit 6).
+
+    The map-makers run this transform beside the HBM-bound solve kernel by default (side stream), where the pipelined
+    synthesis kernel of round 5 -- 256 / 512 registers per lane -- starves the solve kernel of wave slots (2000 -> 1076
+    m-modes/s on the headline day, ``profiles/r05_cu_split_ab.txt``); the 208-register form does not.  The sequential
+    path (``overlap_sht = False``) uses the same form so that a map never depends on that switch: same bits either way.
+    An explicit ``sht_variant`` set on the context by the caller (bench.py's DMM_OPTS A/B) is left alone.
+    """
+    lib = _lib.lib
+    pinned = getattr(c, "sht_variant_pin", None)
+    if pinned is None:
+        _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_variant", 64))
+    try:
+        _lib.check(lib.dmm_alm2map(c.handle, ptr(alm), nfreq, 4, lmax, mmax, nside, ptr(maps)))
+    finally:
+        if pinned is None:
+            _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_variant", 0))
+
+
 def _bound_run_ahead(ctx, depth):
     """Host-wait until at most ``depth - 1`` earlier days are still running on the device, so that with the day about
     to be queued there are ``depth``."""
@@ -141,7 +161,7 @@ class BaseMapMaker(ContainerTask):
             if npol == 1:  # the reference's alm always has 4 pol slots and broadcasts into them (:71,:94)
                 alm_d = alm_d.expand(nfreq, 4, n_m, nl).contiguous()
             maps = ctx.empty((nfreq, 4, npix), np.float64)
-            _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm_d), nfreq, 4, lmax, n_m - 1, nside, ptr(maps)))
+            _alm2map_neighbourly(ctx, alm_d, nfreq, lmax, n_m - 1, nside, maps)
         else:
             # the inverse SHT (:112) of the frequencies a slab has finished runs on a side stream
             # beside the next slab's fill + solves: it is compute-bound, they are HBM/PCIe-bound
@@ -155,11 +175,11 @@ class BaseMapMaker(ContainerTask):
                 if "maps" not in out:
                     out["maps"] = ctx.empty((nfreq, 4, npix), np.float64)
                 if not overlap:
-                    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(out["maps"][f0:f1])))
+                    _alm2map_neighbourly(ctx, alm[f0:f1], f1 - f0, lmax, n_m - 1, nside, out["maps"][f0:f1])
                     return
                 side.wait_for(main)
                 side.uses(alm, out["maps"])  # read / written on the side stream: held until side.sync()
-                _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(out["maps"][f0:f1])))
+                _alm2map_neighbourly(side, alm[f0:f1], f1 - f0, lmax, n_m - 1, nside, out["maps"][f0:f1])
 
             alm_d = self.make_alm(mmodes, on_freqs_done=sht_of)
             maps = out.get("maps")
@@ -223,7 +243,7 @@ class BaseMapMaker(ContainerTask):
                 if d == 0:
                     side.wait_for(main)
                 side.uses(alm, maps[d])
-            _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm[f0:f1]), f1 - f0, 4, lmax, n_m - 1, nside, ptr(maps[d][f0:f1])))
+            _alm2map_neighbourly(side, alm[f0:f1], f1 - f0, lmax, n_m - 1, nside, maps[d][f0:f1])
 
         alms = self.make_alm_many(mmodes_list, on_freqs_done=sht_of)
         pending = None

@@ -242,21 +242,20 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
     (void)hipMemsetAsync(stamps_d, 0, nst * 8, ctx->stream);
     lp.stamps = stamps_d;
 #endif
-    if (ctx->opt_sht_variant & 64)  // bit 6: the first MFMA form (rounds 1-4), the A/B of the pipelined one
-      hipLaunchKernelGGL(k_leg_synth_mfma, dim3(g.mmax + 1, nrc, (nf + kLegF - 1) / kLegF), dim3(kThreads), 0, ctx->stream, lp);
-    else if (ctx->opt_sht_variant & 128)  // bit 7: one frequency group per block, two waves per SIMD
-      hipLaunchKernelGGL(k_leg_synth_mfma2<1>, dim3(g.mmax + 1, nrc, (nf + kLegF - 1) / kLegF), dim3(kThreads), 0, ctx->stream, lp);
-    else
-      hipLaunchKernelGGL(k_leg_synth_mfma2<2>, dim3(g.mmax + 1, nrc, (nf + 2 * kLegF - 1) / (2 * kLegF)), dim3(kThreads), 0, ctx->stream, lp);
-#ifdef LEG_STAMPS
-    {
-      std::vector<unsigned long long> h(nst);
-      (void)hipStreamSynchronize(ctx->stream);
-      (void)hipMemcpy(h.data(), stamps_d, nst * 8, hipMemcpyDeviceToHost);
-      FILE* fo = fopen("gpurun_out/leg_blocks.bin", "wb");
-      if (fo) { fwrite(h.data(), 8, nst, fo); fclose(fo); }
+    const int nx = g.mmax + 1, G = ctx->opt_sht_grid;
+    if (ctx->opt_sht_variant & 64) {  // bit 6: the first MFMA form (rounds 1-4), the A/B of the pipelined one
+      const int nz = (nf + kLegF - 1) / kLegF;
+      if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma_walk, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
+      else hipLaunchKernelGGL(k_leg_synth_mfma, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
+    } else if (ctx->opt_sht_variant & 128) {  // bit 7: one frequency group per block, two waves per SIMD
+      const int nz = (nf + kLegF - 1) / kLegF;
+      if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma2_walk<1>, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
+      else hipLaunchKernelGGL(k_leg_synth_mfma2<1>, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
+    } else {
+      const int nz = (nf + 2 * kLegF - 1) / (2 * kLegF);
+      if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma2_walk<2>, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
+      else hipLaunchKernelGGL(k_leg_synth_mfma2<2>, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
     }
-#endif
   } else
   switch (ctx->opt_sht_variant & 3) {
     case 1: hipLaunchKernelGGL((k_leg_synth<NPOL, 1, 1>), dim3(g.mmax + 1, nf), dim3(kThreads), 0, ctx->stream, lp); break;

@@ -170,10 +170,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_leg_synth(LegParams p) {
 // lane group and the two l rows of a half wave fall on disjoint banks.
 constexpr int kLegL = 8, kLegF = 4, kLegPitch = 72;
 
-__global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) {
+// (the kernels' bodies take their block coordinates as arguments: launched one block per (m, ring chunk, frequency group),
+// or -- `sht_grid` > 0 -- as a fixed number of resident blocks that walk the same items, so that the transform beside the
+// HBM-bound solve kernel keeps to a bounded share of the compute units)
+__device__ __forceinline__ void leg_synth_mfma_body(const LegParams& p, int bx, int by, int bz) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ double slab[kThreads / 64][3][kLegL][kLegPitch];
-  const int m = leg_m_of_block(blockIdx.x, p.g.mmax + 1, p.m_identity), rc = blockIdx.y, f0 = blockIdx.z * kLegF;
+  const int m = leg_m_of_block(bx, p.g.mmax + 1, p.m_identity), rc = by, f0 = bz * kLegF;
   const int lmax = p.g.lmax, nl = lmax - m + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nring = p.g.nring, npair = (nring + 1) / 2;
@@ -315,6 +318,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) {
     }
 }
 
+__global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) { leg_synth_mfma_body(p, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+__global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma_walk(LegParams p, int nx, int ny, int nz) {
+  for (int item = blockIdx.x; item < nx * ny * nz; item += gridDim.x)
+    leg_synth_mfma_body(p, item % nx, (item / nx) % ny, item / (nx * ny));
+}
+
 // ---- synthesis on the matrix cores, second form (round 5; default, `sht_variant` bit 6 restores the one above).
 // What the counters and in-kernel stamps of the first form say (profiles/r01_sht_cfg3_pmc.txt, profiles/r05_sht_*): 17 vector
 // instructions per MFMA, the matrix pipe busy 0.30 of the kernel -- and on this part an f64 VALU operation runs on the SAME
@@ -342,11 +352,11 @@ constexpr int kLeg2Rows = kLegL + 1;  // row 0: lambda of the step before the ch
 #endif
 
 template <int NFG>
-__global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2(LegParams p) {
+__device__ __forceinline__ void leg_synth_mfma2_body(const LegParams& p, int bx, int by, int bz, int ny) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ double slab[kThreads / 64][2][kLeg2Rows][kLegPitch];
   __shared__ double ringf[kThreads / 64][2][64];
-  const int m = leg_m_of_block(blockIdx.x, p.g.mmax + 1, p.m_identity), rc = blockIdx.y, f0 = blockIdx.z * (kLegF * NFG);
+  const int m = leg_m_of_block(bx, p.g.mmax + 1, p.m_identity), rc = by, f0 = bz * (kLegF * NFG);
   const int lmax = p.g.lmax, nl = lmax - m + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nring = p.g.nring, npair = (nring + 1) / 2;
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2(LegParams
 
   // Ring tiles (16 consecutive ring pairs) go round robin over the waves of ALL the blocks of this (m, frequency group):
   // wave W = 4 rc + wave owns the tiles W, W + NW, W + 2 NW, W + 3 NW, so every wave holds polar and equatorial rings alike
-  const int NW = gridDim.y * (kThreads / 64), W = rc * (kThreads / 64) + wave;
+  const int NW = ny * (kThreads / 64), W = rc * (kThreads / 64) + wave;
   // generation state of this thread's ring pair
   const int r = 16 * (W + (lane >> 4) * NW) + (lane & 15);
   double x = 0.0, lam = 0.0, lam_prev = 0.0;
@@ -618,6 +628,17 @@ __global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2(LegParams
     o[7] = m;
   }
 #endif
+}
+
+template <int NFG>
+__global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2(LegParams p) {
+  leg_synth_mfma2_body<NFG>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+}
+
+template <int NFG>
+__global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2_walk(LegParams p, int nx, int ny, int nz) {
+  for (int item = blockIdx.x; item < nx * ny * nz; item += gridDim.x)
+    leg_synth_mfma2_body<NFG>(p, item % nx, (item / nx) % ny, item / (nx * ny), ny);
 }
 
 // ---------------------------------------------------------------- analysis, stage 2'

@@ -85,13 +85,7 @@ class Context:
                     st = torch.cuda.Stream(device=dev, priority=least)
                 except Exception:
                     st = torch.cuda.Stream(device=dev)
-            side = cls(device, st)
-            if every <= 1:
-                # beside the HBM-bound solve kernel the Legendre synthesis must be a good neighbour: the pipelined kernel
-                # (256 / 512 registers per lane) takes whole SIMDs and starves the solve kernel of wave slots -- measured:
-                # 2000 -> 1076 m-modes/s on the headline day -- so the side context keeps the first MFMA form (208 registers)
-                _lib.check(_lib.lib.dmm_ctx_set_option(side.handle, b"sht_variant", 64))
-            cls._side_cache[device] = side
+            cls._side_cache[device] = cls(device, st)
         return cls._side_cache[device]
 
     #: the side stream's share of the GPU: every N-th compute unit (0 / 1: an ordinary low-priority stream on all of them);
