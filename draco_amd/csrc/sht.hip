@@ -331,9 +331,12 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
     // 4-wave blocks, two per CU, the ring pairs in passes of 256 (default since round 4: map2alm 0.116 -> 0.110 ms per
     // frequency at cfg 3, -4.4 % with three iterations); bit 4 of sht_variant: the 8-wave block of rounds 1-3 (A/B)
     if (ctx->opt_sht_variant & 16)
-      hipLaunchKernelGGL(k_leg_anal_mfma<kAnThreads>, dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(kAnThreads), 0, ctx->stream, lp);
+      hipLaunchKernelGGL((k_leg_anal_mfma<kAnThreads, 1>), dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(kAnThreads), 0, ctx->stream, lp);
+    else if (ctx->opt_sht_variant & 512)  // bit 9: two frequency groups per block at 512 registers -- measured SLOWER (map2alm 0.117
+      // against 0.107 ms per frequency: the ring data parked in AGPRs comes back through a v_accvgpr_read per product), an A/B
+      hipLaunchKernelGGL((k_leg_anal_mfma<256, 2>), dim3(g.mmax + 1, (nf + 2 * kLegF - 1) / (2 * kLegF)), dim3(256), 0, ctx->stream, lp);
     else
-      hipLaunchKernelGGL(k_leg_anal_mfma<256>, dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(256), 0, ctx->stream, lp);
+      hipLaunchKernelGGL((k_leg_anal_mfma<256, 1>), dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(256), 0, ctx->stream, lp);
     DMM_HIP(hipGetLastError());
     return DMM_OK;
   }

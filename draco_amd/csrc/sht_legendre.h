@@ -844,13 +844,21 @@ constexpr int kAnL = 32, kAnPitch = 65, kAnThreads = 512;
 // NT = kAnThreads = 512 (sht_variant bit 4, the form of rounds 1-3): one block of 8 waves per CU (137 KB), every ring pair
 // of nside <= 256 in one pass; two barriers per 32-l chunk hold eight waves instead of four.
 
-template <int NT>
-__global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p) {
+// NFG = frequency groups (of kLegF = 4 frequencies: one MFMA B operand) per block.  NFG = 2 (round 5, `sht_variant` bit 9, an
+// A/B): the recurrence and the formation of the A operands -- nothing of which hides under an f64 MFMA on this part, DESIGN
+// 5.4 -- serve twice the products; the ring data of both groups stay in registers (512 per lane, one wave per SIMD: NT = 256
+// only) -- and come back from the AGPR half of the file through a copy per product: slower than NFG = 1.  The (ra, rb) of a
+// chunk's 32 steps are parked in LDS once per chunk and read back as one broadcast ds_read_b128 per step (round 4: four
+// v_readlane per step, ~10 cycles each).
+template <int NT, int NFG>
+__global__ __launch_bounds__(NT, NFG == 2 ? 1 : 512 / NT) void k_leg_anal_mfma(LegAnalParams p) {
   constexpr int kAnWaves = NT / 64;
+  static_assert(NFG == 1 || NT == 256, "two frequency groups per block: the 4-wave form only");
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ double slab[kAnWaves][(kAnL + 1) * kAnPitch];  // row 0: lambda of the step before the chunk
   __shared__ double ringtab[kAnWaves][2][64];                // x / sin^2, 1 / sin^2 of the wave's rings
-  const int m = leg_m_of_block(blockIdx.x, p.g.mmax + 1, p.m_identity), f0 = blockIdx.y * kLegF;
+  __shared__ double2 rrtab[kAnWaves][kAnL];                  // (ra, rb) of the chunk's steps
+  const int m = leg_m_of_block(blockIdx.x, p.g.mmax + 1, p.m_identity), f0 = blockIdx.y * (kLegF * NFG);
   const int lmax = p.g.lmax, nl = lmax - m + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nring = p.g.nring, npair = (nring + 1) / 2;
@@ -860,18 +868,17 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p)
   double* alm_d = reinterpret_cast<double*>(p.alm);
 
   // structural zeros l < m
-  for (int idx = threadIdx.x; idx < kLegF * 4 * m; idx += NT) {
+  for (int idx = threadIdx.x; idx < kLegF * NFG * 4 * m; idx += NT) {
     const int fp = idx / m, l = idx - fp * m;
     const int f = f0 + (fp >> 2);
     if (f < p.nf) p.alm[(((int64_t)f * 4 + (fp & 3)) * p.n_m + m) * (lmax + 1) + l] = make_double2(0.0, 0.0);
   }
 
   const int li = lane & 15, kq = lane >> 4;
-  const int col = li, fi = col >> 2, c = col & 3, f = f0 + fi;
-  const bool fok = f < p.nf;
+  const int col = li, fi = col >> 2, c = col & 3;
   const double* bsrc = reinterpret_cast<const double*>(p.b);
 
-  for (int r0 = 0; r0 < npair; r0 += NT) {  // ring super-chunks of 512 pairs (one at nside <= 256)
+  for (int r0 = 0; r0 < npair; r0 += NT) {  // ring super-chunks of NT pairs
     // generation state of this thread's ring pair
     const int r = r0 + threadIdx.x;
     double x = 0.0, inv_s2 = 0.0, xs2 = 0.0, lam = 0.0, lam_prev = 0.0;
@@ -890,27 +897,32 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p)
 
     // ring data of the wave's 64 pairs as MFMA B operands, kept for every l: per K step ks the lane holds
     // column `col` of ring 4 ks + kq -- (T | V) and -(Q | U), north+south and north-south
-    double bTV[16][2], g1[16][2];
+    double bTV[NFG][16][2], g1[NFG][16][2];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int rr = r0 + wave * 64 + 4 * ks + kq;
-      double tn = 0.0, ts = 0.0, qn = 0.0, qs = 0.0;
-      if (wave_live && fok && rr < npair) {
-        const int rs = nring - 1 - rr;
-        const int64_t on = (((int64_t)f * 4) * nring + rr) * mstride + m, os = (((int64_t)f * 4) * nring + rs) * mstride + m;
-        const int64_t pstride = (int64_t)nring * mstride;
-        const int polTV = c < 2 ? 0 : 3, pol1 = c < 2 ? 1 : 2, comp = c & 1;
-        tn = bsrc[(on + polTV * pstride) * 2 + comp];
-        qn = bsrc[(on + pol1 * pstride) * 2 + comp];
-        if (rs != rr) {
-          ts = bsrc[(os + polTV * pstride) * 2 + comp];
-          qs = bsrc[(os + pol1 * pstride) * 2 + comp];
+    for (int h = 0; h < NFG; ++h) {
+      const int f = f0 + kLegF * h + fi;
+      const bool fok = f < p.nf;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int rr = r0 + wave * 64 + 4 * ks + kq;
+        double tn = 0.0, ts = 0.0, qn = 0.0, qs = 0.0;
+        if (wave_live && fok && rr < npair) {
+          const int rs = nring - 1 - rr;
+          const int64_t on = (((int64_t)f * 4) * nring + rr) * mstride + m, os = (((int64_t)f * 4) * nring + rs) * mstride + m;
+          const int64_t pstride = (int64_t)nring * mstride;
+          const int polTV = c < 2 ? 0 : 3, pol1 = c < 2 ? 1 : 2, comp = c & 1;
+          tn = bsrc[(on + polTV * pstride) * 2 + comp];
+          qn = bsrc[(on + pol1 * pstride) * 2 + comp];
+          if (rs != rr) {
+            ts = bsrc[(os + polTV * pstride) * 2 + comp];
+            qs = bsrc[(os + pol1 * pstride) * 2 + comp];
+          }
         }
+        bTV[h][ks][0] = tn + ts;
+        bTV[h][ks][1] = tn - ts;
+        g1[h][ks][0] = -(qn + qs);
+        g1[h][ks][1] = -(qn - qs);
       }
-      bTV[ks][0] = tn + ts;
-      bTV[ks][1] = tn - ts;
-      g1[ks][0] = -(qn + qs);
-      g1[ks][1] = -(qn - qs);
     }
     const double sg2 = (c == 0 || c == 3) ? -1.0 : 1.0;  // g2[c] = sg2 * g1[3 - c]
 
@@ -918,19 +930,17 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p)
       const int row = row0 + (lane >> 1);
       return cgv[8 * (int64_t)(row < nl ? row : nl - 1) + (lane & 1)];
     };
-    auto bcast = [&](double v, int src) {
-      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-      return __hiloint2double(hi, lo);
-    };
     double cvr = fetch_rr(0);
 
     for (int c0 = 0; c0 < nl; c0 += kAnL) {
-      v4d acc[4];  // TV q=0, TV q=1, EB q=0, EB q=1
+      v4d acc[NFG][4];  // TV q=0, TV q=1, EB q=0, EB q=1
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int h = 0; h < NFG; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[h][t] = (v4d){0.0, 0.0, 0.0, 0.0};
       if (wave_live) {
         const double cvr_next = fetch_rr(c0 + kAnL < nl ? c0 + kAnL : c0);
+        reinterpret_cast<double*>(rrtab[wave])[lane] = cvr;  // (wave-private: LDS operations of a wave complete in order)
         // this lane's two l (one per parity tile): the spin-2 factors of its A operands
         double qc1[2], qc2[2], qcd[2], qc3[2], qc4[2];
 #pragma unroll
@@ -947,7 +957,8 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p)
 #pragma unroll
         for (int kk = 0; kk < kAnL; ++kk) {
           const int k = c0 + kk;
-          const double ra = bcast(cvr, 2 * kk), rb = bcast(cvr, 2 * kk + 1);
+          const double2 rr2 = rrtab[wave][kk];  // broadcast read
+          const double ra = rr2.x, rb = rr2.y;
           double le = 0.0;
           if (k < nl) {
             if (k > 0 && nsc >= 0) {
@@ -976,44 +987,49 @@ __global__ __launch_bounds__(NT, 512 / NT) void k_leg_anal_mfma(LegAnalParams p)
           const double a2e = fma(qc4[0] * ri, l0, -qc3[0] * rx * l1);
           const double a1o = fma(qcd[1] * rx, l1, -fma(qc1[1], ri, qc2[1]) * l2);
           const double a2o = fma(qc4[1] * ri, l1, -qc3[1] * rx * l2);
-          // F2 data: columns reversed within each frequency (quad_perm 3,2,1,0), signs (-,+,+,-)
-          double g2[2];
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int lo = __builtin_amdgcn_mov_dpp(__double2loint(g1[ks][q]), 0x1b, 0xf, 0xf, true);
-            const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(g1[ks][q]), 0x1b, 0xf, 0xf, true);
-            g2[q] = sg2 * __hiloint2double(hi, lo);
+          for (int h = 0; h < NFG; ++h) {
+            // F2 data: columns reversed within each frequency (quad_perm 3,2,1,0), signs (-,+,+,-)
+            double g2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int lo = __builtin_amdgcn_mov_dpp(__double2loint(g1[h][ks][q]), 0x1b, 0xf, 0xf, true);
+              const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(g1[h][ks][q]), 0x1b, 0xf, 0xf, true);
+              g2[q] = sg2 * __hiloint2double(hi, lo);
+            }
+            acc[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, bTV[h][ks][0], acc[h][0], 0, 0, 0);
+            acc[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l2, bTV[h][ks][1], acc[h][1], 0, 0, 0);
+            acc[h][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1e, g1[h][ks][0], acc[h][2], 0, 0, 0);
+            acc[h][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1o, g1[h][ks][1], acc[h][3], 0, 0, 0);
+            acc[h][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2e, g2[1], acc[h][2], 0, 0, 0);
+            acc[h][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2o, g2[0], acc[h][3], 0, 0, 0);
           }
-          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, bTV[ks][0], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(l2, bTV[ks][1], acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1e, g1[ks][0], acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1o, g1[ks][1], acc[3], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2e, g2[1], acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2o, g2[0], acc[3], 0, 0, 0);
         }
         sl[lane] = sl[kAnL * kAnPitch + lane];  // lambda of the last step: "l - 1" of the next chunk
       }
-      // park the tiles in the (now free) rows 1.. of the own slab as [TV | EB][l row 0..31][16 columns]:
+      // park the tiles in the (now free) rows 1.. of the own slab as [group][TV | EB][l row 0..31][16 columns]:
       // tile q row i = kq + 4 reg is l row 2 i + q
       double* out = sl + kAnPitch;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = kq + 4 * reg;
-        out[(0 * kAnL + 2 * i + 0) * 16 + li] = acc[0][reg];
-        out[(0 * kAnL + 2 * i + 1) * 16 + li] = acc[1][reg];
-        out[(1 * kAnL + 2 * i + 0) * 16 + li] = acc[2][reg];
-        out[(1 * kAnL + 2 * i + 1) * 16 + li] = acc[3][reg];
-      }
-      __syncthreads();
-      // 1024 / NT values per thread: fixed-order sum over the waves, then into a_lm
+      for (int h = 0; h < NFG; ++h)
 #pragma unroll
-      for (int h = 0; h < 1024 / NT; ++h) {
-        const int idx = threadIdx.x + h * NT;  // [tile][row][col]
-        const int tile = idx >> 9, row = (idx >> 4) & 31, oc = idx & 15;
+        for (int reg = 0; reg < 4; ++reg) {
+          const int i = kq + 4 * reg;
+          out[((2 * h + 0) * kAnL + 2 * i + 0) * 16 + li] = acc[h][0][reg];
+          out[((2 * h + 0) * kAnL + 2 * i + 1) * 16 + li] = acc[h][1][reg];
+          out[((2 * h + 1) * kAnL + 2 * i + 0) * 16 + li] = acc[h][2][reg];
+          out[((2 * h + 1) * kAnL + 2 * i + 1) * 16 + li] = acc[h][3][reg];
+        }
+      __syncthreads();
+      // 1024 NFG / NT values per thread: fixed-order sum over the waves, then into a_lm
+#pragma unroll
+      for (int hh = 0; hh < 1024 * NFG / NT; ++hh) {
+        const int idx = threadIdx.x + hh * NT;  // [group][tile][row][col]
+        const int h = idx >> 10, tile = (idx >> 9) & 1, row = (idx >> 4) & 31, oc = idx & 15;
         double sum = 0.0;
 #pragma unroll
         for (int w = 0; w < kAnWaves; ++w) sum += slab[w][kAnPitch + idx];
-        const int k = c0 + row, of = f0 + (oc >> 2), cc = oc & 3;
+        const int k = c0 + row, of = f0 + kLegF * h + (oc >> 2), cc = oc & 3;
         if (k < nl && of < p.nf) {
           const int pol = tile == 0 ? (cc < 2 ? 0 : 3) : (cc < 2 ? 1 : 2);
           double* dst = alm_d + ((((int64_t)of * 4 + pol) * p.n_m + m) * (lmax + 1) + m + k) * 2 + (cc & 1);
