@@ -231,6 +231,11 @@ def _cpu_worker(rank, barrier, queue, seed, npairs, nra, lmax, ms, repeats, wind
         otr.mmode_transform(vis, w, mmax=lmax)
         nfft += 1
     res["t_fft"] = (time.perf_counter() - t0) / nfft  # seconds per frequency, this process
+    barrier.wait()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5 * window:  # untimed warm-up: the first window of a cold pool is 30 % slow
+        for bm in tiles:
+            omm.dirty_solve(bm, v, Ni)
     for _ in range(repeats):
         barrier.wait()
         n = 0
@@ -272,7 +277,7 @@ def _process_arm(nproc, npairs, nra, lmax, ms, repeats, window):
     try:
         for p_ in procs:
             p_.start()
-        deadline = time.time() + 60 + (repeats + 1) * window * 6
+        deadline = time.time() + 60 + (repeats + 2) * window * 6
         res = []
         while len(res) < nproc:
             try:
@@ -363,8 +368,8 @@ def cpu_baseline(cfg, seconds):
     Arms (SURVEY 8d / BASELINE.md): (i) one process, one BLAS thread; (ii) one process, BLAS threads = the cores this
     job is granted; (iii) P single-threaded processes, P = the cgroup's CPU quota (16 on a one-GPU box; every core of the
     affinity mask when there is no quota) -- the reference's MPI-over-frequency decomposition, and the arm that wins.
-    (i) and (ii) get a short window each; (iii) gets three barrier-synchronised windows of its own (>= 10 s together at
-    the default budget): `value` is the BEST window (a loaded host only ever slows a window down), `values` lists all of
+    (i) and (ii) get a short window each; (iii) gets a warm-up and five barrier-synchronised windows of its own (>= 10 s
+    together at the default budget): `value` is the BEST window (a loaded host only ever slows a window down), `values` lists all of
     them and `spread` = (max - min) / max says how much the host moved underneath.  In (iii) the
     transform is timed INSIDE the workers, all of them at once.  Runs BEFORE the GPU is touched (workers are spawned).
     """
@@ -387,8 +392,8 @@ def cpu_baseline(cfg, seconds):
     nfreq, nra, lmax = cfg["nfreq"], cfg["nra"], cfg["lmax"]
     rng = np.random.default_rng(0)
     short = max(0.5, seconds * 0.08)  # windows of arms (i) and (ii)
-    repeats = 3
-    window = max(0.5, seconds * 0.22)  # (iii): 3 windows + transform (0.25 w) + many-days (0.25 w) = 3.5 windows
+    repeats = 5
+    window = max(0.5, seconds * 0.13)  # (iii): a warm-up window + 5 timed windows + transform and many-days (0.25 w each)
 
     # single-process arms: transform of a slice of frequencies, then solves on a RAM pool of stratified tiles
     nf_s = max(1, min(nfreq, 2))

@@ -153,3 +153,17 @@ def test_resident_product_entries_check_their_arguments():
     _arg_error(lib.dmm_ctx_set_ml_gram_cache(None, BUF, BUF, 4, 0), "ctx is NULL")
     _arg_error(lib.dmm_ctx_set_ml_basis(None, BUF, BUF, BUF, 4, 448, 0), "ctx is NULL")
     assert lib.dmm_ml_gram_cache_slots(None) == 0 and lib.dmm_ml_gram_cache_bytes(None) == 0
+
+
+def test_round5_stream_entry_points_check_their_arguments():
+    """`dmm_stream_create_cu_subset`: the subset rule is checked before HIP is touched; destroying nothing is fine."""
+    lib = _lib.lib
+    out = C.c_void_p()
+    _arg_error(lib.dmm_stream_create_cu_subset(0, 8, 0, 0, None), "every in 1..64")
+    _arg_error(lib.dmm_stream_create_cu_subset(0, 0, 0, 0, C.byref(out)), "every in 1..64")
+    _arg_error(lib.dmm_stream_create_cu_subset(0, 65, 0, 0, C.byref(out)), "every in 1..64")
+    _arg_error(lib.dmm_stream_create_cu_subset(0, 8, 8, 0, C.byref(out)), "phase in -every..every-1")
+    _arg_error(lib.dmm_stream_create_cu_subset(0, 8, -9, 0, C.byref(out)), "phase in -every..every-1")
+    assert lib.dmm_stream_destroy(None) == 0
+    for name in (b"sht_grid", b"ml_cu_split", b"dirty_cu_split"):
+        _arg_error(lib.dmm_ctx_set_option(None, name, 1), "NULL")

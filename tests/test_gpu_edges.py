@@ -401,3 +401,35 @@ def test_allgather_map_through_the_c_abi_on_a_one_rank_communicator():
         assert torch.equal(full, shard)
     finally:
         _lib.check(lib.dmm_comm_destroy(comm))
+
+
+def test_a_cu_subset_stream_runs_the_transform_to_the_same_bits():
+    """`dmm_stream_create_cu_subset` (round 5): a context on a stream confined to every 8th compute unit, and one on the
+    complement, give the maps of the unconfined stream bit for bit -- where a kernel runs changes nothing it computes."""
+    import ctypes as C
+
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.device import Context, ptr
+
+    ctx = Context.get()
+    gen = torch.Generator(device=ctx.device).manual_seed(3)
+    nf, lmax, nside = 3, 64, 32
+    alm = torch.randn((nf, 4, lmax + 1, lmax + 1), dtype=torch.complex128, device=ctx.device, generator=gen)
+    ref = ctx.empty((nf, 4, 12 * nside * nside), np.float64)
+    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), nf, 4, lmax, lmax, nside, ptr(ref)))
+    ctx.sync()
+    for every, phase in ((8, 0), (8, -1), (1, 0)):
+        h = C.c_void_p()
+        _lib.check(_lib.lib.dmm_stream_create_cu_subset(ctx.device_index, every, phase, 0, C.byref(h)))
+        st = torch.cuda.ExternalStream(int(h.value), device=ctx.device)
+        side = Context(ctx.device_index, st)
+        out = ctx.empty((nf, 4, 12 * nside * nside), np.float64)
+        side.wait_for(torch.cuda.current_stream(ctx.device))
+        side.uses(alm, out)
+        _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm), nf, 4, lmax, lmax, nside, ptr(out)))
+        side.sync()
+        assert torch.equal(out, ref), (every, phase)
+        del side, st
+        _lib.check(_lib.lib.dmm_stream_destroy(h))
