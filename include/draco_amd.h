@@ -75,7 +75,8 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  * ordinary stream of the given HIP priority.  For stages that run BESIDE the HBM-bound solves on a stream of their own --
  * the reference has no counterpart (its stages run one after the other, mapmaker.py:62-118): confined to a few CUs the
  * compute-bound alm2map of finished frequencies leaves the others' registers and LDS to the solve kernel.
- * Hand it to dmm_ctx_set_stream / torch.cuda.ExternalStream; destroy with dmm_stream_destroy when nothing uses it. */
+ * Hand it to dmm_ctx_set_stream / torch.cuda.ExternalStream; destroy with dmm_stream_destroy when nothing uses it -- a
+ * caching allocator that was told `record_stream(tensor, stream)` uses it until that tensor's block is reused. */
 int dmm_stream_create_cu_subset(int device, int every, int phase, int priority, void** hip_stream);
 int dmm_stream_destroy(void* hip_stream);
 /* Options.  Two kinds:

@@ -427,9 +427,47 @@ def test_a_cu_subset_stream_runs_the_transform_to_the_same_bits():
         side = Context(ctx.device_index, st)
         out = ctx.empty((nf, 4, 12 * nside * nside), np.float64)
         side.wait_for(torch.cuda.current_stream(ctx.device))
-        side.uses(alm, out)
+        # (no `record_stream` on a stream that is about to be destroyed: the caching allocator would record an event on it
+        # when the tensors die; `alm` and `out` outlive the synchronisation below instead)
         _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm), nf, 4, lmax, lmax, nside, ptr(out)))
-        side.sync()
+        st.synchronize()
         assert torch.equal(out, ref), (every, phase)
+        _lib.check(_lib.lib.dmm_ctx_destroy(side.handle))
+        side.handle = None
         del side, st
+        torch.cuda.synchronize()
         _lib.check(_lib.lib.dmm_stream_destroy(h))
+
+
+def test_cu_split_options_change_no_result():
+    """`dirty_cu_split` / `ml_cu_split` (round 5's A/B knobs: the call's launches on a library-owned stream confined to a
+    subset of the compute units, ordered with the caller's stream by events): the a_lm of the Dirty and the ML maker are
+    the same bits with and without them, and agree with the oracle."""
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import DirtyMapMaker, MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import SyntheticProvider
+    from draco_amd.device import Context
+
+    ctx = Context.get()
+    tel = _tel(2, 12)
+    bt = SyntheticProvider(tel, seed=4)
+    rng = np.random.default_rng(4)
+    shape = (13, 2, 2, tel.npairs)
+    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    mw = rng.uniform(0.5, 1.5, shape) * 30
+    mm = containers.MModes(mmax=12, freq=tel.frequencies, stack=tel.npairs)
+    mm.vis[:] = mv
+    mm.weight[:] = mw
+    beam = lambda m, f: osyn.beam_tile(4, m, f, tel.npairs, 4, 12)  # noqa: E731
+    for cls, kind, opt, tol in ((DirtyMapMaker, "dirty", b"dirty_cu_split", 1e-12), (MaximumLikelihoodMapMaker, "ml", b"ml_cu_split", 1e-8)):
+        task = cls()
+        task.setup(bt)
+        ref = task.alm_square(task.make_alm(mm))
+        try:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt, 8))
+            got = task.alm_square(task.make_alm(mm))
+        finally:
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt, 0))
+        assert np.array_equal(got, ref), kind
+        assert _rel(got, omm.solve_alm(kind, beam, mv, mw, 12, 12, [0, 1])) < tol, kind
