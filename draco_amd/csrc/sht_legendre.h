@@ -954,26 +954,40 @@ __global__ __launch_bounds__(NT, NFG == 2 ? 1 : 512 / NT) void k_leg_anal_mfma(L
           qc4[q] = cr[6];
         }
         // kAnL steps of the recurrence -> slab rows 1..kAnL
+        if (c0 > 0 && !__any(nsc > 0)) {
+          // no lane of the wave carries 2^-800 blocks any more (wave-uniform; lanes only ever leave that state): three f64
+          // operations per step, no test, no select -- a ring that takes no part carries lam = lam_prev = 0 and stays
+          // there, the steps beyond lmax run on the last coefficient row and their rows of a_lm are never written
 #pragma unroll
-        for (int kk = 0; kk < kAnL; ++kk) {
-          const int k = c0 + kk;
-          const double2 rr2 = rrtab[wave][kk];  // broadcast read
-          const double ra = rr2.x, rb = rr2.y;
-          double le = 0.0;
-          if (k < nl) {
-            if (k > 0 && nsc >= 0) {
-              const double nxt = x * lam * ra - lam_prev * rb;
-              lam_prev = lam;
-              lam = nxt;
-              if (nsc > 0 && fabs(lam) > kBig) {
-                lam *= kSmallStep;
-                lam_prev *= kSmallStep;
-                --nsc;
-              }
-            }
-            if (nsc == 0) le = lam;
+          for (int kk = 0; kk < kAnL; ++kk) {
+            const double2 rr2 = rrtab[wave][kk];  // broadcast read
+            const double nxt = x * lam * rr2.x - lam_prev * rr2.y;
+            lam_prev = lam;
+            lam = nxt;
+            sl[(1 + kk) * kAnPitch + lane] = lam;
           }
-          sl[(1 + kk) * kAnPitch + lane] = le;
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < kAnL; ++kk) {
+            const int k = c0 + kk;
+            const double2 rr2 = rrtab[wave][kk];  // broadcast read
+            const double ra = rr2.x, rb = rr2.y;
+            double le = 0.0;
+            if (k < nl) {
+              if (k > 0 && nsc >= 0) {
+                const double nxt = x * lam * ra - lam_prev * rb;
+                lam_prev = lam;
+                lam = nxt;
+                if (nsc > 0 && fabs(lam) > kBig) {
+                  lam *= kSmallStep;
+                  lam_prev *= kSmallStep;
+                  --nsc;
+                }
+              }
+              if (nsc == 0) le = lam;
+            }
+            sl[(1 + kk) * kAnPitch + lane] = le;
+          }
         }
         cvr = cvr_next;
         // contraction over the wave's rings, four per step
