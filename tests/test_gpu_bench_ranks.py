@@ -44,3 +44,23 @@ def test_bench_refuses_more_ranks_than_gpus():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--no-cpu-baseline"], cwd=ROOT,
                          env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "GPU(s) visible" in res.stderr and not res.stdout.strip()
+
+
+def test_bench_default_command_shape_prints_one_short_parsable_last_line():
+    """What round 4 got wrong: the driver keeps the tail of stdout and parses the LAST line.  The default command shape (N = 1,
+    extras and CPU baseline on) at cfg 2 with a short CPU budget: the last line of stdout is JSON, under 4 KB, carries the
+    contract's keys, `roofline` and `cpu_baseline`, and names the file the full record went to -- which exists and holds more."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--config", "2", "--cpu-seconds", "4", "--pool-freqs", "16"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    tail = res.stdout[-4096:]
+    line = tail.splitlines()[-1]
+    assert len(line) < 4096 and res.stdout.rstrip("\n").endswith(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["repeats"] >= 1 and len(d["cpu_baseline"]["sample"]) <= 200
+    full = json.load(open(os.path.join(ROOT, d["extra_file"])))
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and "arms" in full["cpu_baseline"] and "extra" in full
