@@ -34,7 +34,7 @@ _IN_FLIGHT: dict = {}
 
 
 def _alm2map_neighbourly(c, alm, nfreq, lmax, mmax, nside, maps):
-    """``dmm_alm2map`` of a map-maker: always with the FIRST MFMA form of the Legendre synthesis (``sht_variant`` bit 6).
+    """``dmm_alm2map`` of a map-maker: always with the FIRST MFMA form of the Legendre synthesis (option ``sht_synth_form`` = 1).
 
     The map-makers run this transform beside the HBM-bound solve kernel by default (side stream), where the pipelined
     synthesis kernel of round 5 -- 256 / 512 registers per lane -- starves the solve kernel of wave slots (2000 -> 1076
@@ -44,13 +44,13 @@ def _alm2map_neighbourly(c, alm, nfreq, lmax, mmax, nside, maps):
     """
     lib = _lib.lib
     pinned = getattr(c, "sht_variant_pin", None)
-    if pinned is None:
-        _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_variant", 64))
+    if pinned is None:  # (an option of its own: whatever `sht_variant` the caller has set on the context stays as it is)
+        _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_synth_form", 1))
     try:
         _lib.check(lib.dmm_alm2map(c.handle, ptr(alm), nfreq, 4, lmax, mmax, nside, ptr(maps)))
     finally:
         if pinned is None:
-            _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_variant", 0))
+            _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_synth_form", 0))
 
 
 def _bound_run_ahead(ctx, depth):

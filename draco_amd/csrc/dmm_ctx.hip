@@ -194,6 +194,7 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_outer_sweeps")) c->opt_ml_outer_sweeps = (int)value;
   else if (!strcmp(name, "sht_variant")) c->opt_sht_variant = (int)value;
   else if (!strcmp(name, "sht_grid")) c->opt_sht_grid = (int)value;
+  else if (!strcmp(name, "sht_synth_form")) c->opt_sht_synth_form = (int)value;
   else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
   else if (!strcmp(name, "ml_null")) c->opt_ml_null = (int)value;
   else if (!strcmp(name, "ml_rank_stop")) c->opt_ml_rank_stop = (int)value;

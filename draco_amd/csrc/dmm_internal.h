@@ -50,6 +50,7 @@ struct dmm_ctx {
   int opt_project_variant = 0;
   int opt_ml_inner_sweeps = 0, opt_ml_outer_sweeps = 0;
   int opt_sht_variant = 0;
+  int opt_sht_synth_form = 0;  // 1: the first MFMA form of the Legendre synthesis whatever sht_variant says (the map-makers' alm2map)
   int opt_sht_grid = 0;  // > 0: the Legendre synthesis as that many resident blocks walking the (m, ring chunk, frequency group) items
   int opt_ml_eigen = 0;                    // 0: by batch size (tridiagonalisation + QL for large batches, blocked Jacobi for a few matrices); 1: Jacobi; 4: tridiagonal; 2: tridiagonal with full-matrix trailing updates; 3: tridiagonal with QL made to give up (Jacobi fallback)
   int64_t opt_ml_ws_mib = 0, opt_wiener_ws_mib = 0;  // workspace the ML / Wiener solves size themselves for (0: 20 / 6 GiB)

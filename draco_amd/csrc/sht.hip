@@ -243,7 +243,7 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
     lp.stamps = stamps_d;
 #endif
     const int nx = g.mmax + 1, G = ctx->opt_sht_grid;
-    if (ctx->opt_sht_variant & 64) {  // bit 6: the first MFMA form (rounds 1-4), the A/B of the pipelined one
+    if ((ctx->opt_sht_variant & 64) || ctx->opt_sht_synth_form == 1) {  // bit 6 / "sht_synth_form" = 1: the first MFMA form (rounds 1-4)
       const int nz = (nf + kLegF - 1) / kLegF;
       if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma_walk, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
       else hipLaunchKernelGGL(k_leg_synth_mfma, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);

@@ -88,7 +88,7 @@ int dmm_stream_destroy(void* hip_stream);
  *    "ml_inner_sweeps" / "ml_outer_sweeps" (iteration caps of the Jacobi fallback).
  * "dirty_variant" (0 = default), "grid_mult",
  * "project_variant", "project_grid_mult", "ml_inner_sweeps", "ml_outer_sweeps", "sht_variant",
- * (sht_variant: bits 0-1 synthesis form, bit 2 direct ring sums, bit 3 vector-ALU Legendre kernels, bit 4 the 8-wave analysis block, bit 5 m = blockIdx.x instead of the XCD-aware block -> m map, bit 6 the first MFMA synthesis kernel (rounds 1-4) instead of the pipelined one, bit 7 the pipelined one with 4 instead of 8 frequencies per block, bit 9 the Legendre analysis with 8 instead of 4 frequencies per block), "sht_grid" (> 0: the Legendre synthesis as that many resident blocks walking the same work items; an A/B),
+ * (sht_variant: bits 0-1 synthesis form, bit 2 direct ring sums, bit 3 vector-ALU Legendre kernels, bit 4 the 8-wave analysis block, bit 5 m = blockIdx.x instead of the XCD-aware block -> m map, bit 6 the first MFMA synthesis kernel (rounds 1-4) instead of the pipelined one, bit 7 the pipelined one with 4 instead of 8 frequencies per block, bit 9 the Legendre analysis with 8 instead of 4 frequencies per block), "sht_grid" (> 0: the Legendre synthesis as that many resident blocks walking the same work items; an A/B), "sht_synth_form" (1: the first MFMA form of the Legendre synthesis whatever sht_variant says -- what the shipped map-makers set around their own dmm_alm2map; same sums, 1e-12 of the map's scale apart),
  * "ml_shortcut" (0 = on; 2 = always eigen-decompose; 3 = telescope-side systems only),
  * "ml_eigen" (eigen path of the ML solve: 0 = chosen by batch size; 4 = Householder tridiagonalisation + QL kept
  * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give

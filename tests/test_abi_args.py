@@ -165,5 +165,5 @@ def test_round5_stream_entry_points_check_their_arguments():
     _arg_error(lib.dmm_stream_create_cu_subset(0, 8, 8, 0, C.byref(out)), "phase in -every..every-1")
     _arg_error(lib.dmm_stream_create_cu_subset(0, 8, -9, 0, C.byref(out)), "phase in -every..every-1")
     assert lib.dmm_stream_destroy(None) == 0
-    for name in (b"sht_grid", b"ml_cu_split", b"dirty_cu_split"):
+    for name in (b"sht_grid", b"sht_synth_form", b"ml_cu_split", b"dirty_cu_split"):
         _arg_error(lib.dmm_ctx_set_option(None, name, 1), "NULL")
