@@ -243,11 +243,15 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
     lp.stamps = stamps_d;
 #endif
     const int nx = g.mmax + 1, G = ctx->opt_sht_grid;
-    if ((ctx->opt_sht_variant & 64) || ctx->opt_sht_synth_form == 1) {  // bit 6 / "sht_synth_form" = 1: the first MFMA form (rounds 1-4)
+    // the pipelined kernel addresses a block's a_lm columns with 32-bit byte offsets from one base: its frequency groups must
+    // span less than 4 GiB (8 frequencies: lmax <= 2895; 4: lmax <= 4095) -- beyond that the first form, with 64-bit pointers
+    const int64_t col_bytes = (int64_t)4 * n_m * (g.lmax + 1) * (int64_t)sizeof(double2);  // one frequency's four polarisations
+    const bool fits8 = 2 * kLegF * col_bytes < ((int64_t)1 << 32), fits4 = kLegF * col_bytes < ((int64_t)1 << 32);
+    if ((ctx->opt_sht_variant & 64) || ctx->opt_sht_synth_form == 1 || !fits4) {  // bit 6 / "sht_synth_form" = 1: the first MFMA form (rounds 1-4)
       const int nz = (nf + kLegF - 1) / kLegF;
       if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma_walk, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
       else hipLaunchKernelGGL(k_leg_synth_mfma, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
-    } else if (ctx->opt_sht_variant & 128) {  // bit 7: one frequency group per block, two waves per SIMD
+    } else if ((ctx->opt_sht_variant & 128) || !fits8) {  // bit 7: one frequency group per block, two waves per SIMD
       const int nz = (nf + kLegF - 1) / kLegF;
       if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma2_walk<1>, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
       else hipLaunchKernelGGL(k_leg_synth_mfma2<1>, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
