@@ -275,6 +275,7 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
   rp.b = b;
   rp.map = map;
   rp.map_ref = nullptr;
+  rp.radix8 = (ctx->opt_sht_variant & 2048) ? 0 : 1;  // bit 11: the radix-4 passes of rounds 1-4 (A/B)
   rp.npix = 12LL * g.nside * g.nside;
   constexpr int NROWS = NPOL == 4 ? 2 : 1;  // complex transforms per ring (two polarisations each)
   const int force_direct = ctx->opt_sht_variant & 4;
@@ -305,6 +306,7 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
   rp.b = b;
   rp.map = const_cast<double*>(map);
   rp.map_ref = map_ref;
+  rp.radix8 = (ctx->opt_sht_variant & 2048) ? 0 : 1;  // bit 11: the radix-4 passes of rounds 1-4 (A/B)
   rp.npix = 12LL * g.nside * g.nside;
   constexpr int NROWS = NPOL == 4 ? 2 : 1;
   const int force_direct = ctx->opt_sht_variant & 4;

@@ -14,6 +14,7 @@ struct RingParams {
   int64_t npix;
   const double* map_ref;  // analysis only, or nullptr: the field analysed is map_ref - map (the residual of a Jacobi iteration of
                           // map2alm, formed on the way in instead of by a pass of its own over the maps)
+  int radix8;             // 1 (default): the in-LDS transforms with three stages per pass (fft_dif8 / fft_dit8); 0: two (sht_variant bit 11)
 };
 
 // A launch covers one CLASS of rings that share an FFT length:
@@ -152,9 +153,10 @@ __global__ void k_fill_ring_tables(const double* phi0, int nring, int mmax, doub
 // forward DFT_N of the NROW rows in l.buf (natural order, already multiplied by the chirp and
 // zero-padded to M when BLUE).  Afterwards X_k is ring_dft_at(l, r, k).
 template <int NROW, bool BLUE>
-__device__ __forceinline__ void ring_dft(const RingLds& l, const double2* bfilt, int M, int logM) {
+__device__ __forceinline__ void ring_dft(const RingLds& l, const double2* bfilt, int M, int logM, bool radix8 = false) {
   const int P = M + 1;
-  dmm_fft::fft_dif<double, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
+  if (radix8) dmm_fft::fft_dif8<double, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
+  else dmm_fft::fft_dif<double, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
   if (BLUE) {
     for (int idx = threadIdx.x; idx < NROW * M; idx += kFftThreads) {
       const int r = idx / M, k = idx - r * M;
@@ -162,7 +164,8 @@ __device__ __forceinline__ void ring_dft(const RingLds& l, const double2* bfilt,
       l.buf[r * P + k] = dmm_fft::cmul<double>(l.buf[r * P + k], {fk.x, fk.y});
     }
     __syncthreads();
-    dmm_fft::fft_dit<double, true, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
+    if (radix8) dmm_fft::fft_dit8<double, true, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
+    else dmm_fft::fft_dit<double, true, kFftThreads>(l.buf, l.tw, NROW, M, logM, P);
   }
 }
 
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_synth_fft(RingParams p, Ri
   }
   __syncthreads();
   const double2* bfilt = BLUE ? p.g.bfilt + p.g.bf_off[rc.belt ? 0 : rc.r_lo + ((int)blockIdx.x >> 1)] : nullptr;
-  ring_dft<NROW, BLUE>(l, bfilt, M, rc.logM);
+  ring_dft<NROW, BLUE>(l, bfilt, M, rc.logM, p.radix8 != 0);
   const int64_t base = p.g.start[ring];
   for (int j = threadIdx.x; j < n; j += kFftThreads) {
 #pragma unroll
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(kFftThreads) void k_ring_anal_fft(RingParams p, Rin
   }
   __syncthreads();
   const double2* bfilt = BLUE ? p.g.bfilt + p.g.bf_off[rc.belt ? 0 : rc.r_lo + ((int)blockIdx.x >> 1)] : nullptr;
-  ring_dft<NROW, BLUE>(l, bfilt, M, rc.logM);
+  ring_dft<NROW, BLUE>(l, bfilt, M, rc.logM, p.radix8 != 0);
   const int nm = p.g.mmax + 1;
   const double2* phase = p.g.phase + (int64_t)ring * nm;
   const double w = 4.0 * M_PI / (double)p.npix;
