@@ -614,6 +614,10 @@ def dense_day(args, kind):
     for opt in ("ml_reduce", "gram_stage", "wiener_overlap", "ml_chase_grid", "ml_null", "ml_chase_layout", "ml_rank_stop", "ml_chase_split", "ml_cu_split"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
         if os.environ.get("DMM_" + opt.upper()):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt.encode(), int(os.environ["DMM_" + opt.upper()])))
+    if os.environ.get("DMM_ML_WS_CAP_MIB"):  # A/B: cap the solvers' workspace offer (chunks of fewer matrices)
+        _cap = int(os.environ["DMM_ML_WS_CAP_MIB"])
+        _offer = _solve.SolveEngine._offer_workspace
+        _solve.SolveEngine._offer_workspace = lambda self, option, cap_mib: _offer(self, option, min(cap_mib, _cap))
     tiles = args.tiles or "screen"
     nfreq_cfg, nra, lmax, nside = cfg["nfreq"], cfg["nra"], cfg["lmax"], cfg["nside"]
     nfreq = args.freqs if args.freqs > 0 else nfreq_cfg

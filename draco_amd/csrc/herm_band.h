@@ -48,15 +48,24 @@ __host__ __device__ constexpr size_t sb_chase_lds(int n) { return ((size_t)(kSbB
 // the same for the bank-spread layout of round 4 (pitch n + 1, diagonals 2.. shifted by 6 entries, bulge pitch 22): used where it fits
 __host__ __device__ constexpr size_t sb_chase_lds2(int n) { return ((size_t)(kSbB + 1) * (n + 1) + 6 + (size_t)(n / kSbB + 2) * 22) * sizeof(double2); }
 
-// where a matrix's work arrays live in its log region (single pointers: a struct of them ends up in scratch / LDS)
+// where a matrix's work arrays live in its log region (single pointers: a struct of them ends up in scratch / LDS).
+// Deferred updates (tp.nb >= 1 of them pending at most): rings of nb + 1 reflector arrays V_k and nb arrays X_k.
+constexpr int kSbNB = 4;  // most pending updates the kernels are built for
+__host__ __device__ __forceinline__ int64_t sb_slot(int n) { return (int64_t)n * kSbB; }
 __device__ __forceinline__ double2* sb_base(const TdParams& tp, int mat) { return tp.log_cs + (int64_t)mat * tp.log_stride; }
-__device__ __forceinline__ double2* sb_V(const TdParams& tp, int mat, int k) { return sb_base(tp, mat) + (int64_t)(k & 1) * tp.d.Np * kSbB; }  // V_k
-__device__ __forceinline__ double2* sb_X(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)2 * tp.d.Np * kSbB; }
-__device__ __forceinline__ double2* sb_Z(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)3 * tp.d.Np * kSbB; }
-// [waves of the last sweep][256]: their pieces of V^H Z (16 x 16 real blocks [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]])
-__device__ __forceinline__ double* sb_Mp(const TdParams& tp, int mat) { return reinterpret_cast<double*>(sb_base(tp, mat) + (int64_t)4 * tp.d.Np * kSbB); }
-// lower-triangle sweeps (k_sb_sweep_lo): the row contributions to Z of every 64-column block, [block][n][8 re | 8 im]
+__device__ __forceinline__ double2* sb_V(const TdParams& tp, int mat, int k) { return sb_base(tp, mat) + (int64_t)(k % (tp.nb + 1)) * sb_slot(tp.d.Np); }  // V_k
+__device__ __forceinline__ double2* sb_X(const TdParams& tp, int mat, int k) { return sb_base(tp, mat) + (int64_t)(tp.nb + 1 + k % tp.nb) * sb_slot(tp.d.Np); }  // X_k
+__device__ __forceinline__ double2* sb_Z(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)(2 * tp.nb + 1) * sb_slot(tp.d.Np); }
+// the diagonal of the trailing matrix with every finished update applied (the rank stop's trace; the stored diagonal lags by the pending ones)
+__device__ __forceinline__ double* sb_dg(const TdParams& tp, int mat) { return reinterpret_cast<double*>(sb_base(tp, mat) + (int64_t)(2 * tp.nb + 2) * sb_slot(tp.d.Np)); }
+// [column blocks of the last sweep][256]: their pieces of V^H Z (16 x 16 real blocks [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]])
+__device__ __forceinline__ double* sb_Mp(const TdParams& tp, int mat) { return sb_dg(tp, mat) + tp.d.Np; }
+// the row contributions to Z of every 64-column block, [block][n][8 re | 8 im]
 __device__ __forceinline__ double* sb_Zp(const TdParams& tp, int mat) { return sb_Mp(tp, mat) + (int64_t)(tp.d.Np / 16) * 256; }
+// double2 units the arrays above take at the head of the log region
+__host__ __device__ constexpr int64_t sb_head(int n, int nb) {
+  return (int64_t)(2 * nb + 2) * n * kSbB + n / 2 + (int64_t)(n / 16) * 128 + (int64_t)((n + 63) / 64) * n * 8;
+}
 __device__ __forceinline__ double2* sb_T(const TdParams& tp, int mat) { return sb_base(tp, mat) + tp.log_stride - sb_tail(tp.d.Np); }
 __device__ __forceinline__ double2* sb_rlog(const TdParams& tp, int mat) { return sb_T(tp, mat) + (int64_t)sb_npanel(tp.d.Np) * 64; }
 
@@ -151,12 +160,12 @@ __device__ __forceinline__ void sb_block_sums(double (&x)[NV], double* out) {
   __syncthreads();
 }
 
-// the operand arrays V[2], X of every matrix start from zero (their rows outside the support must read as zero)
+// the operand rings V, X of every matrix start from zero (their rows outside the support must read as zero)
 __global__ __launch_bounds__(kThreads) void k_sb_zero(TdParams tp) {
   const int n = tp.d.Np;
   const int mat = tp.d.msel ? tp.d.msel[blockIdx.y] : blockIdx.y;
   double2* base = tp.log_cs + (int64_t)mat * tp.log_stride;
-  const int64_t cnt = (int64_t)3 * n * kSbB;
+  const int64_t cnt = (int64_t)(2 * tp.nb + 1) * n * kSbB;
   for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * kThreads) base[e] = make_double2(0.0, 0.0);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double* st = sb_state(tp, mat);
@@ -166,8 +175,20 @@ __global__ __launch_bounds__(kThreads) void k_sb_zero(TdParams tp) {
 }
 
 // ---------------------------------------------------------------------------------------------------- stage 1: panel
-// Panel k (tp.j), one block per matrix.  k > 0: finishes update k-1 (X = Z T - V (T^H M T) / 2, M = V^H Z) and applies it
-// to the panel's own columns on the fly; then the diagonal block goes back to A, the sub-panel below it is QR-factored
+// Deferred updates.  The two-sided update of a panel, A -= V X^H + X V^H, is a read AND a write of the whole trailing
+// matrix; the product Z = A V the next panel needs is a read.  So the updates stay PENDING, up to tp.nb of them: the
+// stored matrix lags behind, the sweeps between two flushes only read it (k_sb_sweep_lo<0>), and what they produce is
+// corrected here from the pending operands (LAPACK's zlatrd idea, applied to the band reduction):
+//     Z_k = A_stored V_k - sum_p [ V_p (X_p^H V_k) + X_p (V_p^H V_k) ]                 p = the pending panels
+//     M_k = V_k^H Z_k = M_raw - sum_p [ S2_p^H S1_p + S1_p^H S2_p ],   S1_p = X_p^H V_k,  S2_p = V_p^H V_k
+//     P_k = A_stored[:, panel k] - sum_p [ X_p V_p[panel]^H + V_p X_p[panel]^H ]
+// Every nb-th sweep (k_sb_sweep_lo<nb>) applies all pending updates while it forms Z: nb - 1 reads + one read-and-write
+// of the trailing matrix per nb panels where the undeferred form (nb = 1: rounds 3-5) has nb of the latter.
+// NumPy twin in the kernels' order of events: tools/proto/lazy_band.py.
+//
+// Panel k (tp.j), one block per matrix; tp.p0 = the oldest pending panel (p0 .. k-2 finished, k-1 finished here).
+// k > 0: finishes update k-1 (X = Z T - V (T^H M T) / 2) and applies every pending update to the panel's own columns
+// on the fly; then the diagonal block goes back to A, the sub-panel below it is QR-factored
 // (reflectors into the upper triangle of A and the operand array of the next sweep, R into the lower band, T aside).
 // k == npanel: only the trailing 8 x 8 block is finished.  Rows of a thread: j0 + threadIdx.x + 256 u.
 constexpr int kSbRows = 4;  // most rows per thread: orders up to 1024
@@ -181,21 +202,24 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   __shared__ __align__(16) double2 s_a[1][kSbB];  // the pivot row of the current column
   __shared__ __align__(16) double2 s_M[64];
   __shared__ __align__(16) double2 s_T[64], s_S[64], s_tmp[64];
-  __shared__ __align__(16) double2 s_vrow[kSbB][kSbB], s_xrow[kSbB][kSbB];
-  __shared__ double s_red[256];
+  __shared__ __align__(16) double2 s_vrow[kSbNB][kSbB][kSbB], s_xrow[kSbNB][kSbB][kSbB];  // rows [j0, o) of the pending V_p, X_p
+  __shared__ __align__(16) double2 s_S12[kSbNB - 1][16][kSbB];  // per pending p < k-1: S1_p = X_p^H V_{k-1} (rows 0-7), S2_p = V_p^H V_{k-1} (8-15)
+  __shared__ double s_red[4 * 512];  // (block sums; the four waves' pieces of the S products)
   __shared__ double s_dg[kSbB];
   const DenseParams& p = tp.d;
   const int n = p.Np, k = tp.j, K = sb_npanel(n);
   const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
   double2* A = p.A + (int64_t)mat * n * n;
-  double2* Vold = sb_V(tp, mat, k + 1);  // V_{k-1}
-  double2* Vnew = sb_V(tp, mat, k);      // V_k (holds V_{k-2} on entry)
-  double2* const Xa = sb_X(tp, mat);
+  double2* Vold = sb_V(tp, mat, k + tp.nb);  // V_{k-1}  ((k - 1) mod (nb + 1))
+  double2* Vnew = sb_V(tp, mat, k);          // V_k (holds V_{k-nb-1} on entry)
+  double2* const Xa = sb_X(tp, mat, k + tp.nb - 1);  // X_{k-1}
   const double2* const Za = sb_Z(tp, mat);
   double2* const Ta = sb_T(tp, mat);
   const double* const Mpa = sb_Mp(tp, mat);
   const int j0 = kSbB * k, o = j0 + kSbB;
   const int t = threadIdx.x;
+  const int p0 = tp.p0;            // pending: p0 .. k-1
+  const int nold = k - 1 - p0;     // of them finished before this launch (X known): p0 .. k-2
   if (sb_stopped(tp, mat)) return;  // the rank stop cut this matrix off at an earlier panel
 #ifdef SB_TIMING
   long long sb_t[8];
@@ -215,19 +239,72 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   }
   bool last = k == K;
 
-  // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
+  // ---- finish update k-1
   if (k > 0) {
+    // rows [j0, o) of the older pending operands (the look-ahead below needs them; this launch zeroes them afterwards)
+    for (int idx = t; idx < nold * 64; idx += kThreads) {
+      const int pi = idx >> 6, c = (idx >> 3) & 7, q = idx & 7;
+      s_vrow[pi][c][q] = sb_V(tp, mat, p0 + pi)[(int64_t)(j0 + c) * kSbB + q];
+      s_xrow[pi][c][q] = sb_X(tp, mat, p0 + pi)[(int64_t)(j0 + c) * kSbB + q];
+    }
+    // S products of the older pending panels with V_{k-1}, on the matrix cores: rows in steps of 4 over the block's waves,
+    // A operand = one entry of [X_p | V_p] per lane (real and imaginary plane: two products), B operand = [Re V | Im V]
+    if (nold > 0) {
+      const int lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
+      for (int pi = 0; pi < nold; ++pi) {
+        const double2* const Wp = li < 8 ? sb_X(tp, mat, p0 + pi) : sb_V(tp, mat, p0 + pi);
+        v4d d1 = (v4d){0.0, 0.0, 0.0, 0.0}, d2 = d1;
+        for (int r = j0 + 4 * wave + lk; r < n; r += 16) {
+          const double2 w = Wp[(int64_t)r * kSbB + (li & 7)];
+          const double2 v1 = Vold[(int64_t)r * kSbB + (li & 7)];
+          const double b = li < 8 ? v1.x : v1.y;
+          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, b, d1, 0, 0, 0);
+          d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, b, d2, 0, 0, 0);
+        }
+        __syncthreads();  // (s_red may still be read from the previous p)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {  // D[row (lane >> 4) + 4 reg][column lane & 15]
+          s_red[wave * 512 + (lk + 4 * reg) * 16 + li] = d1[reg];
+          s_red[wave * 512 + 256 + (lk + 4 * reg) * 16 + li] = d2[reg];
+        }
+        __syncthreads();
+        if (t < 128) {  // S[i][c] = (D1[i][c] + D2[i][8 + c]) + i (D1[i][8 + c] - D2[i][c]), summed over the waves in wave order
+          const int i = t >> 3, c = t & 7;
+          double re = 0.0, im = 0.0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            re += s_red[w * 512 + i * 16 + c] + s_red[w * 512 + 256 + i * 16 + 8 + c];
+            im += s_red[w * 512 + i * 16 + 8 + c] - s_red[w * 512 + 256 + i * 16 + c];
+          }
+          s_S12[pi][i][c] = make_double2(re, im);
+        }
+      }
+      __syncthreads();
+    }
+    // M = V^H Z arrives as one 16 x 16 real block per column block of sweep k-1 (k_sb_sweep_lo's epilogue)
     const int org_prev = (kSbB * k) & ~15;
-    const int nw = tp.sb_lower ? (n - org_prev + 63) / 64 : (n - org_prev) / 16;  // pieces of M: one per column block (lower sweeps) / per wave
+    const int nw = (n - org_prev + 63) / 64;
     const double* const Zpa = sb_Zp(tp, mat);
     double acc = 0.0;
     for (int w = 0; w < nw; ++w) acc += Mpa[(int64_t)w * 256 + t];
+    __syncthreads();
     s_red[t] = acc;
     if (t < 64) s_T[t] = Ta[(int64_t)(k - 1) * 64 + t];
     __syncthreads();
     const int q = (t >> 3) & 7, qq = t & 7;
-    if (t < 64)  // M[q][q'] = (Vr'Zr + Vi'Zi) + i (Vr'Zi - Vi'Zr)
-      s_M[t] = make_double2(s_red[q * 16 + qq] + s_red[(8 + q) * 16 + 8 + qq], s_red[q * 16 + 8 + qq] - s_red[(8 + q) * 16 + qq]);
+    if (t < 64) {  // M[q][q'] = (Vr'Zr + Vi'Zi) + i (Vr'Zi - Vi'Zr), minus the pending updates' share
+      double2 m = make_double2(s_red[q * 16 + qq] + s_red[(8 + q) * 16 + 8 + qq], s_red[q * 16 + 8 + qq] - s_red[(8 + q) * 16 + qq]);
+      for (int pi = 0; pi < nold; ++pi) {
+        double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          cfmac(a, s_S12[pi][8 + u][q], s_S12[pi][u][qq]);
+          cfmac(a, s_S12[pi][u][q], s_S12[pi][8 + u][qq]);
+        }
+        m = csub(m, a);
+      }
+      s_M[t] = m;
+    }
     __syncthreads();
     if (t < 64) {  // tmp = M T
       double2 a = make_double2(0.0, 0.0);
@@ -244,7 +321,8 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     }
     __syncthreads();
     SB_T(1);
-    // X = Z T - V S for the rows >= j0, one row per thread and pass.  (The memory clobber keeps the 128 table entries in
+    double* const dgp = sb_dg(tp, mat);
+    // X = Z T - V S for the rows >= j0, one row per thread and pass.  (The memory clobber keeps the table entries in
     // LDS: hoisted out of the row loop as loop invariants they are every register a thread can have.)
 #pragma unroll 1
     for (int r = j0 + t; r < n; r += kThreads) {
@@ -255,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
         z[c] = Za[(int64_t)r * kSbB + c];
         v[c] = Vold[(int64_t)r * kSbB + c];
       }
-      if (tp.sb_lower) {  // + the row contributions of the column blocks left of this row's tile (in block order)
+      {  // + the row contributions of the column blocks left of this row's tile (in block order)
         const int nb = ((r - org_prev) / 16 * 16 + 63) / 64;
         // (ROWS = 3, the kernel of the early panels -- 256 registers anyway --: three blocks' partials in flight at a time.
         // One at a time, a row waited for up to twelve round trips to memory in turn: a third of the kernel's time.  The
@@ -281,6 +359,26 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
           }
         }
       }
+      // the sweep multiplied the STORED matrix: minus the pending updates' share, V_p S1_p + X_p S2_p
+#pragma unroll 1
+      for (int pi = 0; pi < nold; ++pi) {
+        asm volatile("" ::: "memory");
+        const double2* const vpp = sb_V(tp, mat, p0 + pi) + (int64_t)r * kSbB;
+        const double2* const xpp = sb_X(tp, mat, p0 + pi) + (int64_t)r * kSbB;
+        double2 vp[8], xp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vp[u] = vpp[u], xp[u] = xpp[u];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            cfma(a, vp[u], s_S12[pi][u][c]);
+            cfma(a, xp[u], s_S12[pi][8 + u][c]);
+          }
+          z[c] = csub(z[c], a);
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         double2 a = make_double2(0.0, 0.0);
@@ -294,17 +392,19 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) Xa[(int64_t)r * kSbB + c] = x[c];
-      if (tp.stop_tol > 0.0) {  // diagonal entry of T_k: A[r][r] - 2 Re sum_q X[r][q] conj(V[r][q])
+      if (tp.stop_tol > 0.0) {  // diagonal entry of T_k: that of T_{k-1} - 2 Re sum_q X[r][q] conj(V[r][q])
         double dg = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) dg += x[c].x * v[c].x + x[c].y * v[c].y;
-        trp += A[(int64_t)r * n + r].x - 2.0 * dg;
+        const double d = (k == 1 ? A[(int64_t)r * n + r].x : dgp[r]) - 2.0 * dg;
+        dgp[r] = d;
+        trp += d;
       }
       if (r < o) {  // the panel's own rows: their V and X rows are what the look-ahead below needs
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          s_vrow[r - j0][c] = v[c];
-          s_xrow[r - j0][c] = x[c];
+          s_vrow[nold][r - j0][c] = v[c];
+          s_xrow[nold][r - j0][c] = x[c];
         }
       }
     }
@@ -317,7 +417,8 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   }
 
   SB_T(2);
-  // ---- the panel's columns with update k-1 applied:  P[r][c] = A[r][j0+c] - sum_q X[r][q] conj(V[j0+c][q]) + V[r][q] conj(X[j0+c][q])
+  // ---- the panel's columns with every pending update applied:
+  //      P[r][c] = A[r][j0+c] - sum_p sum_q X_p[r][q] conj(V_p[j0+c][q]) + V_p[r][q] conj(X_p[j0+c][q])
   double2 P[ROWS][kSbB];
 #pragma unroll
   for (int u = 0; u < ROWS; ++u) {
@@ -325,21 +426,21 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     if (r < n) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) P[u][c] = A[(int64_t)r * n + j0 + c];
-      if (k > 0) {
+#pragma unroll 1
+      for (int pi = 0; pi < k - p0; ++pi) {
         double2 xr[8], vr[8];
+        const double2* const xpp = sb_X(tp, mat, p0 + pi) + (int64_t)r * kSbB;
+        const double2* const vpp = sb_V(tp, mat, p0 + pi) + (int64_t)r * kSbB;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          xr[q] = Xa[(int64_t)r * kSbB + q];
-          vr[q] = Vold[(int64_t)r * kSbB + q];
-        }
-        asm volatile("" ::: "memory");  // (the 128 entries of s_vrow / s_xrow stay in LDS between the rows)
+        for (int q = 0; q < 8; ++q) xr[q] = xpp[q], vr[q] = vpp[q];
+        asm volatile("" ::: "memory");  // (the entries of s_vrow / s_xrow stay in LDS between the rows)
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           double2 a = make_double2(0.0, 0.0);
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            cfma(a, xr[q], cconj2(s_vrow[c][q]));
-            cfma(a, vr[q], cconj2(s_xrow[c][q]));
+            cfma(a, xr[q], cconj2(s_vrow[pi][c][q]));
+            cfma(a, vr[q], cconj2(s_xrow[pi][c][q]));
           }
           P[u][c] = csub(P[u][c], a);
         }
@@ -349,21 +450,22 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       for (int c = 0; c < 8; ++c) P[u][c] = make_double2(0.0, 0.0);
     }
   }
-  __syncthreads();  // everybody has read rows [j0, o) of V_{k-1} / X_{k-1} (from LDS) and its own rows of them
+  __syncthreads();  // everybody has read rows [j0, o) of the pending V_p / X_p (from LDS) and its own rows of them
   SB_T(3);
-  // rows [j0, o): the finished diagonal block goes back; their operand rows are zeroed -- the sweep then leaves every
-  // tile row / column above o alone, whatever its 16-aligned origin
+  // rows [j0, o): the finished diagonal block goes back; their operand rows are zeroed in every pending array -- a sweep
+  // then leaves every tile row / column above o alone, whatever its 16-aligned origin
   if (t < kSbB) {
     const int r = j0 + t;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      A[(int64_t)r * n + j0 + c] = P[0][c];
-      if (k > 0) {
-        Vold[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
-        Xa[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
-      }
-      Vnew[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
+    for (int c = 0; c < 8; ++c) A[(int64_t)r * n + j0 + c] = P[0][c];
+    for (int pi = 0; pi < k - p0; ++pi) {
+      double2* const vpp = sb_V(tp, mat, p0 + pi) + (int64_t)r * kSbB;
+      double2* const xpp = sb_X(tp, mat, p0 + pi) + (int64_t)r * kSbB;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) vpp[c] = make_double2(0.0, 0.0), xpp[c] = make_double2(0.0, 0.0);
     }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) Vnew[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
   }
 #pragma unroll
   for (int c = 0; c < kSbB; ++c)  // (every index into P[][] a compile-time constant: a run-time one sends the whole array to scratch)
@@ -477,121 +579,27 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------- stage 1: sweep
-// Sweep k (tp.j): every 16 x 16 tile of the trailing matrix from the 16-aligned origin below o_k = 8 (k + 1):
-//   C -= V_I X_J^H + X_I V_J^H   (update k-1; operands zero above their support),   Z_J += C^H V'_I   (V' = V_k).
-// A block owns 64 columns, each of its 4 waves 16 of them for all rows: the wave's piece of Z stays in its accumulators.
-__global__ __launch_bounds__(kThreads) void k_sb_sweep(TdParams tp) {
-  const DenseParams& p = tp.d;
-  const int n = p.Np, k = tp.j;
-  const int mat = p.msel ? p.msel[blockIdx.y] : blockIdx.y;
-  if (sb_stopped(tp, mat)) return;
-  double2* A = p.A + (int64_t)mat * n * n;
-  const double2* Vold = sb_V(tp, mat, k + 1);
-  const double2* Vnew = sb_V(tp, mat, k);
-  const double2* X = sb_X(tp, mat);
-  const int org = (kSbB * (k + 1)) & ~15;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int c0 = org + 64 * blockIdx.x + 16 * wave;
-  if (c0 >= n) return;
-  // J side (this wave's columns), constant over the row loop: negated, so that the MFMAs subtract
-  double nxr[2], nxi[2], pxi[2], nvr[2], nvi[2], pvi[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const double2 x = X[(int64_t)(c0 + lr) * kSbB + lk + 4 * h], v = Vold[(int64_t)(c0 + lr) * kSbB + lk + 4 * h];
-    nxr[h] = -x.x, nxi[h] = -x.y, pxi[h] = x.y;
-    nvr[h] = -v.x, nvi[h] = -v.y, pvi[h] = v.y;
-  }
-  v4d z = (v4d){0.0, 0.0, 0.0, 0.0};
-  double2* cp = A + (int64_t)(org + lk) * n + c0 + lr;  // C[lk + 4 reg][lr] of the current tile
-  const bool lo = lr < 8;
-  const int vq = lr & 7;
-  // operands of a tile: I-side rows r0 + lr (update), r0 + lk + 4 reg (product)
-  double2 cc[4], vi[2], xi[2], vn[4];
-#define SB_LOAD_TILE(R0, CPTR)                                                             \
-  {                                                                                        \
-    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) cc[reg] = (CPTR)[(int64_t)4 * reg * n]; \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                        \
-      vi[h] = Vold[(int64_t)((R0) + lr) * kSbB + lk + 4 * h];                              \
-      xi[h] = X[(int64_t)((R0) + lr) * kSbB + lk + 4 * h];                                 \
-    }                                                                                      \
-    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) vn[reg] = Vnew[(int64_t)((R0) + lk + 4 * reg) * kSbB + vq]; \
-  }
-  SB_LOAD_TILE(org, cp)
-  for (int r0 = org; r0 < n; r0 += 16) {
-    v4d cre, cim;
-    double a_vr[2], a_vi[2], a_xr[2], a_xi[2], b1[4], b2[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      cre[reg] = cc[reg].x;
-      cim[reg] = cc[reg].y;
-      b1[reg] = lo ? vn[reg].x : vn[reg].y;
-      b2[reg] = lo ? vn[reg].y : -vn[reg].x;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) a_vr[h] = vi[h].x, a_vi[h] = vi[h].y, a_xr[h] = xi[h].x, a_xi[h] = xi[h].y;
-    double2* cur = cp;
-    cp += (int64_t)16 * n;
-    if (r0 + 16 < n) SB_LOAD_TILE(r0 + 16, cp)  // the next tile's loads fly under this tile's MFMAs
-    // Re(V X^H + X V^H) = Vr Xr + Vi Xi + Xr Vr + Xi Vi;  Im = Vi Xr - Vr Xi + Xi Vr - Xr Vi
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vr[h], nxr[h], cre, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vi[h], nxr[h], cim, 0, 0, 0);
-      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vi[h], nxi[h], cre, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_vr[h], pxi[h], cim, 0, 0, 0);
-      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xr[h], nvr[h], cre, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xi[h], nvr[h], cim, 0, 0, 0);
-      cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xi[h], nvi[h], cre, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a_xr[h], pvi[h], cim, 0, 0, 0);
-    }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) cur[(int64_t)4 * reg * n] = make_double2(cre[reg], cim[reg]);
-    // Z[c] += sum_r conj(C[r][c]) V'[r]:  [Zr | Zi] += Cr^T [V'r | V'i] + Ci^T [V'i | -V'r], register `reg` of the
-    // accumulators being the A operand of rows r0 + lk + 4 reg
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      z = __builtin_amdgcn_mfma_f64_16x16x4f64(cre[reg], b1[reg], z, 0, 0, 0);
-      z = __builtin_amdgcn_mfma_f64_16x16x4f64(cim[reg], b2[reg], z, 0, 0, 0);
-    }
-  }
-#undef SB_LOAD_TILE
-  // z: row (column of A) c0 + lk + 4 reg, entry lr: Re Z[.][lr] (lr < 8), Im Z[.][lr - 8]
-  double* Zd = reinterpret_cast<double*>(sb_Z(tp, mat));
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) Zd[((int64_t)(c0 + lk + 4 * reg) * kSbB + vq) * 2 + (lo ? 0 : 1)] = z[reg];
-  // this wave's piece of M = V'^H Z (its 16 rows): [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]] = [V'r | V'i]^T [Zr | Zi]; the
-  // accumulator registers of z are B operands as they stand (k = lk <-> row lk + 4 reg, n = lr)
-  v4d mp = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const double2 vj = Vnew[(int64_t)(c0 + lk + 4 * reg) * kSbB + vq];
-    mp = __builtin_amdgcn_mfma_f64_16x16x4f64(lo ? vj.x : vj.y, z[reg], mp, 0, 0, 0);
-  }
-  double* Mw = sb_Mp(tp, mat) + (int64_t)((c0 - org) / 16) * 256;
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) Mw[(lk + 4 * reg) * 16 + lr] = mp[reg];
-}
 
-// ------------------------------------------------------------------------------- stage 1: sweep, lower triangle only
-// The same sweep over the tiles (I, J), I >= J, only: the trailing matrix is Hermitian, so a tile below the diagonal
-// also stands for its mirror image -- Z_J += C^H V'_I as above and, for I > J, Z_I += C V'_J.  The second product
-// contracts over the tile's COLUMNS, which the accumulator layout does not offer as an MFMA operand: the updated tile
-// is transposed through a private 16 x 17 LDS image of the wave (conflict-free both ways).  Who sums what, without any
-// synchronisation inside the loop: a block owns 64 columns and its wave w the row steps w, w + 4, ... -- ALL (up to four)
-// tiles of a row step, so the row contribution of the step is one accumulator chain in that wave (written as this
-// block's partial for those 16 rows: 0.5 KB per tile; the panel kernel adds the partials of a row in block order),
-// and the four column contributions are per-wave accumulators, summed over the block's waves once at the end.
-// 8.5 KB of HBM traffic and 32 MFMAs per tile where the full sweep has 16 KB and 48 for the tile and its mirror image;
-// the upper triangle is never touched again (the reflectors of finished panels stay there).
-// The J-side operands (X, V of update k-1, V' of panel k for the block's 64 columns) sit in LDS in the lane order of
-// the MFMA B operands.
-// UPD = false: sweep 0, which has no update pending -- it only reads (4.5 KB per tile instead of 8.5, on the largest
-// trailing matrix of all) and forms Z_0.
-template <bool UPD>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) void k_sb_sweep_lo(TdParams tp) {
-  __shared__ double sJ[4][kSbB][64];   // Xr, Xi, Vr, Vi: [q][column]
+// ---------------------------------------------------------------------------------------------------- stage 1: sweep
+// Sweep k (tp.j) over the tiles (I, J), I >= J, of the trailing matrix from the 16-aligned origin below o_k = 8 (k + 1):
+// the matrix is Hermitian, so a tile below the diagonal also stands for its mirror image.  Per tile:
+//   NP > 0 (a flush):  C -= sum_p V_p,I X_p,J^H + X_p,I V_p,J^H  over the NP pending updates p0 .. k-1 (operands zero above
+//                      their support), written back;
+//   always:            Z_J += C^H V'_I  and, for I > J,  Z_I += C V'_J    (V' = V_k)
+// -- all on v_mfma_f64_16x16x4_f64, the tile never leaving the accumulators in between: their layout (row = (lane >> 4)
+// + 4 reg, column = lane & 15) IS an A-operand layout for the product over the tile's ROWS.  The second product
+// contracts over the tile's COLUMNS: the tile goes through a private 16 x 17 LDS image of the wave (conflict-free both
+// ways).  Who sums what, without any synchronisation inside the loop: a block owns 64 columns and its wave w the row
+// steps w, w + 4, ... -- ALL (up to four) tiles of a row step, so the row contribution of the step is one accumulator
+// chain in that wave (written as this block's partial for those 16 rows: 0.5 KB per tile; the panel kernel adds the
+// partials of a row in block order), and the four column contributions are per-wave accumulators, summed over the
+// block's waves once at the end.  NP = 0: 4.5 KB of HBM traffic and 16 MFMAs per tile; NP > 0: 8.5 KB and 16 (NP + 1).
+// The upper triangle is never touched outside the diagonal tiles (the reflectors of finished panels live there).
+// The J-side operands (X_p, V_p of the pending updates, V' of panel k for the block's 64 columns) sit in LDS in the lane
+// order of the MFMA B operands.
+template <int NP>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 1 ? 3 : 2))) void k_sb_sweep_lo(TdParams tp) {
+  __shared__ double sJ[NP > 0 ? NP : 1][4][kSbB][NP > 0 ? 64 : 1];  // Xr, Xi, Vr, Vi of pending update pi: [q][column]
   __shared__ double sB[2][64][16];     // per column [V'r | V'i] and [-V'i | V'r] (entries q = 0..7 each)
   __shared__ double sT[4][2][16 * 17]; // per wave: the tile transposed, real and imaginary plane; at the end the reduction buffer
   const DenseParams& p = tp.d;
@@ -602,28 +610,37 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
   if (sb_stopped(tp, mat)) return;  // (uniform over the block)
   const int bx = blockIdx.y;
   double2* A = p.A + (int64_t)mat * n * n;
-  const double2* Vold = sb_V(tp, mat, k + 1);
   const double2* Vnew = sb_V(tp, mat, k);
-  const double2* X = sb_X(tp, mat);
   const int org = (kSbB * (k + 1)) & ~15;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   const int cb0 = org + 64 * bx;     // first column of the block (< n by the grid)
   const int ntile = min(4, (n - cb0) / 16);  // its column tiles
+  const double2* Vp[NP > 0 ? NP : 1];
+  const double2* Xp[NP > 0 ? NP : 1];
+#pragma unroll
+  for (int pi = 0; pi < NP; ++pi) {
+    Vp[pi] = sb_V(tp, mat, tp.p0 + pi);
+    Xp[pi] = sb_X(tp, mat, tp.p0 + pi);
+  }
   for (int idx = threadIdx.x; idx < 64 * kSbB; idx += kThreads) {
     const int col = idx >> 3, q = idx & 7;
-    double2 x = make_double2(0.0, 0.0), v = x, vn = x;
-    if (cb0 + col < n) {
-      x = X[(int64_t)(cb0 + col) * kSbB + q];
-      v = Vold[(int64_t)(cb0 + col) * kSbB + q];
-      vn = Vnew[(int64_t)(cb0 + col) * kSbB + q];
-    }
+    double2 vn = make_double2(0.0, 0.0);
+    if (cb0 + col < n) vn = Vnew[(int64_t)(cb0 + col) * kSbB + q];
+    sB[0][col][q] = vn.x, sB[0][col][8 + q] = vn.y;
+    sB[1][col][q] = -vn.y, sB[1][col][8 + q] = vn.x;
     // (column index XOR 2 q inside its aligned 16: the 8 lanes that share a column land on 8 different banks -- plain, this
     // store was 8-way conflicted -- and a reader, whose q is uniform over its 16 lanes, still sees 16 contiguous columns)
     const int cx = col ^ (2 * q);
-    sJ[0][q][cx] = x.x, sJ[1][q][cx] = x.y, sJ[2][q][cx] = v.x, sJ[3][q][cx] = v.y;
-    sB[0][col][q] = vn.x, sB[0][col][8 + q] = vn.y;
-    sB[1][col][q] = -vn.y, sB[1][col][8 + q] = vn.x;
+#pragma unroll
+    for (int pi = 0; pi < NP; ++pi) {
+      double2 x = make_double2(0.0, 0.0), v = x;
+      if (cb0 + col < n) {
+        x = Xp[pi][(int64_t)(cb0 + col) * kSbB + q];
+        v = Vp[pi][(int64_t)(cb0 + col) * kSbB + q];
+      }
+      sJ[pi][0][q][cx] = x.x, sJ[pi][1][q][cx] = x.y, sJ[pi][2][q][cx] = v.x, sJ[pi][3][q][cx] = v.y;
+    }
   }
   __syncthreads();
   const bool lo = lr < 8;
@@ -645,13 +662,17 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
     const int r0 = cb0 + 16 * t;
     const int ncb = min(t + 1, ntile);  // tiles of this row step; tile t (if it exists) is the diagonal one
     double2* const rowp = A + (int64_t)(r0 + lk) * n + cb0 + lr;
-    // I side of the step: rows r0 + lr of V, X (update), rows r0 + lk + 4 reg of V' (column product)
-    double nvr[2], nvi[2], pvr[2], nxr[2], nxi[2], pxr[2], b1[4], b2[4];
+    // I side of the step: rows r0 + lr of V_p, X_p (updates), rows r0 + lk + 4 reg of V' (column product)
+    double nvr[NP > 0 ? NP : 1][2], nvi[NP > 0 ? NP : 1][2], pvr[NP > 0 ? NP : 1][2], nxr[NP > 0 ? NP : 1][2], nxi[NP > 0 ? NP : 1][2], pxr[NP > 0 ? NP : 1][2];
+    double b1[4], b2[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const double2 v = Vold[(int64_t)(r0 + lr) * kSbB + lk + 4 * h], x = X[(int64_t)(r0 + lr) * kSbB + lk + 4 * h];
-      nvr[h] = -v.x, nvi[h] = -v.y, pvr[h] = v.x;
-      nxr[h] = -x.x, nxi[h] = -x.y, pxr[h] = x.x;
+    for (int pi = 0; pi < NP; ++pi) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double2 v = Vp[pi][(int64_t)(r0 + lr) * kSbB + lk + 4 * h], x = Xp[pi][(int64_t)(r0 + lr) * kSbB + lk + 4 * h];
+        nvr[pi][h] = -v.x, nvi[pi][h] = -v.y, pvr[pi][h] = v.x;
+        nxr[pi][h] = -x.x, nxi[pi][h] = -x.y, pxr[pi][h] = x.x;
+      }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -674,19 +695,22 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3))) v
           }
         }
         // C -= V_I X_J^H + X_I V_J^H:  Re = Vr Xr + Vi Xi + Xr Vr + Xi Vi,  Im = Vi Xr - Vr Xi + Xi Vr - Xr Vi
-        if (UPD) {
+        if (NP > 0) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int q = lk + 4 * h, c = 16 * cb + (lr ^ (2 * q));
-            const double jxr = sJ[0][q][c], jxi = sJ[1][q][c], jvr = sJ[2][q][c], jvi = sJ[3][q][c];
-            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvr[h], jxr, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxr, cim, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[h], jxi, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pvr[h], jxi, cim, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxr[h], jvr, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvr, cim, 0, 0, 0);
-            cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[h], jvi, cre, 0, 0, 0);
-            cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pxr[h], jvi, cim, 0, 0, 0);
+          for (int pi = 0; pi < NP; ++pi) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int q = lk + 4 * h, c = 16 * cb + (lr ^ (2 * q));
+              const double jxr = sJ[pi][0][q][c], jxi = sJ[pi][1][q][c], jvr = sJ[pi][2][q][c], jvi = sJ[pi][3][q][c];
+              cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvr[pi][h], jxr, cre, 0, 0, 0);
+              cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[pi][h], jxr, cim, 0, 0, 0);
+              cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nvi[pi][h], jxi, cre, 0, 0, 0);
+              cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pvr[pi][h], jxi, cim, 0, 0, 0);
+              cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxr[pi][h], jvr, cre, 0, 0, 0);
+              cim = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[pi][h], jvr, cim, 0, 0, 0);
+              cre = __builtin_amdgcn_mfma_f64_16x16x4f64(nxi[pi][h], jvi, cre, 0, 0, 0);
+              cim = __builtin_amdgcn_mfma_f64_16x16x4f64(pxr[pi][h], jvi, cim, 0, 0, 0);
+            }
           }
           double2* const cur = rowp + 16 * cb;
 #pragma unroll

@@ -109,6 +109,13 @@ double sb_stop_tol(const dmm_ctx* ctx) {
 int64_t sb_log_cap(int64_t log_stride, int n, int runs) {
   return log_stride - sb_tail(n) - ((int64_t)3 * runs * (int64_t)sizeof(int) + 15) / 16;
 }
+// "ml_reduce" = 0: up to kSbNB two-sided updates pending (herm_band.h: the trailing matrix is written by every kSbNB-th
+// sweep only); 2: none deferred (rounds 3-5); 3: two.  Small orders, whose log region has no room for the rings, defer nothing.
+int sb_pending(const dmm_ctx* ctx, int n, int64_t log_stride) {
+  int nb = ctx->opt_ml_reduce == 2 ? 1 : ctx->opt_ml_reduce == 3 ? 2 : kSbNB;
+  while (nb > 1 && sb_head(n, nb) + sb_tail(n) > log_stride) nb >>= 1;
+  return nb;
+}
 void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   const int n = tp.d.Np, K = sb_npanel(n);
   hipLaunchKernelGGL(k_sb_zero, dim3(12, nmat), dim3(kThreads), 0, st, tp);
@@ -119,13 +126,20 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
     else if (rows == 3) hipLaunchKernelGGL(k_sb_panel<3>, dim3(nmat), dim3(kThreads), 0, st, tp);
     else hipLaunchKernelGGL(k_sb_panel<4>, dim3(nmat), dim3(kThreads), 0, st, tp);
   };
+  tp.p0 = 0;
   for (int k = 0; k < K; ++k) {
     tp.j = k;
     panel();
     const int org = (kSbB * (k + 1)) & ~15;
-    if (tp.sb_lower && k == 0) hipLaunchKernelGGL(k_sb_sweep_lo<false>, dim3(nmat, (n - org + 63) / 64), dim3(kThreads), 0, st, tp);
-    else if (tp.sb_lower) hipLaunchKernelGGL(k_sb_sweep_lo<true>, dim3(nmat, (n - org + 63) / 64), dim3(kThreads), 0, st, tp);
-    else hipLaunchKernelGGL(k_sb_sweep, dim3((n - org + 63) / 64, nmat), dim3(kThreads), 0, st, tp);
+    const dim3 grid(nmat, (n - org + 63) / 64);
+    if (k - tp.p0 < tp.nb) {  // fewer than nb updates pending: the sweep only reads
+      hipLaunchKernelGGL(k_sb_sweep_lo<0>, grid, dim3(kThreads), 0, st, tp);
+    } else {  // the flush: updates p0 .. k-1 go into the stored matrix
+      if (tp.nb == 1) hipLaunchKernelGGL(k_sb_sweep_lo<1>, grid, dim3(kThreads), 0, st, tp);
+      else if (tp.nb == 2) hipLaunchKernelGGL(k_sb_sweep_lo<2>, grid, dim3(kThreads), 0, st, tp);
+      else hipLaunchKernelGGL(k_sb_sweep_lo<kSbNB>, grid, dim3(kThreads), 0, st, tp);
+      tp.p0 = k;
+    }
   }
   tp.j = K;
   panel();
@@ -893,12 +907,15 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     const double k = std::min<double>(ntel, nsky), K = std::max<double>(ntel, nsky);
     ctx->ml_gram_flops -= (int64_t)(4.0 * k * k * K);
   };
+  // algorithmic bytes of stage 1's sweeps (herm_band.h): 4.5 KB per tile of a reading sweep, 8.5 KB of a flush
+  auto sweep_bytes = [&](int n, int k) {
+    const int nb = sb_pending(ctx, n, (int64_t)2 * L.Np * L.Np);
+    const double t = (n - ((8 * (k + 1)) & ~15)) / 16;
+    return t * (t + 1) / 2 * (k > 0 && k % nb == 0 ? 8.5 : 4.5) * 1024;
+  };
   auto count_band = [&](int n, int nmat) {
     double by = 0.0;
-    for (int k = 0; k < n / 8 - 1; ++k) {
-      const double t = (n - ((8 * (k + 1)) & ~15)) / 16;
-      by += t * (t + 1) / 2 * (k == 0 ? 4.5 : 8.5) * 1024;  // (sweep 0 only reads)
-    }
+    for (int k = 0; k < n / 8 - 1; ++k) by += sweep_bytes(n, k);
     ctx->ml_band_bytes += (int64_t)(by * nmat);
   };
   // a matrix the rank stop cut off at order ne: the sweeps from panel ne / 8 - 1 on did not run; counted as stopped
@@ -906,10 +923,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     ++ctx->ml_order_hist[std::min(((ne ? ne : n) + 63) / 64, 16)];
     if (!ne) return;
     double by = 0.0;
-    for (int k = ne / 8 - 1; k < n / 8 - 1; ++k) {
-      const double t = (n - ((8 * (k + 1)) & ~15)) / 16;
-      by += t * (t + 1) / 2 * 8.5 * 1024;
-    }
+    for (int k = ne / 8 - 1; k < n / 8 - 1; ++k) by += sweep_bytes(n, k);
     ctx->ml_band_bytes -= (int64_t)by;
     ++ctx->ml_tiles_stopped;
     ctx->ml_stop_cols += ne;
@@ -1170,7 +1184,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.fail = fail_b;
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
-        tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
+        tp.nb = sb_pending(ctx, n, tp.log_stride);
         tp.chase_layout = sb_chase_layout(ctx, n);
         tp.stop_tol = sb_stop_tol(ctx);
         tp.bs_U = nullptr;
@@ -1449,7 +1463,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.fail = fail_hd;
     tp.tri = n <= 2048 ? 1 : 0;
     tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
-    tp.sb_lower = ctx->opt_ml_reduce == 2 ? 0 : 1;
+    tp.nb = sb_pending(ctx, n, tp.log_stride);
     tp.chase_layout = sb_chase_layout(ctx, n);
     tp.stop_tol = bs_build ? 1e-16 : sb_stop_tol(ctx);  // (a basis must hold B B^H to 1e-15: its truncation enters the day's Gram matrix in first order)
     if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
