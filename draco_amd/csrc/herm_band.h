@@ -50,21 +50,25 @@ __host__ __device__ constexpr size_t sb_chase_lds2(int n) { return ((size_t)(kSb
 
 // where a matrix's work arrays live in its log region (single pointers: a struct of them ends up in scratch / LDS).
 // Deferred updates (tp.nb >= 1 of them pending at most): rings of nb + 1 reflector arrays V_k and nb arrays X_k.
-constexpr int kSbNB = 4;  // most pending updates the kernels are built for
+constexpr int kSbNB = 2;  // most pending updates the kernels are built for (4 was built and measured: DESIGN 5.5)
 __host__ __device__ __forceinline__ int64_t sb_slot(int n) { return (int64_t)n * kSbB; }
 __device__ __forceinline__ double2* sb_base(const TdParams& tp, int mat) { return tp.log_cs + (int64_t)mat * tp.log_stride; }
 __device__ __forceinline__ double2* sb_V(const TdParams& tp, int mat, int k) { return sb_base(tp, mat) + (int64_t)(k % (tp.nb + 1)) * sb_slot(tp.d.Np); }  // V_k
 __device__ __forceinline__ double2* sb_X(const TdParams& tp, int mat, int k) { return sb_base(tp, mat) + (int64_t)(tp.nb + 1 + k % tp.nb) * sb_slot(tp.d.Np); }  // X_k
 __device__ __forceinline__ double2* sb_Z(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)(2 * tp.nb + 1) * sb_slot(tp.d.Np); }
+// what k_sb_pend leaves for the panel kernel when the older update is still pending: the corrections of Z and of the panel's columns, [n][8]
+__device__ __forceinline__ double2* sb_Zc(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)(2 * tp.nb + 2) * sb_slot(tp.d.Np); }
+__device__ __forceinline__ double2* sb_Pc(const TdParams& tp, int mat) { return sb_base(tp, mat) + (int64_t)(2 * tp.nb + 3) * sb_slot(tp.d.Np); }
 // the diagonal of the trailing matrix with every finished update applied (the rank stop's trace; the stored diagonal lags by the pending ones)
-__device__ __forceinline__ double* sb_dg(const TdParams& tp, int mat) { return reinterpret_cast<double*>(sb_base(tp, mat) + (int64_t)(2 * tp.nb + 2) * sb_slot(tp.d.Np)); }
+__device__ __forceinline__ double* sb_dg(const TdParams& tp, int mat) { return reinterpret_cast<double*>(sb_base(tp, mat) + (int64_t)(2 * tp.nb + 4) * sb_slot(tp.d.Np)); }
+__device__ __forceinline__ double2* sb_Mc(const TdParams& tp, int mat) { return reinterpret_cast<double2*>(sb_dg(tp, mat) + tp.d.Np); }  // and of M, [8][8]
 // [column blocks of the last sweep][256]: their pieces of V^H Z (16 x 16 real blocks [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]])
-__device__ __forceinline__ double* sb_Mp(const TdParams& tp, int mat) { return sb_dg(tp, mat) + tp.d.Np; }
+__device__ __forceinline__ double* sb_Mp(const TdParams& tp, int mat) { return reinterpret_cast<double*>(sb_Mc(tp, mat) + 64); }
 // the row contributions to Z of every 64-column block, [block][n][8 re | 8 im]
 __device__ __forceinline__ double* sb_Zp(const TdParams& tp, int mat) { return sb_Mp(tp, mat) + (int64_t)(tp.d.Np / 16) * 256; }
 // double2 units the arrays above take at the head of the log region
 __host__ __device__ constexpr int64_t sb_head(int n, int nb) {
-  return (int64_t)(2 * nb + 2) * n * kSbB + n / 2 + (int64_t)(n / 16) * 128 + (int64_t)((n + 63) / 64) * n * 8;
+  return (int64_t)(2 * nb + 4) * n * kSbB + n / 2 + 64 + (int64_t)(n / 16) * 128 + (int64_t)((n + 63) / 64) * n * 8;
 }
 __device__ __forceinline__ double2* sb_T(const TdParams& tp, int mat) { return sb_base(tp, mat) + tp.log_stride - sb_tail(tp.d.Np); }
 __device__ __forceinline__ double2* sb_rlog(const TdParams& tp, int mat) { return sb_T(tp, mat) + (int64_t)sb_npanel(tp.d.Np) * 64; }
@@ -175,20 +179,22 @@ __global__ __launch_bounds__(kThreads) void k_sb_zero(TdParams tp) {
 }
 
 // ---------------------------------------------------------------------------------------------------- stage 1: panel
-// Deferred updates.  The two-sided update of a panel, A -= V X^H + X V^H, is a read AND a write of the whole trailing
-// matrix; the product Z = A V the next panel needs is a read.  So the updates stay PENDING, up to tp.nb of them: the
-// stored matrix lags behind, the sweeps between two flushes only read it (k_sb_sweep_lo<0>), and what they produce is
-// corrected here from the pending operands (LAPACK's zlatrd idea, applied to the band reduction):
-//     Z_k = A_stored V_k - sum_p [ V_p (X_p^H V_k) + X_p (V_p^H V_k) ]                 p = the pending panels
-//     M_k = V_k^H Z_k = M_raw - sum_p [ S2_p^H S1_p + S1_p^H S2_p ],   S1_p = X_p^H V_k,  S2_p = V_p^H V_k
-//     P_k = A_stored[:, panel k] - sum_p [ X_p V_p[panel]^H + V_p X_p[panel]^H ]
-// Every nb-th sweep (k_sb_sweep_lo<nb>) applies all pending updates while it forms Z: nb - 1 reads + one read-and-write
-// of the trailing matrix per nb panels where the undeferred form (nb = 1: rounds 3-5) has nb of the latter.
-// NumPy twin in the kernels' order of events: tools/proto/lazy_band.py.
+// Deferred updates (tp.nb = 2).  The two-sided update of a panel, A -= V X^H + X V^H, is a read AND a write of the whole
+// trailing matrix; the product Z = A V the next panel needs is a read.  So an update may stay PENDING: the stored
+// matrix lags one update behind, every other sweep only reads it (k_sb_sweep_lo<0>), and what that sweep produces is
+// corrected from the pending operands (LAPACK's zlatrd idea, applied to the band reduction) -- with p the pending panel,
+//     Z_k = A_stored V_k - [ V_p (X_p^H V_k) + X_p (V_p^H V_k) ]
+//     M_k = V_k^H Z_k = M_raw - [ S2^H S1 + S1^H S2 ],   S1 = X_p^H V_k,  S2 = V_p^H V_k
+//     P_k = A_stored[:, panel k] - [ X_p V_p[panel]^H + V_p X_p[panel]^H ] - (the same for update k-1)
+// -- by k_sb_pend, a launch of its own before the panel kernel of such a step (the panel kernel keeps its registers).
+// The other sweeps (k_sb_sweep_lo<2>) apply both pending updates while they form Z: one read plus one read-and-write of
+// the trailing matrix per two panels where the undeferred form (nb = 1: rounds 3-5, "ml_reduce" = 2) has two of the
+// latter.  (Four pending updates were built and measured too, DESIGN 5.5: the flush of four is matrix-core bound at one
+// wave per SIMD and the corrections of three outweigh the two reads saved.)  NumPy twin: tools/proto/lazy_band.py.
 //
-// Panel k (tp.j), one block per matrix; tp.p0 = the oldest pending panel (p0 .. k-2 finished, k-1 finished here).
-// k > 0: finishes update k-1 (X = Z T - V (T^H M T) / 2) and applies every pending update to the panel's own columns
-// on the fly; then the diagonal block goes back to A, the sub-panel below it is QR-factored
+// Panel k (tp.j), one block per matrix; tp.p0 = the oldest pending panel (k-1, or k-2 with its corrections in Zc / Pc / Mc).
+// k > 0: finishes update k-1 (X = Z T - V (T^H M T) / 2, M = V^H Z) and applies the pending updates
+// to the panel's own columns on the fly; then the diagonal block goes back to A, the sub-panel below it is QR-factored
 // (reflectors into the upper triangle of A and the operand array of the next sweep, R into the lower band, T aside).
 // k == npanel: only the trailing 8 x 8 block is finished.  Rows of a thread: j0 + threadIdx.x + 256 u.
 constexpr int kSbRows = 4;  // most rows per thread: orders up to 1024
@@ -202,9 +208,8 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   __shared__ __align__(16) double2 s_a[1][kSbB];  // the pivot row of the current column
   __shared__ __align__(16) double2 s_M[64];
   __shared__ __align__(16) double2 s_T[64], s_S[64], s_tmp[64];
-  __shared__ __align__(16) double2 s_vrow[kSbNB][kSbB][kSbB], s_xrow[kSbNB][kSbB][kSbB];  // rows [j0, o) of the pending V_p, X_p
-  __shared__ __align__(16) double2 s_S12[kSbNB - 1][16][kSbB];  // per pending p < k-1: S1_p = X_p^H V_{k-1} (rows 0-7), S2_p = V_p^H V_{k-1} (8-15)
-  __shared__ double s_red[4 * 512];  // (block sums; the four waves' pieces of the S products)
+  __shared__ __align__(16) double2 s_vrow[kSbB][kSbB], s_xrow[kSbB][kSbB];
+  __shared__ double s_red[256];
   __shared__ double s_dg[kSbB];
   const DenseParams& p = tp.d;
   const int n = p.Np, k = tp.j, K = sb_npanel(n);
@@ -213,13 +218,12 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   double2* Vold = sb_V(tp, mat, k + tp.nb);  // V_{k-1}  ((k - 1) mod (nb + 1))
   double2* Vnew = sb_V(tp, mat, k);          // V_k (holds V_{k-nb-1} on entry)
   double2* const Xa = sb_X(tp, mat, k + tp.nb - 1);  // X_{k-1}
+  const bool older = k >= 2 && tp.p0 < k - 1;  // update k-2 is pending too: k_sb_pend has left its corrections
   const double2* const Za = sb_Z(tp, mat);
   double2* const Ta = sb_T(tp, mat);
   const double* const Mpa = sb_Mp(tp, mat);
   const int j0 = kSbB * k, o = j0 + kSbB;
   const int t = threadIdx.x;
-  const int p0 = tp.p0;            // pending: p0 .. k-1
-  const int nold = k - 1 - p0;     // of them finished before this launch (X known): p0 .. k-2
   if (sb_stopped(tp, mat)) return;  // the rank stop cut this matrix off at an earlier panel
 #ifdef SB_TIMING
   long long sb_t[8];
@@ -239,70 +243,20 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   }
   bool last = k == K;
 
-  // ---- finish update k-1
+  // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
   if (k > 0) {
-    // rows [j0, o) of the older pending operands (the look-ahead below needs them; this launch zeroes them afterwards)
-    for (int idx = t; idx < nold * 64; idx += kThreads) {
-      const int pi = idx >> 6, c = (idx >> 3) & 7, q = idx & 7;
-      s_vrow[pi][c][q] = sb_V(tp, mat, p0 + pi)[(int64_t)(j0 + c) * kSbB + q];
-      s_xrow[pi][c][q] = sb_X(tp, mat, p0 + pi)[(int64_t)(j0 + c) * kSbB + q];
-    }
-    // S products of the older pending panels with V_{k-1}, on the matrix cores: rows in steps of 4 over the block's waves,
-    // A operand = one entry of [X_p | V_p] per lane (real and imaginary plane: two products), B operand = [Re V | Im V]
-    if (nold > 0) {
-      const int lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
-      for (int pi = 0; pi < nold; ++pi) {
-        const double2* const Wp = li < 8 ? sb_X(tp, mat, p0 + pi) : sb_V(tp, mat, p0 + pi);
-        v4d d1 = (v4d){0.0, 0.0, 0.0, 0.0}, d2 = d1;
-        for (int r = j0 + 4 * wave + lk; r < n; r += 16) {
-          const double2 w = Wp[(int64_t)r * kSbB + (li & 7)];
-          const double2 v1 = Vold[(int64_t)r * kSbB + (li & 7)];
-          const double b = li < 8 ? v1.x : v1.y;
-          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.x, b, d1, 0, 0, 0);
-          d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w.y, b, d2, 0, 0, 0);
-        }
-        __syncthreads();  // (s_red may still be read from the previous p)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {  // D[row (lane >> 4) + 4 reg][column lane & 15]
-          s_red[wave * 512 + (lk + 4 * reg) * 16 + li] = d1[reg];
-          s_red[wave * 512 + 256 + (lk + 4 * reg) * 16 + li] = d2[reg];
-        }
-        __syncthreads();
-        if (t < 128) {  // S[i][c] = (D1[i][c] + D2[i][8 + c]) + i (D1[i][8 + c] - D2[i][c]), summed over the waves in wave order
-          const int i = t >> 3, c = t & 7;
-          double re = 0.0, im = 0.0;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            re += s_red[w * 512 + i * 16 + c] + s_red[w * 512 + 256 + i * 16 + 8 + c];
-            im += s_red[w * 512 + i * 16 + 8 + c] - s_red[w * 512 + 256 + i * 16 + c];
-          }
-          s_S12[pi][i][c] = make_double2(re, im);
-        }
-      }
-      __syncthreads();
-    }
-    // M = V^H Z arrives as one 16 x 16 real block per column block of sweep k-1 (k_sb_sweep_lo's epilogue)
     const int org_prev = (kSbB * k) & ~15;
-    const int nw = (n - org_prev + 63) / 64;
+    const int nw = (n - org_prev + 63) / 64;  // pieces of M: one per column block of the sweep
     const double* const Zpa = sb_Zp(tp, mat);
     double acc = 0.0;
     for (int w = 0; w < nw; ++w) acc += Mpa[(int64_t)w * 256 + t];
-    __syncthreads();
     s_red[t] = acc;
     if (t < 64) s_T[t] = Ta[(int64_t)(k - 1) * 64 + t];
     __syncthreads();
     const int q = (t >> 3) & 7, qq = t & 7;
-    if (t < 64) {  // M[q][q'] = (Vr'Zr + Vi'Zi) + i (Vr'Zi - Vi'Zr), minus the pending updates' share
+    if (t < 64) {  // M[q][q'] = (Vr'Zr + Vi'Zi) + i (Vr'Zi - Vi'Zr), minus the older pending update's share
       double2 m = make_double2(s_red[q * 16 + qq] + s_red[(8 + q) * 16 + 8 + qq], s_red[q * 16 + 8 + qq] - s_red[(8 + q) * 16 + qq]);
-      for (int pi = 0; pi < nold; ++pi) {
-        double2 a = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          cfmac(a, s_S12[pi][8 + u][q], s_S12[pi][u][qq]);
-          cfmac(a, s_S12[pi][u][q], s_S12[pi][8 + u][qq]);
-        }
-        m = csub(m, a);
-      }
+      if (older) m = csub(m, sb_Mc(tp, mat)[t]);
       s_M[t] = m;
     }
     __syncthreads();
@@ -322,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     __syncthreads();
     SB_T(1);
     double* const dgp = sb_dg(tp, mat);
-    // X = Z T - V S for the rows >= j0, one row per thread and pass.  (The memory clobber keeps the table entries in
+    // X = Z T - V S for the rows >= j0, one row per thread and pass.  (The memory clobber keeps the 128 table entries in
     // LDS: hoisted out of the row loop as loop invariants they are every register a thread can have.)
 #pragma unroll 1
     for (int r = j0 + t; r < n; r += kThreads) {
@@ -359,25 +313,10 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
           }
         }
       }
-      // the sweep multiplied the STORED matrix: minus the pending updates' share, V_p S1_p + X_p S2_p
-#pragma unroll 1
-      for (int pi = 0; pi < nold; ++pi) {
-        asm volatile("" ::: "memory");
-        const double2* const vpp = sb_V(tp, mat, p0 + pi) + (int64_t)r * kSbB;
-        const double2* const xpp = sb_X(tp, mat, p0 + pi) + (int64_t)r * kSbB;
-        double2 vp[8], xp[8];
+      if (older) {  // the sweep multiplied the STORED matrix: minus the older pending update's share (k_sb_pend)
+        const double2* const zc = sb_Zc(tp, mat) + (int64_t)r * kSbB;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vp[u] = vpp[u], xp[u] = xpp[u];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          double2 a = make_double2(0.0, 0.0);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            cfma(a, vp[u], s_S12[pi][u][c]);
-            cfma(a, xp[u], s_S12[pi][8 + u][c]);
-          }
-          z[c] = csub(z[c], a);
-        }
+        for (int c = 0; c < 8; ++c) z[c] = csub(z[c], zc[c]);
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -396,15 +335,15 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
         double dg = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) dg += x[c].x * v[c].x + x[c].y * v[c].y;
-        const double d = (k == 1 ? A[(int64_t)r * n + r].x : dgp[r]) - 2.0 * dg;
+        const double d = (k == 1 ? A[(int64_t)r * n + r].x : dgp[r]) - 2.0 * dg;  // (the stored diagonal lags by the pending updates)
         dgp[r] = d;
         trp += d;
       }
       if (r < o) {  // the panel's own rows: their V and X rows are what the look-ahead below needs
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          s_vrow[nold][r - j0][c] = v[c];
-          s_xrow[nold][r - j0][c] = x[c];
+          s_vrow[r - j0][c] = v[c];
+          s_xrow[r - j0][c] = x[c];
         }
       }
     }
@@ -417,8 +356,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   }
 
   SB_T(2);
-  // ---- the panel's columns with every pending update applied:
-  //      P[r][c] = A[r][j0+c] - sum_p sum_q X_p[r][q] conj(V_p[j0+c][q]) + V_p[r][q] conj(X_p[j0+c][q])
+  // ---- the panel's columns with update k-1 applied:  P[r][c] = A[r][j0+c] - sum_q X[r][q] conj(V[j0+c][q]) + V[r][q] conj(X[j0+c][q])
   double2 P[ROWS][kSbB];
 #pragma unroll
   for (int u = 0; u < ROWS; ++u) {
@@ -426,21 +364,26 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
     if (r < n) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) P[u][c] = A[(int64_t)r * n + j0 + c];
-#pragma unroll 1
-      for (int pi = 0; pi < k - p0; ++pi) {
-        double2 xr[8], vr[8];
-        const double2* const xpp = sb_X(tp, mat, p0 + pi) + (int64_t)r * kSbB;
-        const double2* const vpp = sb_V(tp, mat, p0 + pi) + (int64_t)r * kSbB;
+      if (older) {
+        const double2* const pc = sb_Pc(tp, mat) + (int64_t)r * kSbB;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) xr[q] = xpp[q], vr[q] = vpp[q];
-        asm volatile("" ::: "memory");  // (the entries of s_vrow / s_xrow stay in LDS between the rows)
+        for (int c = 0; c < 8; ++c) P[u][c] = csub(P[u][c], pc[c]);
+      }
+      if (k > 0) {
+        double2 xr[8], vr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          xr[q] = Xa[(int64_t)r * kSbB + q];
+          vr[q] = Vold[(int64_t)r * kSbB + q];
+        }
+        asm volatile("" ::: "memory");  // (the 128 entries of s_vrow / s_xrow stay in LDS between the rows)
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           double2 a = make_double2(0.0, 0.0);
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
-            cfma(a, xr[q], cconj2(s_vrow[pi][c][q]));
-            cfma(a, vr[q], cconj2(s_xrow[pi][c][q]));
+            cfma(a, xr[q], cconj2(s_vrow[c][q]));
+            cfma(a, vr[q], cconj2(s_xrow[c][q]));
           }
           P[u][c] = csub(P[u][c], a);
         }
@@ -450,22 +393,21 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
       for (int c = 0; c < 8; ++c) P[u][c] = make_double2(0.0, 0.0);
     }
   }
-  __syncthreads();  // everybody has read rows [j0, o) of the pending V_p / X_p (from LDS) and its own rows of them
+  __syncthreads();  // everybody has read rows [j0, o) of V_{k-1} / X_{k-1} (from LDS) and its own rows of them
   SB_T(3);
-  // rows [j0, o): the finished diagonal block goes back; their operand rows are zeroed in every pending array -- a sweep
-  // then leaves every tile row / column above o alone, whatever its 16-aligned origin
+  // rows [j0, o): the finished diagonal block goes back; their operand rows are zeroed -- the sweep then leaves every
+  // tile row / column above o alone, whatever its 16-aligned origin
   if (t < kSbB) {
     const int r = j0 + t;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) A[(int64_t)r * n + j0 + c] = P[0][c];
-    for (int pi = 0; pi < k - p0; ++pi) {
-      double2* const vpp = sb_V(tp, mat, p0 + pi) + (int64_t)r * kSbB;
-      double2* const xpp = sb_X(tp, mat, p0 + pi) + (int64_t)r * kSbB;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) vpp[c] = make_double2(0.0, 0.0), xpp[c] = make_double2(0.0, 0.0);
+    for (int c = 0; c < 8; ++c) {
+      A[(int64_t)r * n + j0 + c] = P[0][c];
+      if (k > 0) {
+        Vold[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
+        Xa[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
+      }
+      Vnew[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) Vnew[(int64_t)r * kSbB + c] = make_double2(0.0, 0.0);
   }
 #pragma unroll
   for (int c = 0; c < kSbB; ++c)  // (every index into P[][] a compile-time constant: a run-time one sends the whole array to scratch)
@@ -579,6 +521,105 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------ stage 1: pending update
+// Before panel k (tp.j) when update p = k-2 is still pending (tp.p0 = k-2: sweep k-1 only read the stored matrix), one
+// block per matrix:  S1 = X_p^H V_{k-1}, S2 = V_p^H V_{k-1} on the matrix cores (rows in groups of 4 over the waves, A
+// operand = one entry of [X_p | V_p] per lane -- real and imaginary plane: two products --, B operand = [Re V | Im V]),
+// then per row  Zc = V_p S1 + X_p S2  (what Z_{k-1} = A_stored V_{k-1} has too much),
+//               Pc = X_p V_p[panel k]^H + V_p X_p[panel k]^H  (what the stored panel columns have too much),
+// and  Mc = S2^H S1 + S1^H S2;  rows [j0, o) of V_p, X_p are zeroed afterwards (as the panel kernel does for update k-1).
+__global__ __launch_bounds__(kThreads) void k_sb_pend(TdParams tp) {
+  __shared__ __align__(16) double2 s_S12[16][kSbB];  // S1 (rows 0-7), S2 (8-15)
+  __shared__ __align__(16) double2 s_vrow[kSbB][kSbB], s_xrow[kSbB][kSbB];  // rows [j0, o) of V_p, X_p
+  __shared__ double s_red[4 * 512];
+  const DenseParams& p = tp.d;
+  const int n = p.Np, k = tp.j;
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  if (sb_stopped(tp, mat)) return;
+  const int j0 = kSbB * k, o = j0 + kSbB, t = threadIdx.x;
+  double2* const Vp = sb_V(tp, mat, tp.p0);
+  double2* const Xp = sb_X(tp, mat, tp.p0);
+  const double2* const V1 = sb_V(tp, mat, k + tp.nb);  // V_{k-1}
+  if (t < 64) {
+    s_vrow[t >> 3][t & 7] = Vp[(int64_t)(j0 + (t >> 3)) * kSbB + (t & 7)];
+    s_xrow[t >> 3][t & 7] = Xp[(int64_t)(j0 + (t >> 3)) * kSbB + (t & 7)];
+  }
+  {
+    const int lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
+    const double2* const Wp = (li < 8 ? Xp : Vp) + (li & 7);
+    v4d d1 = (v4d){0.0, 0.0, 0.0, 0.0}, d2 = d1;
+    // (four row groups per iteration: 8 loads in flight per lane -- one group at a time every iteration was a round trip to memory)
+    for (int r = j0 + 4 * wave + lk; r < n; r += 64) {
+      double2 w[4], v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rr = min(r + 16 * g, n - 4 + lk);  // (past the end: any valid row, its B operand is zeroed)
+        w[g] = Wp[(int64_t)rr * kSbB];
+        v[g] = V1[(int64_t)rr * kSbB + (li & 7)];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double b = r + 16 * g < n ? (li < 8 ? v[g].x : v[g].y) : 0.0;
+        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[g].x, b, d1, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[g].y, b, d2, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {  // D[row (lane >> 4) + 4 reg][column lane & 15]
+      s_red[wave * 512 + (lk + 4 * reg) * 16 + li] = d1[reg];
+      s_red[wave * 512 + 256 + (lk + 4 * reg) * 16 + li] = d2[reg];
+    }
+  }
+  __syncthreads();
+  if (t < 128) {  // S[i][c] = (D1[i][c] + D2[i][8 + c]) + i (D1[i][8 + c] - D2[i][c]), summed over the waves in wave order
+    const int i = t >> 3, c = t & 7;
+    double re = 0.0, im = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      re += s_red[w * 512 + i * 16 + c] + s_red[w * 512 + 256 + i * 16 + 8 + c];
+      im += s_red[w * 512 + i * 16 + 8 + c] - s_red[w * 512 + 256 + i * 16 + c];
+    }
+    s_S12[i][c] = make_double2(re, im);
+  }
+  __syncthreads();
+  if (t < 64) {  // Mc[q][q'] = sum_u conj(S2[u][q]) S1[u][q'] + conj(S1[u][q]) S2[u][q']
+    const int q = t >> 3, qq = t & 7;
+    double2 a = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      cfmac(a, s_S12[8 + u][q], s_S12[u][qq]);
+      cfmac(a, s_S12[u][q], s_S12[8 + u][qq]);
+    }
+    sb_Mc(tp, mat)[t] = a;
+  }
+  double2* const Zc = sb_Zc(tp, mat);
+  double2* const Pc = sb_Pc(tp, mat);
+#pragma unroll 1
+  for (int r = j0 + t; r < n; r += kThreads) {
+    asm volatile("" ::: "memory");  // (the tables stay in LDS)
+    double2 vp[8], xp[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vp[u] = Vp[(int64_t)r * kSbB + u], xp[u] = Xp[(int64_t)r * kSbB + u];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      double2 a = make_double2(0.0, 0.0), b = a;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        cfma(a, vp[u], s_S12[u][c]);
+        cfma(a, xp[u], s_S12[8 + u][c]);
+        cfma(b, xp[u], cconj2(s_vrow[c][u]));
+        cfma(b, vp[u], cconj2(s_xrow[c][u]));
+      }
+      Zc[(int64_t)r * kSbB + c] = a;
+      Pc[(int64_t)r * kSbB + c] = b;
+    }
+    if (r < o) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) Vp[(int64_t)r * kSbB + u] = make_double2(0.0, 0.0), Xp[(int64_t)r * kSbB + u] = make_double2(0.0, 0.0);
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------- stage 1: sweep
 // Sweep k (tp.j) over the tiles (I, J), I >= J, of the trailing matrix from the 16-aligned origin below o_k = 8 (k + 1):

@@ -110,9 +110,9 @@ int64_t sb_log_cap(int64_t log_stride, int n, int runs) {
   return log_stride - sb_tail(n) - ((int64_t)3 * runs * (int64_t)sizeof(int) + 15) / 16;
 }
 // "ml_reduce" = 0: up to kSbNB two-sided updates pending (herm_band.h: the trailing matrix is written by every kSbNB-th
-// sweep only); 2: none deferred (rounds 3-5); 3: two.  Small orders, whose log region has no room for the rings, defer nothing.
+// sweep only); 2: none deferred (rounds 3-5).  Small orders, whose log region has no room for the rings, defer nothing.
 int sb_pending(const dmm_ctx* ctx, int n, int64_t log_stride) {
-  int nb = ctx->opt_ml_reduce == 2 ? 1 : ctx->opt_ml_reduce == 3 ? 2 : kSbNB;
+  int nb = ctx->opt_ml_reduce == 2 ? 1 : kSbNB;
   while (nb > 1 && sb_head(n, nb) + sb_tail(n) > log_stride) nb >>= 1;
   return nb;
 }
@@ -129,6 +129,7 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   tp.p0 = 0;
   for (int k = 0; k < K; ++k) {
     tp.j = k;
+    if (tp.p0 < k - 1) hipLaunchKernelGGL(k_sb_pend, dim3(nmat), dim3(kThreads), 0, st, tp);  // (update k-2 still pending: its corrections)
     panel();
     const int org = (kSbB * (k + 1)) & ~15;
     const dim3 grid(nmat, (n - org + 63) / 64);
@@ -136,12 +137,12 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
       hipLaunchKernelGGL(k_sb_sweep_lo<0>, grid, dim3(kThreads), 0, st, tp);
     } else {  // the flush: updates p0 .. k-1 go into the stored matrix
       if (tp.nb == 1) hipLaunchKernelGGL(k_sb_sweep_lo<1>, grid, dim3(kThreads), 0, st, tp);
-      else if (tp.nb == 2) hipLaunchKernelGGL(k_sb_sweep_lo<2>, grid, dim3(kThreads), 0, st, tp);
       else hipLaunchKernelGGL(k_sb_sweep_lo<kSbNB>, grid, dim3(kThreads), 0, st, tp);
       tp.p0 = k;
     }
   }
   tp.j = K;
+  if (tp.p0 < K - 1) hipLaunchKernelGGL(k_sb_pend, dim3(nmat), dim3(kThreads), 0, st, tp);
   panel();
 }
 void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0, int cap_hint = 0) {
@@ -1447,7 +1448,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
       }
       // (the lower-triangle band reduction reads the upper triangle only inside the diagonal tiles, which the Gram
       // kernel writes in full)
-      if (!(sb_usable(ctx, n) && ctx->opt_ml_reduce != 2)) hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, S1, p);
+      if (!sb_usable(ctx, n)) hipLaunchKernelGGL(k_mirror, dim3(64, nmat), dim3(kThreads), 0, S1, p);
     }
     TdParams tp;
     tp.d = p;
