@@ -611,7 +611,7 @@ def dense_day(args, kind):
     torch.cuda.set_device(0)
     ctx = Context.get()
     cfg = wl.CONFIGS[args.config]
-    for opt in ("ml_reduce", "gram_stage", "wiener_overlap", "ml_chase_grid", "ml_null", "ml_chase_layout", "ml_rank_stop", "ml_chase_split", "ml_cu_split"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
+    for opt in ("ml_reduce", "gram_stage", "wiener_overlap", "ml_null", "ml_rank_stop", "ml_chase_split"):  # (A/B switches of the dense solvers: see include/draco_amd.h)
         if os.environ.get("DMM_" + opt.upper()):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt.encode(), int(os.environ["DMM_" + opt.upper()])))
     if os.environ.get("DMM_ML_WS_CAP_MIB"):  # A/B: cap the solvers' workspace offer (chunks of fewer matrices)

@@ -60,8 +60,6 @@ _SIGS = {
     "dmm_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "dmm_ctx_destroy": (_i, [_vp]),
     "dmm_ctx_set_stream": (_i, [_vp, _vp]),
-    "dmm_stream_create_cu_subset": (_i, [_i, _i, _i, _i, C.POINTER(_vp)]),
-    "dmm_stream_destroy": (_i, [_vp]),
     "dmm_ctx_sync": (_i, [_vp]),
     "dmm_ctx_set_option": (_i, [_vp, C.c_char_p, _i64]),
     "dmm_ctx_get_counter": (_i, [_vp, C.c_char_p, C.POINTER(_i64)]),

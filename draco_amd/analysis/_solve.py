@@ -179,6 +179,7 @@ class SolveEngine:
         self.fills = 0  # slabs actually filled (the others were resident)
         self.launch_events = None  # set to a list to collect (start, stop, b_bytes, ntile) per Dirty launch
         self._ws_offer = {}
+        self._basis_wkey = None
         self._ws = None
 
     def close(self):
@@ -322,7 +323,8 @@ class SolveEngine:
 
     def _basis_weights_ok(self, weights):
         """One reduction and one host read per CALL of solve / solve_many (not per slab): the verdict is remembered for
-        the weight arrays it was taken on."""
+        the weight arrays it was taken on and forgotten when the next call starts -- the next day's weights are normally
+        handed the same block by the caching allocator, with the same version counter."""
         key = tuple((int(w.data_ptr()), int(w._version), tuple(w.shape)) for w in weights)
         if getattr(self, "_basis_wkey", None) != key:
             hi = max(float(w.max()) for w in weights)
@@ -409,6 +411,7 @@ class SolveEngine:
         alm = torch.empty((nfreq, tel.num_pol_sky, n_m, tel.lmax + 1), dtype=torch.complex128, device=self.ctx.device)
         self.last_b_bytes = 0
         self._ws_offer = {}
+        self._basis_wkey = None  # (the weight-range verdict of the resident bases is per call)
         self._ws = None
         lib = _lib.lib
         issued, f_done = 0, 0
@@ -489,6 +492,7 @@ class SolveEngine:
         alms = [alm_all[d] for d in range(D)]
         self.last_b_bytes = 0
         self._ws_offer = {}
+        self._basis_wkey = None
         self._ws = None
         lib = _lib.lib
         PA = C.c_void_p * D

@@ -16,6 +16,7 @@ never transposed to m and back (``mapmaker.py:62-67,99``): every stage is per-fr
 from __future__ import annotations
 
 import collections
+import ctypes as C
 
 import numpy as np
 import torch
@@ -44,13 +45,16 @@ def _alm2map_neighbourly(c, alm, nfreq, lmax, mmax, nside, maps):
     """
     lib = _lib.lib
     pinned = getattr(c, "sht_variant_pin", None)
-    if pinned is None:  # (an option of its own: whatever `sht_variant` the caller has set on the context stays as it is)
-        _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_synth_form", 1))
+    if pinned is not None:  # (whatever `sht_variant` the caller has pinned on the context stays as it is)
+        _lib.check(lib.dmm_alm2map(c.handle, ptr(alm), nfreq, 4, lmax, mmax, nside, ptr(maps)))
+        return
+    before = C.c_int64()  # the option's value as the caller left it: restored, not reset
+    _lib.check(lib.dmm_ctx_get_counter(c.handle, b"opt_sht_synth_form", C.byref(before)))
+    _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_synth_form", 1))
     try:
         _lib.check(lib.dmm_alm2map(c.handle, ptr(alm), nfreq, 4, lmax, mmax, nside, ptr(maps)))
     finally:
-        if pinned is None:
-            _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_synth_form", 0))
+        _lib.check(lib.dmm_ctx_set_option(c.handle, b"sht_synth_form", int(before.value)))
 
 
 def _bound_run_ahead(ctx, depth):

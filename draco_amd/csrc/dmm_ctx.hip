@@ -57,45 +57,6 @@ hipError_t dmm_ticket(dmm_ctx* ctx, unsigned long long** out) {
   return hipSuccess;
 }
 
-int dmm_make_cu_stream(dmm_ctx* ctx, hipStream_t* st, bool side, int K) {
-  if (K < 2) {
-    DMM_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-    return DMM_OK;
-  }
-  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 256; ++i)
-    if (((i % K) == 0) == side) mask[i >> 5] |= 1u << (i & 31);
-  DMM_HIP(hipExtStreamCreateWithCUMask(st, 8, mask));
-  return DMM_OK;
-}
-
-int dmm_cu_scope::enter(int K) {
-  if (K < 2) return DMM_OK;
-  if (c->cu_main && c->cu_main_every != K) {
-    DMM_HIP(hipStreamSynchronize(c->cu_main));
-    DMM_HIP(hipStreamDestroy(c->cu_main));
-    c->cu_main = nullptr;
-  }
-  if (!c->cu_main) {
-    int rc = dmm_make_cu_stream(c, &c->cu_main, false, K);
-    if (rc) return rc;
-    c->cu_main_every = K;
-  }
-  if (!c->cu_ev) DMM_HIP(hipEventCreateWithFlags(&c->cu_ev, hipEventDisableTiming));
-  DMM_HIP(hipEventRecord(c->cu_ev, c->stream));
-  DMM_HIP(hipStreamWaitEvent(c->cu_main, c->cu_ev, 0));
-  caller = c->stream;
-  c->stream = c->cu_main;
-  return DMM_OK;
-}
-
-dmm_cu_scope::~dmm_cu_scope() {
-  if (!caller) return;
-  (void)hipEventRecord(c->cu_ev, c->cu_main);
-  (void)hipStreamWaitEvent(caller, c->cu_ev, 0);
-  c->stream = caller;
-}
-
 extern "C" {
 
 int dmm_version(void) { return DMM_VERSION; }
@@ -145,8 +106,6 @@ int dmm_ctx_destroy(dmm_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->aux_stream_b) (void)hipStreamDestroy(c->aux_stream_b);
-  if (c->cu_main) (void)hipStreamDestroy(c->cu_main);
-  if (c->cu_ev) (void)hipEventDestroy(c->cu_ev);
   if (c->aux_pinned) (void)hipHostFree(c->aux_pinned);
   delete c;
   return DMM_OK;
@@ -155,31 +114,6 @@ int dmm_ctx_destroy(dmm_ctx* c) {
 int dmm_ctx_set_stream(dmm_ctx* c, void* s) {
   DMM_REQUIRE(c != nullptr, "dmm_ctx_set_stream: ctx is NULL");
   c->stream = (hipStream_t)s;
-  return DMM_OK;
-}
-
-int dmm_stream_create_cu_subset(int device, int every, int phase, int priority, void** stream) {
-  DMM_REQUIRE(stream != nullptr && every >= 1 && every <= 64 && phase >= -every && phase < every, "dmm_stream_create_cu_subset: every in 1..64, phase in -every..every-1");
-  DMM_HIP(hipSetDevice(device));
-  hipStream_t st = nullptr;
-  if (every == 1) {
-    DMM_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
-  } else {
-    // CU i belongs to the subset when i % every == phase (phase >= 0), or when i % every != -phase - 1 (phase < 0: the
-    // complement of subset -phase - 1): spread over the chip whatever the numbering behind the mask bits
-    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 256; ++i) {
-      const bool in = phase >= 0 ? (i % every) == phase : (i % every) != -phase - 1;
-      if (in) mask[i >> 5] |= 1u << (i & 31);
-    }
-    DMM_HIP(hipExtStreamCreateWithCUMask(&st, 8, mask));
-  }
-  *stream = (void*)st;
-  return DMM_OK;
-}
-
-int dmm_stream_destroy(void* stream) {
-  if (stream) DMM_HIP(hipStreamDestroy((hipStream_t)stream));
   return DMM_OK;
 }
 
@@ -193,16 +127,11 @@ int dmm_ctx_set_option(dmm_ctx* c, const char* name, int64_t value) {
   else if (!strcmp(name, "ml_inner_sweeps")) c->opt_ml_inner_sweeps = (int)value;
   else if (!strcmp(name, "ml_outer_sweeps")) c->opt_ml_outer_sweeps = (int)value;
   else if (!strcmp(name, "sht_variant")) c->opt_sht_variant = (int)value;
-  else if (!strcmp(name, "sht_grid")) c->opt_sht_grid = (int)value;
   else if (!strcmp(name, "sht_synth_form")) c->opt_sht_synth_form = (int)value;
   else if (!strcmp(name, "ml_shortcut")) c->opt_ml_shortcut = (int)value;
   else if (!strcmp(name, "ml_null")) c->opt_ml_null = (int)value;
   else if (!strcmp(name, "ml_rank_stop")) c->opt_ml_rank_stop = (int)value;
-  else if (!strcmp(name, "ml_cu_split")) c->opt_ml_cu_split = (int)value;
-  else if (!strcmp(name, "dirty_cu_split")) c->opt_dirty_cu_split = (int)value;
   else if (!strcmp(name, "ml_chase_split")) c->opt_ml_chase_split = (int)value;
-  else if (!strcmp(name, "ml_chase_grid")) c->opt_ml_chase_grid = (int)value;
-  else if (!strcmp(name, "ml_chase_layout")) c->opt_ml_chase_layout = (int)value;
   else if (!strcmp(name, "dirty_prio")) c->opt_dirty_prio = (int)value;
   else if (!strcmp(name, "ml_eigen")) c->opt_ml_eigen = (int)value;
   else if (!strcmp(name, "ringmap_variant")) c->opt_ringmap_variant = (int)value;
@@ -233,6 +162,7 @@ int dmm_ctx_get_counter(dmm_ctx* c, const char* name, int64_t* value) {
   else if (!strcmp(name, "ml_band_bytes")) *value = c->ml_band_bytes;
   else if (!strcmp(name, "ml_tiles_ql_failed")) *value = c->ml_tiles_ql_failed;
   else if (!strcmp(name, "ml_early_chunks")) *value = c->ml_early_chunks;
+  else if (!strcmp(name, "opt_sht_synth_form")) *value = c->opt_sht_synth_form;  // (the option's current value: callers that set it around a call restore it)
   else if (!strncmp(name, "prof_", 5)) {
     const size_t len = strlen(name);
     const bool want_n = len > 7 && !strcmp(name + len - 2, "_n");

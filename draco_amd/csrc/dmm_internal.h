@@ -30,11 +30,6 @@ struct dmm_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t aux_stream = nullptr;        // library-owned second stream (ML eigen path: QL of one half-batch under the reduction of the next)
   hipStream_t aux_stream_b = nullptr;      // and a third: the QL launches of the two chunk slots are latency bound and run side by side
-  hipStream_t cu_main = nullptr;           // "ml_cu_split" (A/B): the caller's queue of dmm_ml_run, confined to the CUs the side streams do not own
-  hipEvent_t cu_ev = nullptr;
-  int opt_ml_cu_split = 0;
-  int opt_dirty_cu_split = 0;
-  int cu_main_every = 0;                   // the split cu_main was created for
   hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   int* aux_pinned = nullptr;               // pinned host words for flags read back on the second stream
   size_t aux_pinned_n = 0;
@@ -51,14 +46,11 @@ struct dmm_ctx {
   int opt_ml_inner_sweeps = 0, opt_ml_outer_sweeps = 0;
   int opt_sht_variant = 0;
   int opt_sht_synth_form = 0;  // 1: the first MFMA form of the Legendre synthesis whatever sht_variant says (the map-makers' alm2map)
-  int opt_sht_grid = 0;  // > 0: the Legendre synthesis as that many resident blocks walking the (m, ring chunk, frequency group) items
   int opt_ml_eigen = 0;                    // 0: by batch size (tridiagonalisation + QL for large batches, blocked Jacobi for a few matrices); 1: Jacobi; 4: tridiagonal; 2: tridiagonal with full-matrix trailing updates; 3: tridiagonal with QL made to give up (Jacobi fallback)
   int64_t opt_ml_ws_mib = 0, opt_wiener_ws_mib = 0;  // workspace the ML / Wiener solves size themselves for (0: 20 / 6 GiB)
   int opt_ml_shortcut = 0;                 // 0/1: certified full-rank shortcut on; 2: eigen path always; 3: telescope side only
   int ml_probe_every = 8;                  // how thinly dmm_ml_run probes the certificate while the probes keep failing (8 ... 64 batches; remembered with the rate)
   double ml_pass_rate = 1.0;               // share of the last certificate batch / probe that passed (dmm_ml_run starts the next call from it)
-  int opt_ml_chase_layout = 0;             // 1: the bulge chase uses the bank-spread band layout in LDS (A/B; no effect on its run time)
-  int opt_ml_chase_grid = 0;               // > 0: the bulge-chase kernel's grid is capped at this many blocks (each loops over matrices)
   int opt_ml_null = 0;                     // 1: no null certificate (tiles whose Frobenius norm puts every singular value below acond are decomposed like any other)
   int64_t ml_gram_flops = 0, ml_band_bytes = 0;  // counters: useful flops of the ML Gram launches (4 k^2 K per tile), algorithmic bytes of stage 1 of the two-stage reduction (8.5 KB per lower-triangle tile and panel)
   int64_t ml_tiles_null = 0;               // counter: tiles the null certificate answered with zero
@@ -182,14 +174,3 @@ int dmm_fft_tables_f64(dmm_ctx* ctx, int n, dmm_fft_tables** out);  // mfft.hip
 
 static inline bool dmm_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-// ---- "ml_cu_split" / "dirty_cu_split" = K >= 2: for the length of a call the caller's queue is moved to a library-owned
-// stream confined to the CUs with i % K != 0 (the complement of dmm_stream_create_cu_subset(device, K, 0, ...), the side
-// stream's share), ordered with the caller's stream by events on both ends.
-int dmm_make_cu_stream(dmm_ctx* ctx, hipStream_t* st, bool side, int K);
-struct dmm_cu_scope {
-  dmm_ctx* c;
-  hipStream_t caller = nullptr;
-  explicit dmm_cu_scope(dmm_ctx* ctx) : c(ctx) {}
-  int enter(int K);
-  ~dmm_cu_scope();
-};

@@ -45,8 +45,6 @@ __host__ __device__ constexpr int64_t sb_nlog(int n) { return sb_total(n - 1); }
 __host__ __device__ constexpr int64_t sb_tail(int n) { return (int64_t)sb_npanel(n) * 64 + sb_nlog(n) * kSbB; }
 // LDS of the chase kernel: band [9][n+1] + bulge triangles [n/8 + 2][21], double2
 __host__ __device__ constexpr size_t sb_chase_lds(int n) { return ((size_t)(kSbB + 1) * (n + 2) + (size_t)(n / kSbB + 2) * 21) * sizeof(double2); }
-// the same for the bank-spread layout of round 4 (pitch n + 1, diagonals 2.. shifted by 6 entries, bulge pitch 22): used where it fits
-__host__ __device__ constexpr size_t sb_chase_lds2(int n) { return ((size_t)(kSbB + 1) * (n + 1) + 6 + (size_t)(n / kSbB + 2) * 22) * sizeof(double2); }
 
 // where a matrix's work arrays live in its log region (single pointers: a struct of them ends up in scratch / LDS).
 // Deferred updates (tp.nb >= 1 of them pending at most): rings of nb + 1 reflector arrays V_k and nb arrays X_k.
@@ -880,24 +878,23 @@ __global__ __launch_bounds__(64 * kSbCW) void k_sb_chase(TdParams tp, int nmat, 
   __shared__ int s_prog[kSbCW];
   __shared__ __align__(16) double2 s_scr[kSbCW][64];
   const DenseParams& p = tp.d;
-  // Layout of the band image.  tp.chase_layout = 0 (rounds 3): diagonal d at d * (n + 2), bulge pitch 21.  1 (round 4, from the
-  // bank model tools/proto/chase_banks.py: 63-65 instead of 151 extra LDS cycles per step): diagonal d at d * (n + 1) + (6 from
-  // d = 2 on), bulge pitch 22, and the wave's octets take the slots 0 1 4 5 2 3 6 7 -- so that the lanes of one
-  // ds_read_b128 group ({0-3, 12-15, 20-27}, ...) fall on different 16-byte bank slots for every element index.
-  const int nA = p.Np, lay = tp.chase_layout;
+  // Layout of the band image: diagonal d at d * (n + 2), bulge pitch 21.  (A bank-spread layout from a model of the LDS,
+  // tools/proto/chase_banks.py, was built in round 4: twice the counted conflicts, the same run time -- DESIGN_HISTORY.)
+  const int nA = p.Np;
   double2* ab = reinterpret_cast<double2*>(smem_sb);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 7;
-  const int oct = lane >> 3, g = lay ? ((oct & 1) | ((oct & 2) << 1) | ((oct & 4) >> 1)) : oct;
-#define SB_DIAG(d) ((d) * pitch + ((d) >= 2 ? jump : 0))
-  // a block works through the matrices bi = blockIdx.x, blockIdx.x + gridDim.x, ... (grid < nmat: "ml_chase_grid")
+  const int g = lane >> 3;
+#define SB_DIAG(d) ((d) * pitch)
+  // a block works through the matrices bi = blockIdx.x, blockIdx.x + gridDim.x, ... (the second launch of sb_chase: grid < nmat)
   for (int bi = blockIdx.x; bi < nmat; bi += gridDim.x) {
   const int mat = p.msel ? p.msel[bi] : bi;
   // the matrix's effective order (the rank stop of stage 1): the band image, the sweeps and the reflector log are those
   // of an order-n matrix; only A's row pitch and the vector slots keep the padded order nA
   const int n = sb_order(tp, mat);
   if (n <= ne_lo || n > ne_hi) continue;  // (uniform over the block)
-  const int pitch = lay ? n + 1 : sb_pitch(n), jump = lay ? 6 : 0, bgp = lay ? 22 : 21;
-  const int bg0 = (kSbB + 1) * pitch + jump;  // the bulge triangles follow the band
+  const int pitch = sb_pitch(n);
+  constexpr int bgp = 21;
+  const int bg0 = (kSbB + 1) * pitch;  // the bulge triangles follow the band
   const double2* A = p.A + (int64_t)mat * nA * nA;
   double2* const rlog = sb_rlog(tp, mat);
   double2* vbm = tp.vec + (int64_t)mat * td_slots(nA) * nA;

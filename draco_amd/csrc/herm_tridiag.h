@@ -51,7 +51,6 @@ struct TdParams {
   int nb;              // two-stage reduction, stage 1: most two-sided updates left pending (1: every sweep applies its
                        // predecessor's update, rounds 3-5; herm_band.h), and p0, the oldest pending panel at this launch
   int p0;
-  int chase_layout;    // LDS layout of the bulge chase's band image: 0 = round 3's, 1 = the bank-spread one (herm_band.h)
   // basis build (dmm_ctx_set_ml_basis, build = 1): PH 3 writes the eigenvectors of the kept eigenvalues instead of solving
   double2* bs_U;       // [slot][bs_rmax][bs_ld]: row j = conj of the j-th kept eigenvector (nullptr: normal solve)
   double* bs_sigma;    // [slot][bs_rmax] sqrt(lambda_j)

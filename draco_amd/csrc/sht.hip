@@ -242,23 +242,20 @@ int synth_chunk(dmm_ctx* ctx, const ShtGeom& g, const double2* alm, int n_m, int
     (void)hipMemsetAsync(stamps_d, 0, nst * 8, ctx->stream);
     lp.stamps = stamps_d;
 #endif
-    const int nx = g.mmax + 1, G = ctx->opt_sht_grid;
+    const int nx = g.mmax + 1;
     // the pipelined kernel addresses a block's a_lm columns with 32-bit byte offsets from one base: its frequency groups must
     // span less than 4 GiB (8 frequencies: lmax <= 2895; 4: lmax <= 4095) -- beyond that the first form, with 64-bit pointers
     const int64_t col_bytes = (int64_t)4 * n_m * (g.lmax + 1) * (int64_t)sizeof(double2);  // one frequency's four polarisations
     const bool fits8 = 2 * kLegF * col_bytes < ((int64_t)1 << 32), fits4 = kLegF * col_bytes < ((int64_t)1 << 32);
     if ((ctx->opt_sht_variant & 64) || ctx->opt_sht_synth_form == 1 || !fits4) {  // bit 6 / "sht_synth_form" = 1: the first MFMA form (rounds 1-4)
       const int nz = (nf + kLegF - 1) / kLegF;
-      if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma_walk, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
-      else hipLaunchKernelGGL(k_leg_synth_mfma, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
+      hipLaunchKernelGGL(k_leg_synth_mfma, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
     } else if ((ctx->opt_sht_variant & 128) || !fits8) {  // bit 7: one frequency group per block, two waves per SIMD
       const int nz = (nf + kLegF - 1) / kLegF;
-      if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma2_walk<1>, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
-      else hipLaunchKernelGGL(k_leg_synth_mfma2<1>, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
+      hipLaunchKernelGGL(k_leg_synth_mfma2<1>, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
     } else {
       const int nz = (nf + 2 * kLegF - 1) / (2 * kLegF);
-      if (G > 0) hipLaunchKernelGGL(k_leg_synth_mfma2_walk<2>, dim3(G), dim3(kThreads), 0, ctx->stream, lp, nx, nrc, nz);
-      else hipLaunchKernelGGL(k_leg_synth_mfma2<2>, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
+      hipLaunchKernelGGL(k_leg_synth_mfma2<2>, dim3(nx, nrc, nz), dim3(kThreads), 0, ctx->stream, lp);
     }
   } else
   switch (ctx->opt_sht_variant & 3) {
@@ -338,9 +335,6 @@ int anal_chunk(dmm_ctx* ctx, const ShtGeom& g, const double* map, int n_m, int n
     // frequency at cfg 3, -4.4 % with three iterations); bit 4 of sht_variant: the 8-wave block of rounds 1-3 (A/B)
     if (ctx->opt_sht_variant & 16)
       hipLaunchKernelGGL((k_leg_anal_mfma<kAnThreads, 1>), dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(kAnThreads), 0, ctx->stream, lp);
-    else if (ctx->opt_sht_variant & 512)  // bit 9: two frequency groups per block at 512 registers -- measured SLOWER (map2alm 0.117
-      // against 0.107 ms per frequency: the ring data parked in AGPRs comes back through a v_accvgpr_read per product), an A/B
-      hipLaunchKernelGGL((k_leg_anal_mfma<256, 2>), dim3(g.mmax + 1, (nf + 2 * kLegF - 1) / (2 * kLegF)), dim3(256), 0, ctx->stream, lp);
     else
       hipLaunchKernelGGL((k_leg_anal_mfma<256, 1>), dim3(g.mmax + 1, (nf + kLegF - 1) / kLegF), dim3(256), 0, ctx->stream, lp);
     DMM_HIP(hipGetLastError());

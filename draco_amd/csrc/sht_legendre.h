@@ -170,9 +170,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_leg_synth(LegParams p) {
 // lane group and the two l rows of a half wave fall on disjoint banks.
 constexpr int kLegL = 8, kLegF = 4, kLegPitch = 72;
 
-// (the kernels' bodies take their block coordinates as arguments: launched one block per (m, ring chunk, frequency group),
-// or -- `sht_grid` > 0 -- as a fixed number of resident blocks that walk the same items, so that the transform beside the
-// HBM-bound solve kernel keeps to a bounded share of the compute units)
+// (the kernels' bodies take their block coordinates as arguments: one block per (m, ring chunk, frequency group))
 __device__ __forceinline__ void leg_synth_mfma_body(const LegParams& p, int bx, int by, int bz) {
   typedef double v4d __attribute__((ext_vector_type(4)));
   __shared__ double slab[kThreads / 64][3][kLegL][kLegPitch];
@@ -320,10 +318,6 @@ __device__ __forceinline__ void leg_synth_mfma_body(const LegParams& p, int bx, 
 
 __global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) { leg_synth_mfma_body(p, blockIdx.x, blockIdx.y, blockIdx.z); }
 
-__global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma_walk(LegParams p, int nx, int ny, int nz) {
-  for (int item = blockIdx.x; item < nx * ny * nz; item += gridDim.x)
-    leg_synth_mfma_body(p, item % nx, (item / nx) % ny, item / (nx * ny));
-}
 
 // ---- synthesis on the matrix cores, second form (round 5; default, `sht_variant` bit 6 restores the one above).
 // What the counters and in-kernel stamps of the first form say (profiles/r01_sht_cfg3_pmc.txt, profiles/r05_sht_*): 17 vector
@@ -633,12 +627,6 @@ __device__ __forceinline__ void leg_synth_mfma2_body(const LegParams& p, int bx,
 template <int NFG>
 __global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2(LegParams p) {
   leg_synth_mfma2_body<NFG>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
-}
-
-template <int NFG>
-__global__ __launch_bounds__(kThreads, 3 - NFG) void k_leg_synth_mfma2_walk(LegParams p, int nx, int ny, int nz) {
-  for (int item = blockIdx.x; item < nx * ny * nz; item += gridDim.x)
-    leg_synth_mfma2_body<NFG>(p, item % nx, (item / nx) % ny, item / (nx * ny), ny);
 }
 
 // ---------------------------------------------------------------- analysis, stage 2'

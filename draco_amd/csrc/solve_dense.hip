@@ -87,9 +87,6 @@ void td_reduce(TdParams& tp, int nmat, hipStream_t st) {
 
 // ---- two-stage reduction (herm_band.h): dense -> band of half-width 8 on the MFMA units, band -> tridiagonal in LDS
 constexpr size_t kSbLdsMax = 160 * 1024;
-// "ml_chase_layout" = 1: the bank-spread band image of round 4 wherever it fits the LDS (the A/B: it removes most of the
-// chase's LDS bank conflicts and changes nothing in its run time); 0, default: round 3's
-int sb_chase_layout(const dmm_ctx* ctx, int n) { return ctx->opt_ml_chase_layout == 1 && sb_chase_lds2(n) + 4608 <= kSbLdsMax ? 1 : 0; }
 bool sb_usable(const dmm_ctx* ctx, int n) {
   if (ctx->opt_ml_reduce == 1) return false;
   return n >= 64 && n % 64 == 0 && n <= kSbRows * kThreads && sb_chase_lds(n) + 4608 <= kSbLdsMax;  // (+ the chase kernel's static scratch)
@@ -145,12 +142,10 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   if (tp.p0 < K - 1) hipLaunchKernelGGL(k_sb_pend, dim3(nmat), dim3(kThreads), 0, st, tp);
   panel();
 }
-void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, int grid_cap = 0, int cap_hint = 0) {
-  // grid_cap > 0 ("ml_chase_grid"): at most that many blocks, each working through several matrices -- the chase keeps a
-  // CU's whole LDS, so a capped grid confines it to that many CUs instead of letting it take every CU in turn
-  const int grid = grid_cap > 0 && grid_cap < nmat ? grid_cap : nmat;
+void sb_chase(const dmm_ctx* ctx, const TdParams& tp, int nmat, hipStream_t st, int cap_hint = 0) {
+  const int grid = nmat;
   const int n = tp.d.Np;
-  auto lds_of = [&](int order) { return tp.chase_layout ? sb_chase_lds2(order) : sb_chase_lds(order); };
+  auto lds_of = [&](int order) { return sb_chase_lds(order); };
   // The rank stop leaves the matrices of a telescope at a fraction of their order, and which fraction is known from the
   // chunks before (ctx->ml_order_hist).  A launch sized for the largest order seen so far plus 64 columns (the orders
   // drift with frequency and m, a few columns from one chunk to the next) takes (and keeps) half a CU's LDS or less --
@@ -841,8 +836,6 @@ int dmm_wiener_run(dmm_plan* pl, const void* B, const void* mvis, const double* 
   return DMM_OK;
 }
 
-// ("ml_cu_split" = K >= 2, A/B of DESIGN 5.5 / VERDICT r4 item 3: the side streams -- bulge chase, serial QL -- own every K-th
-// CU, the caller's queue of dmm_ml_run is moved to a stream confined to the others: dmm_cu_scope)
 int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mweight, double acond, double rcond,
                void* workspace, void* alm) {
   DMM_REQUIRE(pl && B && mvis && mweight && workspace && alm, "dmm_ml_run: NULL argument");
@@ -858,11 +851,6 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     hipStream_t s;
     ~StreamRestore() { c->stream = s; }
   } stream_guard{ctx, ctx->stream};
-  dmm_cu_scope cu_guard(ctx);  // (declared after stream_guard: leaves before that restores the caller's stream pointer)
-  {
-    int rc_ = cu_guard.enter(ctx->opt_ml_cu_split);
-    if (rc_) return rc_;
-  }
   const Layout L = layout_of(pl, 2);  // telescope-side order: the largest any batch uses
   const int64_t wsb = dmm_ml_workspace_bytes(pl);
   const int cap = (int)((wsb - L.header - 1024) / (L.per_mat + L.per_mat_extra));
@@ -1050,7 +1038,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
-    if (sb_usable(ctx, L.Np)) DMM_HIP(hipFuncSetAttribute((const void*)k_sb_chase, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(sb_chase_lds(L.Np), sb_chase_layout(ctx, L.Np) ? sb_chase_lds2(L.Np) : (size_t)0)));
+    if (sb_usable(ctx, L.Np)) DMM_HIP(hipFuncSetAttribute((const void*)k_sb_chase, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_chase_lds(L.Np)));
   }
 
   std::vector<dmm_tile> tiles_c;
@@ -1186,7 +1174,6 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
         tp.nb = sb_pending(ctx, n, tp.log_stride);
-        tp.chase_layout = sb_chase_layout(ctx, n);
         tp.stop_tol = sb_stop_tol(ctx);
         tp.bs_U = nullptr;
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
@@ -1198,7 +1185,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
             sb_reduce(tp, nsel, ctx->stream);
           }
           dmm_prof_scope prof(ctx, DMM_PROF_CHASE, ctx->stream);
-          sb_chase(ctx, tp, nsel, ctx->stream, ctx->opt_ml_chase_grid);
+          sb_chase(ctx, tp, nsel, ctx->stream);
         } else {
           dmm_prof_scope prof(ctx, DMM_PROF_TRIDIAG, ctx->stream);
           td_reduce(tp, nsel, ctx->stream);
@@ -1304,8 +1291,8 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
   bool redo_is_sky[2] = {false, false};
   int redo_np[2] = {0, 0};
   auto pipe_ready = [&]() -> int {
-    if (!ctx->aux_stream) { int rc_ = dmm_make_cu_stream(ctx, &ctx->aux_stream, true, ctx->opt_ml_cu_split); if (rc_) return rc_; }
-    if (!ctx->aux_stream_b) { int rc_ = dmm_make_cu_stream(ctx, &ctx->aux_stream_b, true, ctx->opt_ml_cu_split); if (rc_) return rc_; }
+    if (!ctx->aux_stream) DMM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux_stream_b) DMM_HIP(hipStreamCreateWithFlags(&ctx->aux_stream_b, hipStreamNonBlocking));
     for (hipEvent_t& e : ctx->aux_ev)
       if (!e) DMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (ctx->aux_pinned_n < (size_t)cap + 1) {
@@ -1465,7 +1452,6 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.tri = n <= 2048 ? 1 : 0;
     tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
     tp.nb = sb_pending(ctx, n, tp.log_stride);
-    tp.chase_layout = sb_chase_layout(ctx, n);
     tp.stop_tol = bs_build ? 1e-16 : sb_stop_tol(ctx);  // (a basis must hold B B^H to 1e-15: its truncation enters the day's Gram matrix in first order)
     if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
     if (nr > 0) tp.log_cap = (int)std::min<int64_t>(tp.log_cap, (int64_t)L.Np * L.Np - ((int64_t)3 * runs * sizeof(int) + 15) / 16);  // (QL's log and its chase headers end where X begins)
@@ -1505,7 +1491,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         }
         if (all) hint = (mx + TB - 1) / TB * TB + TB;
       }
-      sb_chase(ctx, tp, nmat, S2, ctx->opt_ml_chase_grid, hint);
+      sb_chase(ctx, tp, nmat, S2, hint);
     }
     {
       dmm_prof_scope prof(ctx, DMM_PROF_QL, S2);

@@ -752,11 +752,6 @@ int dmm_dirty_run(dmm_plan* pl, const void* B, const void* mvis, const double* m
   if (pl->ntile == 0) return DMM_OK;
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
-  dmm_cu_scope cu_guard(ctx);  // "dirty_cu_split": the solve kernel on the CUs the side stream's alm2map does not own
-  {
-    int rc_ = cu_guard.enter(ctx->opt_dirty_cu_split);
-    if (rc_) return rc_;
-  }
   SolveParams p = base_params(pl);
   return launch_dirty<false>(pl, p, B, (const double2*)mvis, mweight, (double2*)alm);
 }
@@ -773,11 +768,6 @@ int dmm_dirty_run_multi(dmm_plan* pl, const void* B, const void* const* mvis, co
   if (pl->ntile == 0) return DMM_OK;
   dmm_ctx* ctx = pl->ctx;
   DMM_HIP(hipSetDevice(ctx->device));
-  dmm_cu_scope cu_guard(ctx);
-  {
-    int rc_ = cu_guard.enter(ctx->opt_dirty_cu_split);
-    if (rc_) return rc_;
-  }
   // groups of 8, 4, 2 days per read of B (8 days' w = Ni o v take 8 x 12 KB of LDS at cfg 3); a last single day goes
   // through the one-day kernel
   const size_t w_day = (size_t)2 * pl->npairs * sizeof(double2);  // LDS of one day's w = Ni o v

@@ -71,33 +71,12 @@ class Context:
                 least = int(torch.cuda.Stream.priority_range()[0])
             except Exception:
                 least = 0
-            every = cls.side_cu_every()
-            if every > 1:
-                # the side stream owns every `every`-th compute unit and nothing else (dmm_stream_create_cu_subset): the
-                # register- and LDS-hungry Legendre kernels of alm2map then cannot crowd the HBM-bound solve kernel off
-                # the other CUs (measured: the day beside an unconfined alm2map)
-                h = C.c_void_p()
-                _lib.check(_lib.lib.dmm_stream_create_cu_subset(int(device), int(every), 0, least, C.byref(h)))
-                st = torch.cuda.ExternalStream(int(h.value), device=dev)
-                st._dmm_owned = h  # (lives as long as the process: the context cache never drops it)
-            else:
-                try:
-                    st = torch.cuda.Stream(device=dev, priority=least)
-                except Exception:
-                    st = torch.cuda.Stream(device=dev)
+            try:
+                st = torch.cuda.Stream(device=dev, priority=least)
+            except Exception:
+                st = torch.cuda.Stream(device=dev)
             cls._side_cache[device] = cls(device, st)
         return cls._side_cache[device]
-
-    #: the side stream's share of the GPU: every N-th compute unit (0 / 1: an ordinary low-priority stream on all of them);
-    #: DRACO_AMD_SIDE_CU_EVERY overrides it (read when the side context of a device is first made)
-    SIDE_CU_EVERY = 0
-
-    @classmethod
-    def side_cu_every(cls) -> int:
-        import os
-
-        v = os.environ.get("DRACO_AMD_SIDE_CU_EVERY")
-        return int(v) if v else int(cls.SIDE_CU_EVERY)
 
     @classmethod
     def fill(cls, device: int | None = None) -> "Context":

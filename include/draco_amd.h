@@ -70,59 +70,22 @@ int dmm_ctx_destroy(dmm_ctx* ctx);
 /* run on the caller's HIP stream (hipStream_t passed as void*; NULL = default stream) */
 int dmm_ctx_set_stream(dmm_ctx* ctx, void* hip_stream);
 int dmm_ctx_sync(dmm_ctx* ctx);
-/* A HIP stream (returned as void*) whose kernels run on a SUBSET of the GPU's compute units (hipExtStreamCreateWithCUMask):
- * CU i is in the subset when i % every == phase; phase < 0 selects the complement of subset -phase - 1; every = 1: an
- * ordinary stream of the given HIP priority.  For stages that run BESIDE the HBM-bound solves on a stream of their own --
- * the reference has no counterpart (its stages run one after the other, mapmaker.py:62-118): confined to a few CUs the
- * compute-bound alm2map of finished frequencies leaves the others' registers and LDS to the solve kernel.
- * Hand it to dmm_ctx_set_stream / torch.cuda.ExternalStream; destroy with dmm_stream_destroy when nothing uses it -- a
- * caching allocator that was told `record_stream(tensor, stream)` uses it until that tensor's block is reused. */
-int dmm_stream_create_cu_subset(int device, int every, int phase, int priority, void** hip_stream);
-int dmm_stream_destroy(void* hip_stream);
-/* Options.  Two kinds:
- *  - performance only, never results (A/B switches and sizes): every name below EXCEPT the ones listed next;
- *  - accuracy-affecting: "ml_rank_stop" (on by default: an approximation of the reference's pinv_svd validated at 1.7e-9 on
- *    the structured tiles, exact for Gram matrices that are not numerically rank deficient; requires POSITIVE SEMI-DEFINITE
- *    input -- the library applies it to the Gram matrices D B B^H D / B^H N B and X X^H only; values are clamped to
- *    v >= 11, i.e. a stop no looser than 1e-11 of lambda_max, five decades under pinv_svd's relative cut of 1e-6),
- *    "ml_inner_sweeps" / "ml_outer_sweeps" (iteration caps of the Jacobi fallback).
- * "dirty_variant" (0 = default), "grid_mult",
- * "project_variant", "project_grid_mult", "ml_inner_sweeps", "ml_outer_sweeps", "sht_variant",
- * (sht_variant: bits 0-1 synthesis form, bit 2 direct ring sums, bit 3 vector-ALU Legendre kernels, bit 4 the 8-wave analysis block, bit 5 m = blockIdx.x instead of the XCD-aware block -> m map, bit 6 the first MFMA synthesis kernel (rounds 1-4) instead of the pipelined one, bit 7 the pipelined one with 4 instead of 8 frequencies per block, bit 9 the Legendre analysis with 8 instead of 4 frequencies per block), "sht_grid" (> 0: the Legendre synthesis as that many resident blocks walking the same work items; an A/B), "sht_synth_form" (1: the first MFMA form of the Legendre synthesis whatever sht_variant says -- what the shipped map-makers set around their own dmm_alm2map; same sums, 1e-12 of the map's scale apart),
- * "ml_shortcut" (0 = on; 2 = always eigen-decompose; 3 = telescope-side systems only),
- * "ml_eigen" (eigen path of the ML solve: 0 = chosen by batch size; 4 = Householder tridiagonalisation + QL kept
- * in factored form; 1 = blocked Jacobi; 2 = as 4 with full-matrix trailing updates; 3 = as 4 with QL made to give
- * up on every other matrix, which exercises the Jacobi fallback),
- * "ml_null" (0, default: a tile whose weighted Frobenius norm puts EVERY singular value at or below acond is answered
- * with zero -- what pinv_svd's rule gives -- without a Gram matrix or a decomposition, the candidates found on a sample of
- * every 16th m per frequency; 1: such tiles are decomposed like any other, with the same result; 2: every tile's norm is
- * taken, the A/B of the sampling),
- * "ml_chase_layout" (0, default: the bulge chase's band image in LDS as in round 3; 1: a layout meant to spread the bank
- * conflicts -- an A/B of DESIGN 5.5: the counted conflicts change, the run time does not),
- * "ml_rank_stop" (rank stop of the two-stage reduction, DESIGN 5.5: once the trace of a Gram matrix's trailing matrix has
- * fallen to 1e-13 of a lower bound of its largest eigenvalue -- seven decades below pinv_svd's relative cut -- the matrix is
- * cut off at that order and the bulge chase, QL and both back-transformations work on it; 0, default: on; 1: off; v >= 11:
- * on at 10^-v, 2 <= v < 11 is taken as 11), "ml_chase_split" (0, default: the bulge chase's LDS is sized for the effective order 98 % of the
- * context's matrices so far stayed under, the few above go through a second small launch; 1: one launch, full band image),
- * "ml_cu_split" (0, default: off; K >= 2: the library's side streams -- bulge chase, serial QL -- are created on every K-th CU
- * (hipExtStreamCreateWithCUMask) and dmm_ml_run moves the caller's queue to a stream on the others for the length of the
- * call: an A/B of DESIGN 5.5; set before the first dmm_ml_run of the context),
- * "ml_chase_grid" (0, default: one bulge-chase block per matrix; > 0: at most that many persistent blocks, each working
- * through several matrices -- an A/B of DESIGN 5.5),
- * "ringmap_variant" (1 = the three-kernel form of dmm_ringmap_deconvolve even where the single-pass kernel applies; 2 = the
- * single pass with 8 instead of 16 elevations per block),
- * "ml_reduce" (tridiagonal reduction of the eigen path: 0 = two-stage, dense -> band of half-width 8 on the matrix
- * cores over the lower triangle -> tridiagonal by bulge chasing in LDS, for orders whose band fits the LDS, one-stage
- * Householder otherwise; 1 = one-stage always; 2 = two-stage with sweeps over both triangles, the first form),
- * "gram_stage" (operand staging of the beam Gram kernel of the Wiener / ML solves: 0 = through registers, 1 = LDS-DMA
- * `global_load_lds_dwordx4` into a source-swizzled image, complex128 packed tiles only: the A/B of DESIGN 5.3),
- * "wiener_overlap" (1, default: the batches of dmm_wiener_run alternate between the caller's stream and a second one,
- * half the workspace each -- one batch's factorisation beside the other's Gram products; 0: one stream),
- * "ml_workspace_mib" / "wiener_workspace_mib" (size dmm_ml_workspace_bytes / dmm_wiener_workspace_bytes report,
- * i.e. the matrices solved per sub-batch; 0 = 20 GiB / 6 GiB), "profile" (1: time the kernel classes of the dense
- * solvers with HIP events on their launch streams, sums cleared; 0: off) */
+/* Options (name, integer value).  All but the first group change run time only, never results; details: INTEGRATION.md section C.
+ *  accuracy-affecting: "ml_rank_stop" (0 on at 1e-13 of lambda_max [default], 1 off, v >= 11 on at 10^-v; positive
+ *    semi-definite input only), "ml_inner_sweeps" / "ml_outer_sweeps" (iteration caps of the Jacobi fallback);
+ *  ML path: "ml_shortcut" (0 certificate on, 2 always eigen-decompose, 3 telescope side only), "ml_eigen" (0 by batch
+ *    size, 4 tridiagonal + QL, 1 blocked Jacobi, 2 full-matrix trailing updates, 3 QL made to fail: tests), "ml_null"
+ *    (0 sampled null certificate, 1 off, 2 every tile), "ml_reduce" (0 two-stage with every other update deferred,
+ *    2 none deferred, 1 one-stage), "ml_chase_split" (1: one chase launch with the full band image), "gram_stage"
+ *    (1: LDS-DMA operand staging of the Gram kernel), "wiener_overlap" (0: one stream);
+ *  sizes: "ml_workspace_mib" / "wiener_workspace_mib" (0 = 20 / 6 GiB), "grid_mult", "project_grid_mult";
+ *  kernel forms: "dirty_variant", "dirty_static", "dirty_prio", "project_variant", "ringmap_variant" (1 three-kernel
+ *    form, 2 eight elevations per block), "sht_variant" (bits: 0-1 vector-ALU synthesis form, 2 direct ring sums,
+ *    3 vector-ALU Legendre kernels, 4 eight-wave analysis block, 5 m = blockIdx.x, 6 first MFMA synthesis form,
+ *    7 pipelined synthesis with 4 frequencies per block, 11 radix-4 ring FFTs), "sht_synth_form" (1: first MFMA form);
+ *  "profile" (1: HIP-event timing of the dense solvers' kernel classes, sums cleared; 0 off). */
 int dmm_ctx_set_option(dmm_ctx* ctx, const char* name, int64_t value);
-/* diagnostics counters, cumulative per context: "ml_tiles_direct" (tiles whose pseudo-inverse was
+/* diagnostics counters, cumulative per context ("opt_sht_synth_form": that option's current value): "ml_tiles_direct" (tiles whose pseudo-inverse was
  * certified to cut no mode and solved by Cholesky), "ml_tiles_eigen" (tiles eigen-decomposed), "ml_tiles_null" (tiles answered with zero by the null certificate: every
  * singular value at or below acond), "ml_tiles_stopped" / "ml_stop_cols" (eigen-decomposed tiles whose reduction the rank stop cut off,
  * and the sum of their effective orders), "ml_gram_flops" / "ml_band_bytes" (useful flops 4 k^2 K of the
@@ -169,7 +132,9 @@ int dmm_ctx_set_ml_gram_cache(dmm_ctx* ctx, void* cache, int32_t* valid, int64_t
  *   build = 0: dmm_ml_run takes the basis route for every chunk whose tiles all have a basis -- and whose small problem fits
  *              the workspace beside the basis product (otherwise the chunk keeps the full-order path).  The library sizes the
  *              chunks from a host copy of `rank`, taken when the array is first used through this context and kept until a
- *              build through this context; build = 2: as 0, and take the copy again (the array was written by other means).
+ *              build through this context; build = 2: as 0, and take the copy again.  The copy is keyed on the `rank`
+ *              POINTER alone: build = 2 is MANDATORY after the array was written by other means (another context, a
+ *              copy) or freed and allocated again at the same address.
  * U = NULL: off.  The arrays are the caller's and live with the B block they were computed from.
  * Accuracy: the bases are truncated at 1e-15 of the largest eigenvalue of the UNWEIGHTED B B^H; a day whose non-zero noise
  * weights span more than six decades should use the full-order path (the dropped modes enter the day's Gram matrix at up to

@@ -155,15 +155,8 @@ def test_resident_product_entries_check_their_arguments():
     assert lib.dmm_ml_gram_cache_slots(None) == 0 and lib.dmm_ml_gram_cache_bytes(None) == 0
 
 
-def test_round5_stream_entry_points_check_their_arguments():
-    """`dmm_stream_create_cu_subset`: the subset rule is checked before HIP is touched; destroying nothing is fine."""
+def test_round5_option_names_check_their_context():
+    """Options are refused on a NULL context before anything is dereferenced."""
     lib = _lib.lib
-    out = C.c_void_p()
-    _arg_error(lib.dmm_stream_create_cu_subset(0, 8, 0, 0, None), "every in 1..64")
-    _arg_error(lib.dmm_stream_create_cu_subset(0, 0, 0, 0, C.byref(out)), "every in 1..64")
-    _arg_error(lib.dmm_stream_create_cu_subset(0, 65, 0, 0, C.byref(out)), "every in 1..64")
-    _arg_error(lib.dmm_stream_create_cu_subset(0, 8, 8, 0, C.byref(out)), "phase in -every..every-1")
-    _arg_error(lib.dmm_stream_create_cu_subset(0, 8, -9, 0, C.byref(out)), "phase in -every..every-1")
-    assert lib.dmm_stream_destroy(None) == 0
-    for name in (b"sht_grid", b"sht_synth_form", b"ml_cu_split", b"dirty_cu_split"):
+    for name in (b"sht_synth_form", b"ml_reduce"):
         _arg_error(lib.dmm_ctx_set_option(None, name, 1), "NULL")

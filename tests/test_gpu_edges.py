@@ -402,72 +402,3 @@ def test_allgather_map_through_the_c_abi_on_a_one_rank_communicator():
     finally:
         _lib.check(lib.dmm_comm_destroy(comm))
 
-
-def test_a_cu_subset_stream_runs_the_transform_to_the_same_bits():
-    """`dmm_stream_create_cu_subset` (round 5): a context on a stream confined to every 8th compute unit, and one on the
-    complement, give the maps of the unconfined stream bit for bit -- where a kernel runs changes nothing it computes."""
-    import ctypes as C
-
-    import torch
-
-    from draco_amd import _lib
-    from draco_amd.device import Context, ptr
-
-    ctx = Context.get()
-    gen = torch.Generator(device=ctx.device).manual_seed(3)
-    nf, lmax, nside = 3, 64, 32
-    alm = torch.randn((nf, 4, lmax + 1, lmax + 1), dtype=torch.complex128, device=ctx.device, generator=gen)
-    ref = ctx.empty((nf, 4, 12 * nside * nside), np.float64)
-    _lib.check(_lib.lib.dmm_alm2map(ctx.handle, ptr(alm), nf, 4, lmax, lmax, nside, ptr(ref)))
-    ctx.sync()
-    for every, phase in ((8, 0), (8, -1), (1, 0)):
-        h = C.c_void_p()
-        _lib.check(_lib.lib.dmm_stream_create_cu_subset(ctx.device_index, every, phase, 0, C.byref(h)))
-        st = torch.cuda.ExternalStream(int(h.value), device=ctx.device)
-        side = Context(ctx.device_index, st)
-        out = ctx.empty((nf, 4, 12 * nside * nside), np.float64)
-        side.wait_for(torch.cuda.current_stream(ctx.device))
-        # (no `record_stream` on a stream that is about to be destroyed: the caching allocator would record an event on it
-        # when the tensors die; `alm` and `out` outlive the synchronisation below instead)
-        _lib.check(_lib.lib.dmm_alm2map(side.handle, ptr(alm), nf, 4, lmax, lmax, nside, ptr(out)))
-        st.synchronize()
-        assert torch.equal(out, ref), (every, phase)
-        _lib.check(_lib.lib.dmm_ctx_destroy(side.handle))
-        side.handle = None
-        del side, st
-        torch.cuda.synchronize()
-        _lib.check(_lib.lib.dmm_stream_destroy(h))
-
-
-def test_cu_split_options_change_no_result():
-    """`dirty_cu_split` / `ml_cu_split` (round 5's A/B knobs: the call's launches on a library-owned stream confined to a
-    subset of the compute units, ordered with the caller's stream by events): the a_lm of the Dirty and the ML maker are
-    the same bits with and without them, and agree with the oracle."""
-    from draco_amd import _lib
-    from draco_amd.analysis.mapmaker import DirtyMapMaker, MaximumLikelihoodMapMaker
-    from draco_amd.core import containers
-    from draco_amd.core.products import SyntheticProvider
-    from draco_amd.device import Context
-
-    ctx = Context.get()
-    tel = _tel(2, 12)
-    bt = SyntheticProvider(tel, seed=4)
-    rng = np.random.default_rng(4)
-    shape = (13, 2, 2, tel.npairs)
-    mv = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
-    mw = rng.uniform(0.5, 1.5, shape) * 30
-    mm = containers.MModes(mmax=12, freq=tel.frequencies, stack=tel.npairs)
-    mm.vis[:] = mv
-    mm.weight[:] = mw
-    beam = lambda m, f: osyn.beam_tile(4, m, f, tel.npairs, 4, 12)  # noqa: E731
-    for cls, kind, opt, tol in ((DirtyMapMaker, "dirty", b"dirty_cu_split", 1e-12), (MaximumLikelihoodMapMaker, "ml", b"ml_cu_split", 1e-8)):
-        task = cls()
-        task.setup(bt)
-        ref = task.alm_square(task.make_alm(mm))
-        try:
-            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt, 8))
-            got = task.alm_square(task.make_alm(mm))
-        finally:
-            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, opt, 0))
-        assert np.array_equal(got, ref), kind
-        assert _rel(got, omm.solve_alm(kind, beam, mv, mw, 12, 12, [0, 1])) < tol, kind
