@@ -578,7 +578,13 @@ class SolveEngine:
         self.last_b_bytes = 0
         for slab in self.slabs(freq_ind, mmax, nfreq, n_m):
             self.last_b_bytes += slab.b_bytes
+            if self.launch_events is not None:  # (HIP events on the launch stream, as around the Dirty launches)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             _lib.check(_lib.lib.dmm_project_run(slab.plan, ptr(slab.pool), ptr(alm_d), ptr(vis)))
+            if self.launch_events is not None:
+                e1.record()
+                self.launch_events.append((e0, e1, slab.b_bytes, slab.ntile))
         return vis
 
 
