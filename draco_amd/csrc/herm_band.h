@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
   if (k > 0) {
     const int org_prev = (kSbB * k) & ~15;
-    const int nw = (n - org_prev + 63) / 64;  // pieces of M: one per column block of the sweep
+    const int nw = tp.zfull ? 1 : (n - org_prev + 63) / 64;  // pieces of M: one per column block of the sweep (one: k_sb_sweep_one)
     const double* const Zpa = sb_Zp(tp, mat);
     double acc = 0.0;
     for (int w = 0; w < nw; ++w) acc += Mpa[(int64_t)w * 256 + t];
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
         v[c] = Vold[(int64_t)r * kSbB + c];
       }
       {  // + the row contributions of the column blocks left of this row's tile (in block order)
-        const int nb = ((r - org_prev) / 16 * 16 + 63) / 64;
+        const int nb = tp.zfull ? 0 : ((r - org_prev) / 16 * 16 + 63) / 64;
         // (ROWS = 3, the kernel of the early panels -- 256 registers anyway --: three blocks' partials in flight at a time.
         // One at a time, a row waited for up to twelve round trips to memory in turn: a third of the kernel's time.  The
         // additions keep their order.  The later panels' kernels keep their smaller register budgets.)
@@ -818,6 +818,168 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
       Mw[(lk + 4 * reg) * 16 + lr] = (sR[reg * 64 + lane] + sR[256 + reg * 64 + lane]) + (sR[512 + reg * 64 + lane] + sR[768 + reg * 64 + lane]);
+  }
+}
+
+// ------------------------------------------------------------------ stage 1: the reading sweep, one block per matrix
+// ("ml_reduce" = 3; not the default.)  A sweep that only READS the matrix moves 4.5 KB per tile -- and, as column blocks of
+// a grid, another 0.5 KB of partial row sums Z_I that the panel kernel adds up: scattered 2 KB writes beside the read
+// stream, which cost the sweep +43 % (tools/probe/tri_read_probe.hip; mixed read / write traffic is what HBM does badly),
+// plus a reduction epilogue per block.  Here ONE block of 8 waves owns the whole trailing matrix: Z (n x 8 complex, 96 KB
+// at order 768) lives in LDS, the 64-column strips are worked through one after the other -- inside a strip a row step
+// belongs to one wave, so its row sums go into the LDS image by a plain read-modify-write, and the strips' column sums are
+// added in strip order: deterministic -- and Z, M = V'^H Z leave once, complete (tp.zfull tells the panel kernel: no
+// partials to add).  Measured (profiles/r06_ml_stage1_ab.txt): alone, a full chunk, 1.07 against 1.28 ms per launch
+// (5.05 against 4.2 TB/s), and the panel kernel after it 279 against 337 us; in the pass the same 845 ms of stage 1 per 32
+// frequencies -- a block needs 147 KB of a CU's LDS and waits for the previous chunk's bulge-chase blocks to leave
+// (4.7 / 2.5 / 2.0 ms for a chunk's first launches where the grid form takes 3.2 / 1.8 / 1.6).  Kept as the A/B.
+constexpr int kSbOneWaves = 8;
+__host__ __device__ constexpr size_t sb_one_lds(int rows) { return ((size_t)rows * 16 + 64 * 16 + (size_t)kSbOneWaves * 2 * 16 * 17) * sizeof(double); }
+__global__ __launch_bounds__(64 * kSbOneWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sb_sweep_one(TdParams tp) {
+  extern __shared__ __align__(16) double sb_one_smem[];
+  const DenseParams& p = tp.d;
+  const int n = p.Np, k = tp.j;
+  const int mat = p.msel ? p.msel[blockIdx.x] : blockIdx.x;
+  if (sb_stopped(tp, mat)) return;  // (uniform over the block)
+  const double2* A = p.A + (int64_t)mat * n * n;
+  const double2* Vnew = sb_V(tp, mat, k);
+  const int org = (kSbB * (k + 1)) & ~15, rows = n - org;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const bool lo = lr < 8;
+  const int vq = lr & 7;
+  double* const Zl = sb_one_smem;                      // [rows][16]: Re Z[.][0..7] | Im Z[.][0..7]
+  double* const sB = Zl + (size_t)rows * 16;           // [64][16]: per column of the strip [V'r | V'i]
+  double* const tre = sB + 64 * 16 + (size_t)wave * 2 * 16 * 17;  // per wave: the tile transposed, real / imaginary plane
+  double* const tim = tre + 16 * 17;
+  double* const sR = sB + 64 * 16;                     // (the waves' transposition images double as the reduction buffer)
+  for (int e = threadIdx.x; e < rows * 16; e += 64 * kSbOneWaves) Zl[e] = 0.0;
+  const int nblk = (rows + 63) / 64;
+  for (int bx = 0; bx < nblk; ++bx) {
+    const int cb0 = org + 64 * bx;
+    const int ntile = min(4, (n - cb0) / 16), nstep = (n - cb0) / 16;
+    __syncthreads();  // (the previous strip's readers of sB / sR are done; Zl zeroed)
+    for (int idx = threadIdx.x; idx < 64 * kSbB; idx += 64 * kSbOneWaves) {
+      const int col = idx >> 3, q = idx & 7;
+      double2 vn = make_double2(0.0, 0.0);
+      if (cb0 + col < n) vn = Vnew[(int64_t)(cb0 + col) * kSbB + q];
+      sB[col * 16 + q] = vn.x, sB[col * 16 + 8 + q] = vn.y;
+    }
+    __syncthreads();
+    v4d zc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) zc[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double2 cc[4];
+    if (wave < nstep) {
+      const double2* cp = A + (int64_t)(cb0 + 16 * wave + lk) * n + cb0 + lr;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) cc[reg] = cp[(int64_t)4 * reg * n];
+    }
+    for (int t = wave; t < nstep; t += kSbOneWaves) {
+      const int r0 = cb0 + 16 * t;
+      const int ncb = min(t + 1, ntile);  // tiles of this row step; tile t (if it exists) is the diagonal one
+      const double2* const rowp = A + (int64_t)(r0 + lk) * n + cb0 + lr;
+      double b1[4], b2[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const double2 vn = Vnew[(int64_t)(r0 + lk + 4 * reg) * kSbB + vq];
+        b1[reg] = lo ? vn.x : vn.y;
+        b2[reg] = lo ? vn.y : -vn.x;
+      }
+      v4d zr = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        if (cb < ncb) {
+          v4d cre, cim;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) cre[reg] = cc[reg].x, cim[reg] = cc[reg].y;
+          {  // the next tile's loads fly under this tile's MFMAs
+            const double2* nx = cb + 1 < ncb ? rowp + 16 * (cb + 1) : rowp + (int64_t)16 * kSbOneWaves * n;
+            if (cb + 1 < ncb || t + kSbOneWaves < nstep) {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) cc[reg] = nx[(int64_t)4 * reg * n];
+            }
+          }
+          // Z_J += C^H V'_I
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            zc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cre[reg], b1[reg], zc[cb], 0, 0, 0);
+            zc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(cim[reg], b2[reg], zc[cb], 0, 0, 0);
+          }
+          if (cb < t) {  // below the diagonal: Z_I += C V'_J
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              tre[lr * 17 + 4 * reg + lk] = cre[reg];
+              tim[lr * 17 + 4 * reg + lk] = cim[reg];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: the LDS serves its requests in order)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const double are = tre[(4 * s + lk) * 17 + lr], aim = tim[(4 * s + lk) * 17 + lr];
+              // [V'r | V'i] of column 16 cb + 4 s + lk, and [-V'i | V'r] read from the same row with the halves swapped
+              const double r1 = sB[(16 * cb + 4 * s + lk) * 16 + lr], rs = sB[(16 * cb + 4 * s + lk) * 16 + (lr ^ 8)];
+              const double r2 = lo ? -rs : rs;
+              zr = __builtin_amdgcn_mfma_f64_16x16x4f64(are, r1, zr, 0, 0, 0);
+              zr = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, r2, zr, 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+      if (t > 0) {  // the step's row sums: rows r0 .. r0 + 15 belong to this wave for the length of the strip
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Zl[(size_t)(r0 - org + lk + 4 * reg) * 16 + lr] += zr[reg];
+      }
+    }
+    // the strip's column sums: over the waves in wave order, two column tiles per round, into rows cb0 .. cb0 + 63 of the image
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) sR[((wave * 2 + c2) * 4 + reg) * 64 + lane] = zc[2 * h + c2][reg];
+      }
+      __syncthreads();
+      if (wave < 2) {
+        const int cb = 2 * h + wave;
+        if (cb < ntile) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            double zs = 0.0;
+#pragma unroll
+            for (int w = 0; w < kSbOneWaves; ++w) zs += sR[((w * 2 + wave) * 4 + reg) * 64 + lane];
+            Zl[(size_t)(cb0 - org + 16 * cb + lk + 4 * reg) * 16 + lr] += zs;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // Z leaves complete; M = V'^H Z as ONE 16 x 16 real piece [[Vr'Zr, Vr'Zi], [Vi'Zr, Vi'Zi]] (rows in groups of 4 over the waves)
+  double2* const Zg = sb_Z(tp, mat);
+  for (int e = threadIdx.x; e < rows * kSbB; e += 64 * kSbOneWaves) {
+    const int r = e >> 3, q = e & 7;
+    Zg[(int64_t)(org + r) * kSbB + q] = make_double2(Zl[(size_t)r * 16 + q], Zl[(size_t)r * 16 + 8 + q]);
+  }
+  v4d mp = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int r = 4 * wave + lk; r < rows; r += 4 * kSbOneWaves) {
+    const double2 vj = Vnew[(int64_t)(org + r) * kSbB + vq];
+    mp = __builtin_amdgcn_mfma_f64_16x16x4f64(lo ? vj.x : vj.y, Zl[(size_t)r * 16 + lr], mp, 0, 0, 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) sR[(wave * 4 + reg) * 64 + lane] = mp[reg];
+  __syncthreads();
+  if (wave == 0) {
+    double* Mw = sb_Mp(tp, mat);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      double m = 0.0;
+#pragma unroll
+      for (int w = 0; w < kSbOneWaves; ++w) m += sR[(w * 4 + reg) * 64 + lane];
+      Mw[(lk + 4 * reg) * 16 + lr] = m;
+    }
   }
 }
 

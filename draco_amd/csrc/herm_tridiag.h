@@ -51,6 +51,8 @@ struct TdParams {
   int nb;              // two-stage reduction, stage 1: most two-sided updates left pending (1: every sweep applies its
                        // predecessor's update, rounds 3-5; herm_band.h), and p0, the oldest pending panel at this launch
   int p0;
+  int one_block;       // 1: reading sweeps run as k_sb_sweep_one
+  int zfull;           // 1: the sweep before this panel was the one-block-per-matrix form (k_sb_sweep_one): Z and M arrive complete
   // basis build (dmm_ctx_set_ml_basis, build = 1): PH 3 writes the eigenvectors of the kept eigenvalues instead of solving
   double2* bs_U;       // [slot][bs_rmax][bs_ld]: row j = conj of the j-th kept eigenvector (nullptr: normal solve)
   double* bs_sigma;    // [slot][bs_rmax] sqrt(lambda_j)

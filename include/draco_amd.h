@@ -75,8 +75,8 @@ int dmm_ctx_sync(dmm_ctx* ctx);
  *    semi-definite input only), "ml_inner_sweeps" / "ml_outer_sweeps" (iteration caps of the Jacobi fallback);
  *  ML path: "ml_shortcut" (0 certificate on, 2 always eigen-decompose, 3 telescope side only), "ml_eigen" (0 by batch
  *    size, 4 tridiagonal + QL, 1 blocked Jacobi, 2 full-matrix trailing updates, 3 QL made to fail: tests), "ml_null"
- *    (0 sampled null certificate, 1 off, 2 every tile), "ml_reduce" (0 two-stage with every other update deferred,
- *    2 none deferred, 1 one-stage), "ml_chase_split" (1: one chase launch with the full band image), "gram_stage"
+ *    (0 sampled null certificate, 1 off, 2 every tile), "ml_reduce" (0 two-stage with every other update deferred;
+ *    3 its reading sweeps as one block per matrix; 2 none deferred; 1 one-stage), "ml_chase_split" (1: one chase launch with the full band image), "gram_stage"
  *    (1: LDS-DMA operand staging of the Gram kernel), "wiener_overlap" (0: one stream);
  *  sizes: "ml_workspace_mib" / "wiener_workspace_mib" (0 = 20 / 6 GiB), "grid_mult", "project_grid_mult";
  *  kernel forms: "dirty_variant", "dirty_static", "dirty_prio", "project_variant", "ringmap_variant" (1 three-kernel

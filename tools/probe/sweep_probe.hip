@@ -45,8 +45,17 @@ int main(int argc, char** argv) {
   k_fill<<<2048, 256>>>(tp.log_cs, (int64_t)nmat * tp.log_stride, 1e-3);
   hipDeviceSynchronize();
   printf("# nmat %d, order %d; times per launch; bytes = algorithmic (4.5 / 8.5 KB per tile)\n", nmat, n);
+  hipFuncSetAttribute((const void*)k_sb_sweep_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_one_lds(n));
   for (int k : {0, 8, 16, 24, 32, 48}) {
     tp.j = k;
+    {
+      const int org1 = (kSbB * (k + 1)) & ~15;
+      const double t1 = (n - org1) / 16, tiles1 = t1 * (t1 + 1) / 2 * nmat, gb1 = tiles1 * 4.5 * 1024 / 1e9;
+      tp.nb = kSbNB;
+      tp.p0 = k;
+      const double ms1 = time_ms([&]() { hipLaunchKernelGGL(k_sb_sweep_one, dim3(nmat), dim3(64 * kSbOneWaves), sb_one_lds(n - org1), 0, tp); }, 5);
+      printf("sweep_one k=%2d: %8.3f ms  %7.1f GB/s  (%.2f GB: one block per matrix, Z in LDS, no partial sums)\n", k, ms1, gb1 / ms1 * 1e3, gb1);
+    }
     const int org = (kSbB * (k + 1)) & ~15, nblk = (n - org + 63) / 64;
     const double t = (n - org) / 16, tiles = t * (t + 1) / 2 * nmat;
     for (int np : {0, 1, 2, 4}) {
