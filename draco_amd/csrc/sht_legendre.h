@@ -334,8 +334,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_leg_synth_mfma(LegParams p) { l
 //    the per-l broadcasts shrink from 14 v_readlane to 4 (ra, rb);
 //  * the recurrence of chunk c + 1 is interleaved, step by step, with the products of chunk c (other buffer), and the LDS
 //    reads of a group's operands are issued BEFORE the previous group's products, so their round trip runs under them;
-//  * ring tiles go round robin over the waves of all blocks of an (m, frequency group) and a tile none of whose rings has
-//    reached the scale of its values is skipped (wave-uniform): no operands, no products;
+//  * ring tiles go round robin over the waves of all blocks of an (m, frequency group); a wave none of whose rings takes part
+//    (all beyond the polar cut-off of this m) leaves at once, and while any ring is still below the scale of its values the
+//    chunk loop runs its rescaling form (two loops, not a branch inside one) -- the products of a tile are issued
+//    unconditionally (an earlier version of this comment claimed a per-tile skip that the code does not have);
 //  * the loads of a chunk use one uniform base and 32-bit lane offsets; signs and the zeros beyond lmax are applied to the
 //    B values once per chunk, the masks only where a chunk is ragged.
 // Same products, same summation order per accumulator as the first form; lambda_{l-1} of the step at which a ring's scale
