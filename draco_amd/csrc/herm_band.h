@@ -832,7 +832,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 
 // partials to add).  Measured (profiles/r06_ml_stage1_ab.txt): alone, a full chunk, 1.07 against 1.28 ms per launch
 // (5.05 against 4.2 TB/s), and the panel kernel after it 279 against 337 us; in the pass the same 845 ms of stage 1 per 32
 // frequencies -- a block needs 147 KB of a CU's LDS and waits for the previous chunk's bulge-chase blocks to leave
-// (4.7 / 2.5 / 2.0 ms for a chunk's first launches where the grid form takes 3.2 / 1.8 / 1.6).  Kept as the A/B.
+// (4.7 / 2.5 / 2.0 ms for a chunk's first launches where the grid form takes 3.2 / 1.8 / 1.6), and once matrices stop a
+// block per matrix no longer fills the GPU.  Used only for the panels of a chunk where it pays (the 7th until the chunk's
+// smallest remembered order is near) it bought 1 % of stage 1 -- and made a tile's bits depend on its chunk's history
+// (the two forms add in different orders): dropped, the form stays an explicit mode.
 constexpr int kSbOneWaves = 8;
 __host__ __device__ constexpr size_t sb_one_lds(int rows) { return ((size_t)rows * 16 + 64 * 16 + (size_t)kSbOneWaves * 2 * 16 * 17) * sizeof(double); }
 __global__ __launch_bounds__(64 * kSbOneWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sb_sweep_one(TdParams tp) {

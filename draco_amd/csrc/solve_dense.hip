@@ -1185,7 +1185,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
         tp.nb = sb_pending(ctx, n, tp.log_stride);
     tp.one_block = ctx->opt_ml_reduce == 3 ? 1 : 0;
-        tp.one_block = ctx->opt_ml_reduce == 3 ? 1 : 0;  // ("ml_reduce" = 3: the reading sweeps as one block per matrix -- 16-20 % faster alone, the same in the pass: herm_band.h)
+        tp.one_block = ctx->opt_ml_reduce == 3 ? 1 : 0;  // ("ml_reduce" = 3: every reading sweep as one block per matrix: herm_band.h)
         tp.stop_tol = sb_stop_tol(ctx);
         tp.bs_U = nullptr;
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
