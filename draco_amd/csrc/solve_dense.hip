@@ -1184,7 +1184,6 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.tri = (n <= 2048 && ctx->opt_ml_eigen != 2) ? 1 : 0;  // ml_eigen = 2: full-matrix trailing updates
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
         tp.nb = sb_pending(ctx, n, tp.log_stride);
-    tp.one_block = ctx->opt_ml_reduce == 3 ? 1 : 0;
         tp.one_block = ctx->opt_ml_reduce == 3 ? 1 : 0;  // ("ml_reduce" = 3: every reading sweep as one block per matrix: herm_band.h)
         tp.stop_tol = sb_stop_tol(ctx);
         tp.bs_U = nullptr;
