@@ -589,3 +589,57 @@ def test_resident_beam_bases_weight_guard_is_taken_per_day():
     plain.setup(bt)
     a_ref = day(plain, w)
     assert np.abs(a2 - a_ref).max() <= 1e-9 * np.abs(a_ref).max()
+
+
+def test_stage1_forms_keep_the_same_modes_on_structured_tiles():
+    """Round 6: the three forms of stage 1 of the band reduction -- every other two-sided update deferred (default), the same
+    with the reading sweeps as one block per matrix ("ml_reduce" = 3), no update deferred ("ml_reduce" = 2: rounds 3-5) --
+    on structured, cut-truncated tiles where the rank stop engages (the running diagonal of the deferred forms against the
+    stored one of the undeferred): the same modes kept on every tile, a_lm within the solver's own resolution, and the
+    highest-rank tile against the oracle's SVD."""
+    import torch
+
+    from draco_amd import _lib
+    from draco_amd.analysis.mapmaker import MaximumLikelihoodMapMaker
+    from draco_amd.core import containers
+    from draco_amd.core.products import BeamScreenProvider, TransitTelescope
+    from draco_amd.device import Context, ptr
+
+    ctx = Context.get()
+    lmax = 256
+    tel = TransitTelescope(np.array([600.0]), lmax=lmax, ncyl=2, nfeed_cyl=16)
+    bt = BeamScreenProvider(tel, seed=3003, feed_sep=1.0, sigma_n=1.2)
+    shape = (lmax + 1, 2, 1, tel.npairs)
+    gen = torch.Generator(device=ctx.device).manual_seed(37)
+    mv = torch.randn(shape, dtype=torch.complex128, device=ctx.device, generator=gen)
+    mw = (torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) + 0.5) * 2e4
+    mw[torch.rand(shape, dtype=torch.float64, device=ctx.device, generator=gen) < 0.02] = 0.0
+    mm = containers.MModes(mmax=lmax, freq=tel.frequencies, stack=tel.npairs, allocate=False)
+    mm.attach("vis", mv)
+    mm.attach("vis_weight", mw)
+    per_f = sum(2 * tel.npairs * 4 * (lmax + 1 - m) for m in range(lmax + 1)) * 16
+    task = MaximumLikelihoodMapMaker(nside=64, pool_bytes=per_f + (1 << 20))
+    task.setup(bt)
+    out, ranks = {}, {}
+    try:
+        for red in (0, 3, 2):
+            _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", red))
+            diag = torch.full((1, lmax + 1, 4), -1.0, dtype=torch.float64, device=ctx.device)
+            _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, ptr(diag)))
+            try:
+                out[red] = task.make_alm(mm).cpu().numpy()
+                ctx.sync()
+            finally:
+                _lib.check(_lib.lib.dmm_ctx_set_ml_diag(ctx.handle, None))
+            ranks[red] = diag.cpu().numpy()[0, :, 0]
+    finally:
+        _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", 0))
+    assert ranks[0].max() > 32  # (tiles that are really decomposed and truncated)
+    scale = np.abs(out[2]).max()
+    for red in (0, 3):
+        assert np.array_equal(ranks[red], ranks[2]), red
+        assert np.abs(out[red] - out[2]).max() < 2e-8 * scale, (red, np.abs(out[red] - out[2]).max() / scale)
+    m = int(np.argmax(ranks[0]))
+    ref, rank_o, _ = omm.ml_solve_with_spectrum(bt.beam_m(m, fi=0), mv.cpu().numpy()[m, :, 0], mw.cpu().numpy()[m, :, 0])
+    assert int(ranks[0][m]) == rank_o
+    assert _rel(out[0][0, :, m, :], ref) < 1e-7
