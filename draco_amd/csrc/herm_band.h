@@ -244,7 +244,8 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
   // ---- finish update k-1:  M = V^H Z arrives as one 16 x 16 real block per wave of sweep k-1 (k_sb_sweep's epilogue)
   if (k > 0) {
     const int org_prev = (kSbB * k) & ~15;
-    const int nw = tp.zfull ? 1 : (n - org_prev + 63) / 64;  // pieces of M: one per column block of the sweep (one: k_sb_sweep_one)
+    const int zw = tp.zw;  // columns per block of the sweep before this panel (64; 128 for a reading sweep)
+    const int nw = tp.zfull ? 1 : (n - org_prev + zw - 1) / zw;  // pieces of M: one per column block of the sweep (one: k_sb_sweep_one)
     const double* const Zpa = sb_Zp(tp, mat);
     double acc = 0.0;
     for (int w = 0; w < nw; ++w) acc += Mpa[(int64_t)w * 256 + t];
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void k_sb_panel(TdParams tp) {
         v[c] = Vold[(int64_t)r * kSbB + c];
       }
       {  // + the row contributions of the column blocks left of this row's tile (in block order)
-        const int nb = tp.zfull ? 0 : ((r - org_prev) / 16 * 16 + 63) / 64;
+        const int nb = tp.zfull ? 0 : ((r - org_prev) / 16 * 16 + zw - 1) / zw;
         // (ROWS = 3, the kernel of the early panels -- 256 registers anyway --: three blocks' partials in flight at a time.
         // One at a time, a row waited for up to twelve round trips to memory in turn: a third of the kernel's time.  The
         // additions keep their order.  The later panels' kernels keep their smaller register budgets.)
@@ -636,10 +637,15 @@ __global__ __launch_bounds__(kThreads) void k_sb_pend(TdParams tp) {
 // The upper triangle is never touched outside the diagonal tiles (the reflectors of finished panels live there).
 // The J-side operands (X_p, V_p of the pending updates, V' of panel k for the block's 64 columns) sit in LDS in the lane
 // order of the MFMA B operands.
+// column tiles of a block: 4 (64 columns); 8 for the reading sweep -- half the partial row sums, half the V' operand rows, half
+// the epilogues (tools/probe/tri_read_probe.hip: 1.14 against 1.24 ms), at two instead of three waves per SIMD, which that
+// kernel does not mind
+__host__ __device__ constexpr int sb_ncb(int np) { return np == 0 ? 8 : 4; }
 template <int NP>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 1 ? 3 : 2))) void k_sb_sweep_lo(TdParams tp) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP == 1 ? 3 : 2))) void k_sb_sweep_lo(TdParams tp) {
+  constexpr int NCB = sb_ncb(NP), BW = 16 * NCB;
   __shared__ double sJ[NP > 0 ? NP : 1][4][kSbB][NP > 0 ? 64 : 1];  // Xr, Xi, Vr, Vi of pending update pi: [q][column]
-  __shared__ double sB[2][64][16];     // per column [V'r | V'i] and [-V'i | V'r] (entries q = 0..7 each)
+  __shared__ double sB[2][BW][16];     // per column [V'r | V'i] and [-V'i | V'r] (entries q = 0..7 each)
   __shared__ double sT[4][2][16 * 17]; // per wave: the tile transposed, real and imaginary plane; at the end the reduction buffer
   const DenseParams& p = tp.d;
   const int n = p.Np, k = tp.j;
@@ -653,8 +659,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 
   const int org = (kSbB * (k + 1)) & ~15;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const int cb0 = org + 64 * bx;     // first column of the block (< n by the grid)
-  const int ntile = min(4, (n - cb0) / 16);  // its column tiles
+  const int cb0 = org + BW * bx;     // first column of the block (< n by the grid)
+  const int ntile = min(NCB, (n - cb0) / 16);  // its column tiles
   const double2* Vp[NP > 0 ? NP : 1];
   const double2* Xp[NP > 0 ? NP : 1];
 #pragma unroll
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 
     Vp[pi] = sb_V(tp, mat, tp.p0 + pi);
     Xp[pi] = sb_X(tp, mat, tp.p0 + pi);
   }
-  for (int idx = threadIdx.x; idx < 64 * kSbB; idx += kThreads) {
+  for (int idx = threadIdx.x; idx < BW * kSbB; idx += kThreads) {
     const int col = idx >> 3, q = idx & 7;
     double2 vn = make_double2(0.0, 0.0);
     if (cb0 + col < n) vn = Vnew[(int64_t)(cb0 + col) * kSbB + q];
@@ -687,9 +693,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 
   double* const tre = &sT[wave][0][0];
   double* const tim = &sT[wave][1][0];
   double* const Zp = sb_Zp(tp, mat) + (int64_t)bx * n * 16;
-  v4d zc[4], mp = (v4d){0.0, 0.0, 0.0, 0.0};
+  v4d zc[NCB], mp = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) zc[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int cb = 0; cb < NCB; ++cb) zc[cb] = (v4d){0.0, 0.0, 0.0, 0.0};
   const int nstep = (n - cb0) / 16;
   double2 cc[4];
   if (wave < nstep) {
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 
     }
     v4d zr = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
       if (cb < ncb) {
         v4d cre, cim;
 #pragma unroll
@@ -791,11 +797,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(NP <= 
   __syncthreads();
   double* const sR = &sT[0][0][0];
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) {
+  for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) sR[wave * 256 + reg * 64 + lane] = zc[cb][reg];
     __syncthreads();
-    if (wave == cb && cb < ntile) {
+    if (wave == (cb & 3) && cb < ntile) {
       const int c0 = cb0 + 16 * cb;
       double* Zd = reinterpret_cast<double*>(sb_Z(tp, mat));
 #pragma unroll

@@ -52,6 +52,7 @@ struct TdParams {
                        // predecessor's update, rounds 3-5; herm_band.h), and p0, the oldest pending panel at this launch
   int p0;
   int one_block;       // 1: reading sweeps run as k_sb_sweep_one
+  int zw;              // columns per block of the sweep before this panel (the width of its partial row sums)
   int zfull;           // 1: the sweep before this panel was the one-block-per-matrix form (k_sb_sweep_one): Z and M arrive complete
   // basis build (dmm_ctx_set_ml_basis, build = 1): PH 3 writes the eigenvectors of the kept eigenvalues instead of solving
   double2* bs_U;       // [slot][bs_rmax][bs_ld]: row j = conj of the j-th kept eigenvector (nullptr: normal solve)

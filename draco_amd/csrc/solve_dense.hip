@@ -124,11 +124,13 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
     else hipLaunchKernelGGL(k_sb_panel<4>, dim3(nmat), dim3(kThreads), 0, st, tp);
   };
   tp.p0 = 0;
-  int zfull_next = 0;
+  int zfull_next = 0, zw_next = 64;
   for (int k = 0; k < K; ++k) {
     tp.j = k;
     tp.zfull = zfull_next;
+    tp.zw = zw_next;
     zfull_next = 0;
+    zw_next = 64;
     if (tp.p0 < k - 1) hipLaunchKernelGGL(k_sb_pend, dim3(nmat), dim3(kThreads), 0, st, tp);  // (update k-2 still pending: its corrections)
     panel();
     const int org = (kSbB * (k + 1)) & ~15;
@@ -138,7 +140,9 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
         hipLaunchKernelGGL(k_sb_sweep_one, dim3(nmat), dim3(64 * kSbOneWaves), sb_one_lds(n - org), st, tp);
         zfull_next = 1;
       } else {
-        hipLaunchKernelGGL(k_sb_sweep_lo<0>, grid, dim3(kThreads), 0, st, tp);
+        constexpr int BW0 = 16 * sb_ncb(0);
+        hipLaunchKernelGGL(k_sb_sweep_lo<0>, dim3(nmat, (n - org + BW0 - 1) / BW0), dim3(kThreads), 0, st, tp);
+        zw_next = BW0;
       }
     } else {  // the flush: updates p0 .. k-1 go into the stored matrix
       if (tp.nb == 1) hipLaunchKernelGGL(k_sb_sweep_lo<1>, grid, dim3(kThreads), 0, st, tp);
@@ -148,6 +152,7 @@ void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   }
   tp.j = K;
   tp.zfull = zfull_next;
+  tp.zw = zw_next;
   if (tp.p0 < K - 1) hipLaunchKernelGGL(k_sb_pend, dim3(nmat), dim3(kThreads), 0, st, tp);
   panel();
 }

@@ -63,7 +63,8 @@ int main(int argc, char** argv) {
       tp.p0 = k - np < 0 ? 0 : k - np;
       if (np && k < np) continue;
       {
-        const dim3 grid(nmat, nblk);
+        const int bw = 16 * (np == 0 ? sb_ncb(0) : 4);
+        const dim3 grid(nmat, (n - org + bw - 1) / bw);
         auto f = [&]() {
           if (np == 0) hipLaunchKernelGGL(k_sb_sweep_lo<0>, grid, dim3(kThreads), 0, 0, tp);
           else if (np == 1) hipLaunchKernelGGL(k_sb_sweep_lo<1>, grid, dim3(kThreads), 0, 0, tp);
