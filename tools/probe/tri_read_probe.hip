@@ -309,6 +309,132 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCB > 4 ? 2
   if (keep == 1.2345e300) sink[0] = keep;
 }
 
+// V7: a flush-like stream -- every tile read, NM MFMAs, written back -- in the matrices' row-major layout (16 pieces of 256 B per
+// tile, 12 KB apart) or with the tiles of the lower triangle stored one after the other (TILED: 4 KB contiguous per tile)
+template <int NM, bool TILED, bool WRITE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_rw(double2* __restrict__ Aall, int n, int org, double* sink) {
+  const int mat = blockIdx.x, bx = blockIdx.y;
+  double2* A = Aall + (int64_t)mat * n * n;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int cb0 = org + 64 * bx;
+  const int ntile = min(4, (n - cb0) / 16), nstep = (n - cb0) / 16;
+  v4d z1 = (v4d){0, 0, 0, 0}, z2 = z1;
+  const double b = 1.0 + lane;
+  // tile (I, J) of the lower triangle (I >= J, in units of 16) -> element offset of its first entry
+  auto tile_at = [&](int I, int J) -> int64_t { return TILED ? ((int64_t)I * (I + 1) / 2 + J) * 256 : ((int64_t)I * 16 * n + J * 16); };
+  const int64_t lofs = TILED ? lk * 16 + lr : (int64_t)lk * n + lr, rstep = TILED ? 64 : (int64_t)4 * n;
+  double2 cc[4];
+  if (wave < nstep) {
+    double2* cp = A + tile_at(cb0 / 16 + wave, cb0 / 16) + lofs;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) cc[reg] = cp[reg * rstep];
+  }
+  for (int t = wave; t < nstep; t += 4) {
+    const int ncb = min(t + 1, ntile);
+    for (int cb = 0; cb < ncb; ++cb) {
+      double2 cur[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) cur[reg] = cc[reg];
+      double2* me = A + tile_at(cb0 / 16 + t, cb0 / 16 + cb) + lofs;
+      if (cb + 1 < ncb || t + 4 < nstep) {
+        double2* nx = cb + 1 < ncb ? A + tile_at(cb0 / 16 + t, cb0 / 16 + cb + 1) + lofs : A + tile_at(cb0 / 16 + t + 4, cb0 / 16) + lofs;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cc[reg] = nx[reg * rstep];
+      }
+      v4d cre, cim;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) cre[reg] = cur[reg].x, cim[reg] = cur[reg].y;
+#pragma unroll
+      for (int i = 0; i < NM / 2; ++i) {
+        cre = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[i & 3].x, b, cre, 0, 0, 0);
+        cim = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[i & 3].y, b, cim, 0, 0, 0);
+      }
+      if (WRITE) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) me[reg * rstep] = make_double2(cre[reg] * 1e-300, cim[reg] * 1e-300);
+      } else {
+        z1 += cre, z2 += cim;
+      }
+    }
+  }
+  if (z1[0] + z2[1] == 1.2345e300) sink[0] = z1[0];
+}
+
+// V8: V7 (read, 48 MFMAs, write back) + the flush sweep's other traffic: per row step the I-side operand rows of the two pending
+// updates and of V' (NOPS arrays of 128 B per row, from an [n][8] array per matrix each) and the partial row sums (PART), for
+// blocks of 4 or 8 column tiles
+template <int NCB, int NOPS, bool PART, bool PREF, int WPE = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_flush(double2* __restrict__ Aall, const double2* __restrict__ Oall, double* __restrict__ Zp, int n, int org, double* sink) {
+  const int mat = blockIdx.x, bx = blockIdx.y;
+  double2* A = Aall + (int64_t)mat * n * n;
+  const double2* O = Oall + (int64_t)mat * n * 8 * 5;
+  double* Zpm = Zp + ((int64_t)mat * 12 + bx) * n * 16;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int cb0 = org + 16 * NCB * bx;
+  const int ntile = min(NCB, (n - cb0) / 16), nstep = (n - cb0) / 16;
+  v4d zr = (v4d){0, 0, 0, 0};
+  double2 cc[4], op[NOPS > 0 ? NOPS : 1][2], opn[NOPS > 0 ? NOPS : 1][2];
+  auto load_ops = [&](double2 (&o)[NOPS > 0 ? NOPS : 1][2], int r0) {
+#pragma unroll
+    for (int a = 0; a < NOPS; ++a) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) o[a][h] = O[((int64_t)a * n + r0 + lr) * 8 + lk + 4 * h];
+    }
+  };
+  if (wave < nstep) {
+    double2* cp = A + (int64_t)(cb0 + 16 * wave + lk) * n + cb0 + lr;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) cc[reg] = cp[(int64_t)4 * reg * n];
+    if (PREF) load_ops(opn, cb0 + 16 * wave);
+  }
+  for (int t = wave; t < nstep; t += 4) {
+    const int r0 = cb0 + 16 * t, ncb = min(t + 1, ntile);
+    double2* rowp = A + (int64_t)(r0 + lk) * n + cb0 + lr;
+    if (PREF) {
+#pragma unroll
+      for (int a = 0; a < NOPS; ++a) op[a][0] = opn[a][0], op[a][1] = opn[a][1];
+      if (t + 4 < nstep) load_ops(opn, r0 + 64);
+    } else {
+      load_ops(op, r0);
+    }
+    double bsum = 1.0 + lane;
+#pragma unroll
+    for (int a = 0; a < NOPS; ++a) bsum += op[a][0].x + op[a][1].y;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      if (cb < ncb) {
+        double2 cur[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cur[reg] = cc[reg];
+        double2* me = rowp + 16 * cb;
+        if (cb + 1 < ncb || t + 4 < nstep) {
+          double2* nx = cb + 1 < ncb ? rowp + 16 * (cb + 1) : rowp + (int64_t)64 * n;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) cc[reg] = nx[(int64_t)4 * reg * n];
+        }
+        v4d cre, cim;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) cre[reg] = cur[reg].x, cim[reg] = cur[reg].y;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+          cre = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[i & 3].x, bsum, cre, 0, 0, 0);
+          cim = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[i & 3].y, bsum, cim, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) me[(int64_t)4 * reg * n] = make_double2(cre[reg] * 1e-300, cim[reg] * 1e-300);
+        zr += cre;
+      }
+    }
+    if (PART && t > 0) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Zpm[(int64_t)(r0 + lk + 4 * reg) * 16 + lr] = zr[reg];
+    }
+  }
+  if (zr[0] == 1.2345e300) sink[0] = zr[0];
+}
+
 template <typename F>
 static double time_ms(F&& f, int reps) {
   hipEvent_t e0, e1;
@@ -336,6 +462,9 @@ int main(int argc, char** argv) {
   hipMalloc(&Vv, (size_t)nmat * n * 8 * sizeof(double2));
   hipMalloc(&Zp, (size_t)nmat * 12 * n * 16 * sizeof(double) + (1 << 22));
   k_fill<<<2048, 256>>>(Vv, (int64_t)nmat * n * 8);
+  double2* Ov;
+  hipMalloc(&Ov, (size_t)nmat * n * 8 * 5 * sizeof(double2));
+  k_fill<<<2048, 256>>>(Ov, (int64_t)nmat * n * 8 * 5);
   hipDeviceSynchronize();
   printf("# nmat %d, order %d: loads only; bytes = 4 KB per 16 x 16 tile of the lower triangle (V2 / V3 read up to 3 tiles more per block: not counted)\n", nmat, n);
   for (int k : {8, 32}) {
@@ -367,6 +496,26 @@ int main(int argc, char** argv) {
 #define NCB 8
     RUNF(0) RUNF(8) RUNF(29)
 #undef NCB
+#define RUNW(NM, TILED, WRITE)                                                                                  \
+  {                                                                                                            \
+    const double ms = time_ms([&]() { hipLaunchKernelGGL((k_rw<NM, TILED, WRITE>), grid, dim3(256), 0, 0, A, n, org, sink); }, 5); \
+    printf("k=%2d V7 %s, %2d MFMAs per tile, %s layout: %7.3f ms  %7.1f GB/s of tiles moved\n", k, WRITE ? "read + write back" : "read only", NM, TILED ? "tile-contiguous" : "row-major", ms, gb * (WRITE ? 2 : 1) / ms * 1e3); \
+  }
+    RUNW(16, false, false) RUNW(16, true, false) RUNW(0, false, true) RUNW(0, true, true) RUNW(16, false, true) RUNW(16, true, true) RUNW(48, false, true) RUNW(48, true, true)
+#define RUNX(NCB_, NOPS, PART, PREF)                                                                           \
+  {                                                                                                            \
+    const dim3 g3(nmat, (n - org + 16 * NCB_ - 1) / (16 * NCB_));                                              \
+    const double ms = time_ms([&]() { hipLaunchKernelGGL((k_flush<NCB_, NOPS, PART, PREF>), g3, dim3(256), 0, 0, A, Ov, Zp, n, org, sink); }, 5); \
+    printf("k=%2d V8 flush-like, %d tiles per row step, %d operand arrays%s%s: %7.3f ms\n", k, NCB_, NOPS, PREF ? " (a step ahead)" : "", PART ? ", partial sums stored" : "", ms); \
+  }
+    RUNX(4, 0, false, false) RUNX(4, 1, false, false) RUNX(4, 5, false, false) RUNX(4, 5, false, true) RUNX(4, 5, true, false) RUNX(4, 5, true, true)
+    RUNX(8, 0, false, false) RUNX(8, 5, false, false) RUNX(8, 5, true, false) RUNX(8, 5, true, true)
+    {
+      const dim3 g3(nmat, (n - org + 127) / 128);
+      const double ms1 = time_ms([&]() { hipLaunchKernelGGL((k_flush<8, 5, true, false, 1>), g3, dim3(256), 0, 0, A, Ov, Zp, n, org, sink); }, 5);
+      const double ms1p = time_ms([&]() { hipLaunchKernelGGL((k_flush<8, 5, true, true, 1>), g3, dim3(256), 0, 0, A, Ov, Zp, n, org, sink); }, 5);
+      printf("k=%2d V8 flush-like, 8 tiles per row step, 5 operand arrays, partial sums stored, ONE wave per SIMD: %7.3f ms (operands a step ahead: %7.3f)\n", k, ms1, ms1p);
+    }
     RUNM(16, false, 2) RUNM(16, false, 4) RUNM(16, false, 6) RUNM(8, true, 4) RUNM(8, true, 6) RUNM(48, false, 2) RUNM(48, false, 4)
   }
   return 0;
