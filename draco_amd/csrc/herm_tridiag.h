@@ -51,6 +51,7 @@ struct TdParams {
   int nb;              // two-stage reduction, stage 1: most two-sided updates left pending (1: every sweep applies its
                        // predecessor's update, rounds 3-5; herm_band.h), and p0, the oldest pending panel at this launch
   int p0;
+  int fused;           // 1: stage 1 as one kernel, a block per matrix (herm_band_fused.h)
   int one_block;       // 1: reading sweeps run as k_sb_sweep_one
   int zw;              // columns per block of the sweep before this panel (the width of its partial row sums)
   int zfull;           // 1: the sweep before this panel was the one-block-per-matrix form (k_sb_sweep_one): Z and M arrive complete

@@ -37,6 +37,9 @@
 #include "dense_kernels.h"
 #include "herm_tridiag.h"
 #include "herm_band.h"
+#ifdef DMM_AB  // forms measured slower than the shipped ones, kept buildable (make EXTRA=-DDMM_AB): "ml_reduce" = 5
+#include "herm_band_fused.h"
+#endif
 
 namespace {
 
@@ -115,6 +118,15 @@ int sb_pending(const dmm_ctx* ctx, int n, int64_t log_stride) {
 }
 void sb_reduce(TdParams& tp, int nmat, hipStream_t st) {
   const int n = tp.d.Np, K = sb_npanel(n);
+#ifdef DMM_AB
+  if (tp.fused && n <= 3 * kThreads && sb_fused_lds(n) <= kSbFusedLdsMax) {  // the whole of stage 1 as one launch, a block per matrix (herm_band_fused.h)
+    const size_t lds = sb_fused_lds(n);
+    if (n <= kThreads) hipLaunchKernelGGL(k_sb_fused<1>, dim3(nmat), dim3(kThreads), lds, st, tp);
+    else if (n <= 2 * kThreads) hipLaunchKernelGGL(k_sb_fused<2>, dim3(nmat), dim3(kThreads), lds, st, tp);
+    else hipLaunchKernelGGL(k_sb_fused<3>, dim3(nmat), dim3(kThreads), lds, st, tp);
+    return;
+  }
+#endif
   hipLaunchKernelGGL(k_sb_zero, dim3(12, nmat), dim3(kThreads), 0, st, tp);
   auto panel = [&]() {  // rows per thread by what is left of the matrix: the later panels take fewer registers (more blocks per CU)
     const int rows = (n - kSbB * tp.j + kThreads - 1) / kThreads;
@@ -1054,6 +1066,14 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     DMM_HIP(hipFuncSetAttribute((const void*)k_td_solve<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)td_sol));
     if (sb_usable(ctx, L.Np)) DMM_HIP(hipFuncSetAttribute((const void*)k_sb_chase, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_chase_lds(L.Np)));
     if (sb_usable(ctx, L.Np)) DMM_HIP(hipFuncSetAttribute((const void*)k_sb_sweep_one, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_one_lds(L.Np)));
+#ifdef DMM_AB
+    if (sb_usable(ctx, L.Np) && ctx->opt_ml_reduce == 5) {
+      const int fl = (int)std::min(sb_fused_lds(std::min(L.Np, 3 * kThreads)), kSbFusedLdsMax);
+      DMM_HIP(hipFuncSetAttribute((const void*)k_sb_fused<1>, hipFuncAttributeMaxDynamicSharedMemorySize, fl));
+      DMM_HIP(hipFuncSetAttribute((const void*)k_sb_fused<2>, hipFuncAttributeMaxDynamicSharedMemorySize, fl));
+      DMM_HIP(hipFuncSetAttribute((const void*)k_sb_fused<3>, hipFuncAttributeMaxDynamicSharedMemorySize, fl));
+    }
+#endif
   }
 
   std::vector<dmm_tile> tiles_c;
@@ -1190,6 +1210,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
         tp.two_stage = (ctx->opt_ml_eigen != 2 && sb_usable(ctx, n)) ? 1 : 0;
         tp.nb = sb_pending(ctx, n, tp.log_stride);
         tp.one_block = ctx->opt_ml_reduce == 3 ? 1 : 0;  // ("ml_reduce" = 3: every reading sweep as one block per matrix: herm_band.h)
+        tp.fused = ctx->opt_ml_reduce == 5 ? 1 : 0;
         tp.stop_tol = sb_stop_tol(ctx);
         tp.bs_U = nullptr;
         if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
@@ -1469,6 +1490,7 @@ int dmm_ml_run(dmm_plan* pl, const void* B, const void* mvis, const double* mwei
     tp.two_stage = sb_usable(ctx, n) ? 1 : 0;
     tp.nb = sb_pending(ctx, n, tp.log_stride);
     tp.one_block = ctx->opt_ml_reduce == 3 ? 1 : 0;
+    tp.fused = ctx->opt_ml_reduce == 5 ? 1 : 0;
     tp.stop_tol = bs_build ? 1e-16 : sb_stop_tol(ctx);  // (a basis must hold B B^H to 1e-15: its truncation enters the day's Gram matrix in first order)
     if (tp.two_stage) tp.log_cap = (int)std::min<int64_t>(sb_log_cap(tp.log_stride, n, runs), 0x7fffffff);
     if (nr > 0) tp.log_cap = (int)std::min<int64_t>(tp.log_cap, (int64_t)L.Np * L.Np - ((int64_t)3 * runs * sizeof(int) + 15) / 16);  // (QL's log and its chase headers end where X begins)

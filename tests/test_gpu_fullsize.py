@@ -494,8 +494,9 @@ def test_ml_two_stage_reduction_at_the_largest_order_the_lds_takes():
     """Orders 832 (the largest whose band plus the chase kernel's scratch fits the 160 KB of LDS) down to 64 in one
     pass: ntel = 820 on the telescope side (m <= 6), every sky-side order below it.  The reductions against each
     other -- stage 1 with every other two-sided update deferred (default), the same with its reading sweeps as one block
-    per matrix ("ml_reduce" = 3), with no update deferred ("ml_reduce" = 2: rounds 3-5's form), one-stage ("ml_reduce" =
-    1) -- and sampled rows against the oracle's SVD."""
+    per matrix ("ml_reduce" = 3), as one kernel ("ml_reduce" = 5: only in a `make EXTRA=-DDMM_AB` build, the default form
+    otherwise), with no update deferred ("ml_reduce" = 2: rounds 3-5's form), one-stage ("ml_reduce" = 1) -- and sampled
+    rows against the oracle's SVD."""
     import ctypes as C
 
     import torch
@@ -525,7 +526,7 @@ def test_ml_two_stage_reduction_at_the_largest_order_the_lds_takes():
     out, spans = {}, {}
     try:
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 2))
-        for red in (0, 3, 2, 1):
+        for red in (0, 3, 5, 2, 1):
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", red))
             _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 1))
             out[red] = eng.solve("ml", mv, mw, [0], lmax).cpu().numpy()
@@ -534,11 +535,12 @@ def test_ml_two_stage_reduction_at_the_largest_order_the_lds_takes():
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"profile", 0))
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_shortcut", 0))
         _lib.check(_lib.lib.dmm_ctx_set_option(ctx.handle, b"ml_reduce", 0))
-    for red in (0, 3, 2):
+    for red in (0, 3, 5, 2):
         assert spans[red][0] > 0 and spans[red][1] > 0 and spans[red][2] == 0, spans  # two-stage only
     assert spans[1][0] == 0 and spans[1][2] > 0, spans  # one-stage only
     assert np.all(np.isfinite(out[0]))
     assert _rel(out[0], out[1]) < 1e-9
     assert _rel(out[2], out[1]) < 1e-9
     assert _rel(out[3], out[1]) < 1e-9
+    assert _rel(out[5], out[1]) < 1e-9
     _check_rows_against_oracle_svd(out[0], 36, mv, mw, 0, 0, (0, 6, 7, 100, 195, 209, 210), 1e-8)
